@@ -1,0 +1,160 @@
+"""ORACLE tooling — generates tests/golden/*.npz by importing the REAL reference (authoring container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+Needs /root/reference (read-only).  The reference never travels: only inputs' seeds (regenerated through
+zutis_amd/detgen.py) and the reference's OUTPUTS are stored.  Stubs follow SURVEY.md Appendix B:
+`clip` (random-init clip_arch.CLIP), `torchvision.ops.masks_to_boxes`, `pycocotools.mask.encode`, and the
+SciPy>=1.14 `cg(tol->rtol)` shim.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+from zutis_amd import detgen
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def install_stubs(cfg: detgen.ZutisConfig):
+    tv = types.ModuleType("torchvision")
+    tvo = types.ModuleType("torchvision.ops")
+
+    def masks_to_boxes(masks):
+        out = torch.zeros((masks.shape[0], 4), dtype=torch.float32)
+        for i, m in enumerate(masks):
+            ys, xs = torch.where(m != 0)
+            out[i] = torch.tensor([xs.min(), ys.min(), xs.max(), ys.max()], dtype=torch.float32)
+        return out
+    tvo.masks_to_boxes = masks_to_boxes
+    tv.ops = tvo
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.ops"] = tvo
+    pc = types.ModuleType("pycocotools")
+    pcm = types.ModuleType("pycocotools.mask")
+    pcm.encode = lambda m: {"size": list(m.shape), "mask": np.array(m)}   # stand-in: masks compared, not RLE bytes
+    pc.mask = pcm
+    sys.modules["pycocotools"] = pc
+    sys.modules["pycocotools.mask"] = pcm
+    clip = types.ModuleType("clip")
+
+    def load(name, device=None):
+        from networks.clip_arch import CLIP
+        m = CLIP(embed_dim=cfg.embed_dim, image_resolution=cfg.patch * cfg.grid, vision_layers=cfg.layers,
+                 vision_width=cfg.width, vision_patch_size=cfg.patch, context_length=8, vocab_size=64,
+                 transformer_width=64, transformer_heads=1, transformer_layers=1)
+        return m.float().eval(), None
+
+    def tokenize(texts):
+        t = torch.zeros((len(texts), 8), dtype=torch.long)
+        t[:, 0] = 1
+        t[:, -1] = 63
+        return t
+    clip.load, clip.tokenize = load, tokenize
+    sys.modules["clip"] = clip
+
+
+def build_reference_zutis(cfg: detgen.ZutisConfig, n_cat: int, seed: int = 1234):
+    install_stubs(cfg)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for m in [k for k in sys.modules if k.startswith("networks") or k.startswith("utils")]:
+        del sys.modules[m]
+    from networks.zutis import ZUTIS
+    net = ZUTIS(categories=[f"c{i}" for i in range(n_cat)], clip_arch="ViT-B/16", n_queries=cfg.n_queries,
+                n_decoder_layers=cfg.dec_layers, n_heads=cfg.dec_heads, device=torch.device("cpu"))
+    # decoder ff is fixed at 2048 by the reference ctor; rebuild layers' FFN only through state_dict shapes
+    sd = {k: torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg, seed).items()}
+    net.load_state_dict(sd, strict=True)
+    net.text_embeddings = torch.from_numpy(detgen.text_embeddings(n_cat, cfg.embed_dim))
+    return net.eval().requires_grad_(False)
+
+
+def gen_e2e(tag: str, cfg: detgen.ZutisConfig, b: int, H: int, W: int, n_cat: int, size, full: bool):
+    net = build_reference_zutis(cfg, n_cat)
+    x = torch.from_numpy(detgen.images(b, H, W))
+    with torch.no_grad():
+        enc_tokens, h, w = net.encoder(x)
+        out = net(x)
+        labels = net.predict(out, mask_type="semantic", size=size)
+        logits_full = net.predict(out, mask_type="semantic", size=size, return_logits=True)
+        logits_lo = net.predict(out, mask_type="semantic", size=None, return_logits=True)
+    d = dict(b=b, H=H, W=W, n_cat=n_cat, size=np.array(size), labels=labels.astype(np.uint8 if n_cat < 256 else np.int16),
+             logits_lo=logits_lo.numpy())
+    if full:   # tiny config: store everything
+        d.update(enc_tokens=enc_tokens.numpy(), mask_proposals=out["mask_proposals"].numpy(),
+                 patch_tokens=out["patch_tokens"].numpy(), logits_full=logits_full.numpy())
+        for nms in ("hard", "linear", "gaussian", None):
+            with torch.no_grad():
+                preds = net.predict(out, mask_type="instance", size=size, image_ids=list(range(b)), nms_type=nms)
+            key = str(nms).lower()
+            d[f"inst_{key}_n"] = len(preds)
+            if len(preds):
+                d[f"inst_{key}_masks"] = np.packbits(np.stack([p["segmentation"]["mask"] for p in preds]).astype(bool), axis=-1)
+                d[f"inst_{key}_score"] = np.array([p["score"] for p in preds], np.float64)
+                d[f"inst_{key}_cat"] = np.array([p["category_id"] for p in preds], np.int64)
+                d[f"inst_{key}_img"] = np.array([p["image_id"] for p in preds], np.int64)
+                d[f"inst_{key}_bbox"] = np.array([p["bbox"] for p in preds], np.float64)
+    else:      # full-size: subsample the big tensors
+        d.update(enc_tokens_sub=enc_tokens.numpy()[:, ::7, ::5], mask_proposals_sub=out["mask_proposals"].numpy()[:, :, ::9, ::3, ::3],
+                 patch_tokens_sub=out["patch_tokens"].numpy()[:, ::3, ::3, ::4])
+    np.savez_compressed(os.path.join(GOLD, f"e2e_{tag}.npz"), **d)
+    print(tag, "labels hist", np.bincount(labels.reshape(-1))[:10], {k: getattr(v, "shape", v) for k, v in d.items()})
+
+
+def gen_ops():
+    """Per-op vectors from reference modules / the exact torch calls the reference makes."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import torch.nn.functional as F
+    from networks.clip_arch import VisionTransformer
+    from networks.positional_embedding import PositionEmbeddingSine
+    from utils.running_score import RunningScore
+    from utils.iou import compute_iou
+    d = {}
+    for g, (h, w) in [(14, (21, 21)), (14, (32, 32)), (7, (7, 7)), (14, (30, 40)), (4, (5, 7))]:
+        pe = torch.from_numpy(detgen.det_normal(f"pe_{g}", (g * g + 1, 48)))
+        d[f"posembed_g{g}_{h}x{w}"] = VisionTransformer.interpolate_positional_embedding(pe, (h, w))[0].numpy()
+    for (h, w) in [(10, 14), (12, 17)]:
+        pos = PositionEmbeddingSine(96 // 2 if h == 10 else 384, normalize=True)(torch.zeros(1, 1, h, w))
+        d[f"sine_{h}x{w}"] = pos[0].permute(1, 2, 0).reshape(h * w, -1).numpy()
+    x = torch.from_numpy(detgen.det_normal("up2", (2, 5, 7, 24)))
+    d["up2"] = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear").permute(0, 2, 3, 1).numpy()
+    lo = torch.from_numpy(detgen.det_normal("argmax_lo", (2, 9, 10, 14)))
+    lo[0, 3] = lo[0, 5]                      # exact ties between classes 3 and 5 everywhere on image 0
+    lo[1, :, 2:4] = 0.25                     # all-class ties on two rows of image 1
+    d["argmax_lo"] = lo.numpy()
+    d["argmax_labels_80x112"] = torch.argmax(F.interpolate(lo, size=(80, 112), mode="bilinear"), dim=1).numpy()
+    d["argmax_labels_77x45"] = torch.argmax(F.interpolate(lo, size=(77, 45), mode="bilinear"), dim=1).numpy()
+    rs = RunningScore(7)
+    gt = (np.abs(detgen.det_normal("gt", (3, 20, 30))) * 3).astype(np.int64)
+    gt[0, :2] = 255
+    pr = (np.abs(detgen.det_normal("pr", (3, 20, 30))) * 3).astype(np.int64) % 7
+    rs.update(gt, pr)
+    sc, iu = rs.get_scores()
+    d["rs_gt"], d["rs_pred"], d["rs_hist"] = gt, pr, rs.confusion_matrix
+    d["rs_scores"] = np.array([sc["Pixel Acc"], sc["Mean Acc"], sc["FreqW Acc"], sc["Mean IoU"]])
+    m1 = detgen.det_normal("m1", (16, 16)) > 0
+    m2 = detgen.det_normal("m2", (16, 16)) > 0.3
+    d["iou_m1"], d["iou_m2"], d["iou"] = m1, m2, np.array(compute_iou(m1, m2))
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **d)
+    print("ops:", {k: v.shape for k, v in d.items()})
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference not mounted"
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    gen_ops()
+    gen_e2e("tiny", detgen.TINY, b=2, H=80, W=112, n_cat=7, size=(80, 112), full=True)
+    gen_e2e("vitb16_336", detgen.VIT_B16, b=1, H=336, W=336, n_cat=81, size=(336, 336), full=False)
+    gen_e2e("vitb32_224", detgen.VIT_B32, b=1, H=224, W=224, n_cat=81, size=(224, 224), full=False)
