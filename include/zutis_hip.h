@@ -1,0 +1,124 @@
+/* libzutis_hip — C ABI of the MI355X (gfx950) kernels behind the ZUTIS dense-prediction hot path.
+ *
+ * The reference (NoelShin/zutis) has no FFI layer: its boundary is the Python nn.Module call surface
+ * (SURVEY.md §8b).  This header is the boundary *underneath* this build's Python mirror of that surface
+ * (zutis_amd/dropin/networks/zutis.py ...): every entry point replaces one stock-op sequence of the reference,
+ * cited per function as file:line relative to the reference root.
+ *
+ * Conventions
+ *   - extern "C"; every entry returns int: 0 = ok, <0 = error (ZH_ERR_*); zh_last_error() gives thread-local text.
+ *   - All pointers are raw DEVICE pointers owned by the caller (PyTorch tensors); the library never allocates,
+ *     frees or synchronises.  Scratch is passed in (void* workspace, size_t bytes) with a *_workspace_size query.
+ *   - Last argument: the hipStream_t to launch on (pass torch.cuda.current_stream().cuda_stream).
+ *   - Layout: contiguous row-major, tokens channels-last [B, T, D].  "f16" = IEEE half; fp32 accumulate everywhere.
+ *   - Re-entrant; no global mutable state.
+ */
+#ifndef ZUTIS_HIP_H
+#define ZUTIS_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
+
+#define ZH_OK 0
+#define ZH_ERR_ARG (-1)
+#define ZH_ERR_HIP (-2)
+#define ZH_ERR_WORKSPACE (-3)
+
+/* GEMM epilogue activations */
+#define ZH_ACT_NONE 0
+#define ZH_ACT_QUICKGELU 1 /* x*sigmoid(1.702x)  networks/clip_arch.py:295-297 */
+#define ZH_ACT_RELU 2      /* networks/zutis.py:546-549; networks/transformer.py:289 */
+#define ZH_ACT_SIGMOID 3   /* networks/zutis.py:209 */
+#define ZH_ACT_GELU_ERF 4  /* nn.GELU, networks/selfmask/vision_transformer.py:79 */
+
+int zh_version(void);
+const char* zh_arch(void);
+const char* zh_last_error(void);
+
+/* C[b][m][n] = act(sum_k A[b][m][k]*W[b][n][k] + bias[n]) + residual[b][m % res_rows][n]
+ * A [M,K] f16 (lda), W [N,K] f16 (ldw) — torch Linear layout; C f32 or f16 (out_f16); bias/residual f32 or NULL.
+ * K % 64 == 0; lda/ldw % 8 == 0.  residual may alias C (in-place x += ...).
+ * Replaces: conv1-as-GEMM clip_arch.py:378; in_proj/out_proj/c_fc/c_proj clip_arch.py:314-320; MLP zutis.py:546-549;
+ * decoder projections + FFN transformer.py:272-290; einsum("bdqc,bhwc->bdqhw")+sigmoid zutis.py:196-198,209 (batched);
+ * einsum("bhwn,nc->bhwc") zutis.py:319; einsum("nc,bchw->bnhw") zutis.py:361-365 (batched, strideA = 0). */
+int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, long strideW,
+                void* C, long ldc, long strideC, int out_f16,
+                const float* bias, const float* residual, long ldr, long strideR, int res_rows,
+                int act, int M, int N, int K, int batch, zh_stream_t stream);
+
+/* Flash attention: O = softmax(scale * Q K^T) V per (image, head); Q [Tq, heads*dh] rows with stride ldq, etc.
+ * f16 in/out, fp32 softmax/accumulate; head_dim in {64, 96}.
+ * Replaces nn.MultiheadAttention core at clip_arch.py:314-316, transformer.py:272-286,
+ * selfmask/vision_transformer.py:110-133 (which materialises [B,heads,T,T]). */
+int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                     const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
+                     int batch, int heads, int Tq, int Tk, int head_dim, float scale, zh_stream_t stream);
+
+/* Row LayerNorm (biased variance, eps inside sqrt): clip_arch.py:286-292, transformer.py:249-251, 140-150.
+ * in_row(r) = (r / in_group_rows)*in_group_stride + in_offset + r % in_group_rows   (drops the cls token for ln_post,
+ * clip_arch.py:403-404); out_row(r) uses the same form (stacks decoder layers as [B,L,Q,D], transformer.py:140-150).
+ * Outputs (any may be NULL): y f32, y f16, (y + add[r % add_rows]) f16 / f32
+ * (query_pos add, transformer.py:268,277). gamma/beta both NULL => no affine. */
+int zh_layernorm_f32(const float* x, long in_group_rows, long in_group_stride, long in_offset,
+                     long out_group_rows, long out_group_stride, long out_offset,
+                     const float* gamma, const float* beta, float eps,
+                     float* out_f32, void* out_f16, void* out_f16_plus, float* out_f32_plus,
+                     const float* add, int add_rows, int rows, int D, zh_stream_t stream);
+
+/* cat(class_embedding, patch_emb) + pos_embed, then ln_pre: clip_arch.py:384-397.  out [B,T,D] f32. */
+int zh_assemble_tokens_ln(const float* patch_emb, const float* class_embedding, const float* pos_embed,
+                          const float* gamma, const float* beta, float eps, float* out,
+                          int B, int T, int D, zh_stream_t stream);
+
+/* x / (||x||_2 + eps) per row: queries (eps = 0) zutis.py:515; averaged tokens (eps = 1e-7) zutis.py:413. */
+int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, zh_stream_t stream);
+
+/* F.layer_norm over the whole (h,w,c) volume per image (no affine) then x/(||x||_c + l2_eps): zutis.py:320-322. */
+size_t zh_global_ln_l2_workspace_size(int B, int M, int C);
+int zh_global_ln_l2(const float* x, float* out_f32, void* out_f16, float eps, float l2_eps,
+                    int B, int M, int C, void* workspace, size_t workspace_bytes, zh_stream_t stream);
+
+/* im2col of the stride==kernel patch conv (pure re-index): clip_arch.py:340,378; selfmask/vision_transformer.py:182.
+ * out f16 [B*gh*gw, Kpad], k = c*p*p + i*p + j, zero padded. */
+int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, zh_stream_t stream);
+
+/* Bicubic positional-embedding resample: clip_arch.py:356-374 (scale = float(1/((h+0.1)/g))) and
+ * selfmask/vision_transformer.py:377-401 (scale = g/h).  pos [has_cls + g*g, D] -> out [has_cls + h*w, D]. */
+int zh_posembed_bicubic(const float* pos, float* out, int grid, int h, int w, int D, float scale_h, float scale_w,
+                        int has_cls, zh_stream_t stream);
+
+/* F.interpolate(scale_factor=2, bilinear) on channels-last tokens: zutis.py:491-495. */
+int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, zh_stream_t stream);
+
+/* PositionEmbeddingSine(normalize=True): positional_embedding.py:29-52 -> [h*w, D] channels-last. */
+int zh_sine_pe(float* out, int h, int w, int D, float temperature, zh_stream_t stream);
+
+/* memory + pos (transformer.py:281): out f16 = a f16 + add f32[r % add_rows]. */
+int zh_add_rowperiodic_f16(const void* a, const float* add, void* out, long rows, int D, int add_rows, zh_stream_t stream);
+
+/* f32 -> f16 (optionally + add[r % add_rows]). */
+int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, zh_stream_t stream);
+
+/* argmax_c(F.interpolate(logits, size=(H,W), bilinear)) fused, bit-identical to ATen incl. ties: zutis.py:366-372.
+ * logits_lo f32 [B,n,h,w] -> labels int64 [B,H,W].  scale_* = float32(in)/float32(out) computed by the host. */
+int zh_upsample_argmax(const float* logits_lo, long long* labels, int B, int n, int h, int w, int H, int W,
+                       float scale_h, float scale_w, zh_stream_t stream);
+
+/* F.interpolate(x, size, bilinear) on `planes` NCHW planes (return_logits zutis.py:368-371; masks zutis.py:422-423);
+ * optional mask_u8 = value > threshold. */
+int zh_upsample_bilinear_nchw(const float* x, float* out, unsigned char* mask_u8, float threshold, long planes,
+                              int h, int w, int H, int W, float scale_h, float scale_w, zh_stream_t stream);
+
+/* RunningScore._fast_hist: utils/running_score.py:11-16.  hist_accum int64 [n*n] += bincount(n*gt+pred), 0<=gt<n. */
+int zh_confusion_hist(const long long* label_true, const long long* label_pred, long long* hist_accum, long total,
+                      int n_class, zh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZUTIS_HIP_H */

@@ -134,7 +134,7 @@ def gen_ops():
     lo[1, :, 2:4] = 0.25                     # all-class ties on two rows of image 1
     d["argmax_lo"] = lo.numpy()
     d["argmax_labels_80x112"] = torch.argmax(F.interpolate(lo, size=(80, 112), mode="bilinear"), dim=1).numpy()
-    d["argmax_labels_77x45"] = torch.argmax(F.interpolate(lo, size=(77, 45), mode="bilinear"), dim=1).numpy()
+    d["argmax_labels_77x145"] = torch.argmax(F.interpolate(lo, size=(77, 145), mode="bilinear"), dim=1).numpy()
     rs = RunningScore(7)
     gt = (np.abs(detgen.det_normal("gt", (3, 20, 30))) * 3).astype(np.int64)
     gt[0, :2] = 255

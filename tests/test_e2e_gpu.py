@@ -1,0 +1,82 @@
+"""-m gpu: the HIP engine end to end against (a) the reference's golden outputs and (b) the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3   # north_star: fp32 logits within 1e-3
+MASK_TOL = 2e-3    # sigmoid mask proposals (fp16 MFMA operands, fp32 accumulate)
+
+
+def _engine(cfg, dev):
+    from zutis_amd import detgen
+    from zutis_amd.engine import ZutisEngine
+    P = {k: torch.from_numpy(v).to(dev) for k, v in detgen.zutis_state_dict(cfg).items()}
+    return ZutisEngine(P, cfg.patch, cfg.dec_heads)
+
+
+@pytest.mark.parametrize("tag,cfgname", [("tiny", "TINY"), ("vitb32_224", "VIT_B32"), ("vitb16_336", "VIT_B16")])
+def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname):
+    from zutis_amd import detgen
+    cfg = getattr(detgen, cfgname)
+    g = np.load(f"{golden_dir}/e2e_{tag}.npz")
+    b, H, W, n = int(g["b"]), int(g["H"]), int(g["W"]), int(g["n_cat"])
+    eng = _engine(cfg, dev)
+    x = torch.from_numpy(detgen.images(b, H, W)).to(dev)
+    text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
+    out = eng.forward(x)
+    lo = eng.semantic_logits_lowres(out["patch_tokens"], text).cpu().numpy()
+    err = np.abs(lo - g["logits_lo"]).max()
+    assert err < LOGIT_TOL, err
+    labels = eng.predict_semantic(out["patch_tokens"], text, tuple(g["size"])).cpu().numpy()
+    agree = (labels == g["labels"]).mean()
+    assert agree > 0.995, agree
+    mp, pt = out["mask_proposals"].cpu().numpy(), out["patch_tokens"].cpu().numpy()
+    assert mp.min() >= 0 and mp.max() <= 1
+    if "mask_proposals" in g:
+        assert np.abs(mp - g["mask_proposals"]).max() < MASK_TOL
+        assert np.abs(pt - g["patch_tokens"]).max() < LOGIT_TOL
+        lf = eng.predict_semantic(out["patch_tokens"], text, tuple(g["size"]), return_logits=True).cpu().numpy()
+        assert np.abs(lf - g["logits_full"]).max() < LOGIT_TOL
+    else:
+        assert np.abs(mp[:, :, ::9, ::3, ::3] - g["mask_proposals_sub"]).max() < MASK_TOL
+        assert np.abs(pt[:, ::3, ::3, ::4] - g["patch_tokens_sub"]).max() < LOGIT_TOL
+    print(f"{tag}: logits maxerr {err:.2e}, label agreement {agree:.5f}")
+
+
+def test_engine_vs_oracle_ragged_batch(dev):
+    """Non-square, non-multiple-of-patch input, batch 3, against the CPU oracle on the same seeded inputs."""
+    from zutis_amd import detgen
+    from oracle import zutis_ref as O
+    cfg = detgen.TINY
+    eng = _engine(cfg, dev)
+    P = O.to_torch_params(detgen.zutis_state_dict(cfg))
+    x = torch.from_numpy(detgen.images(3, 75, 123))
+    text = torch.from_numpy(detgen.text_embeddings(5, cfg.embed_dim))
+    with torch.no_grad():
+        ref = O.zutis_forward(P, x, cfg.patch, cfg.dec_heads)
+        ref_lo = O.semantic_logits_lowres(ref["patch_tokens"], text).numpy()
+    out = eng.forward(x.to(dev))
+    assert out["mask_proposals"].shape == ref["mask_proposals"].shape
+    lo = eng.semantic_logits_lowres(out["patch_tokens"], text.to(dev)).cpu().numpy()
+    assert np.abs(lo - ref_lo).max() < LOGIT_TOL
+    assert np.abs(out["mask_proposals"].cpu().numpy() - ref["mask_proposals"].numpy()).max() < MASK_TOL
+    # argmax kernel is bit-exact GIVEN the same low-res logits (integer output)
+    from oracle import resample as R
+    lab = torch.empty((3, 75, 123), dtype=torch.int64, device=dev)
+    from zutis_amd import ops
+    ops.upsample_argmax(torch.from_numpy(ref_lo).to(dev), lab, 3, 5, ref_lo.shape[2], ref_lo.shape[3], 75, 123)
+    assert np.array_equal(lab.cpu().numpy(), R.bilinear_argmax_nchw(ref_lo, 75, 123))
+
+
+def test_engine_repack_on_weight_change(dev):
+    from zutis_amd import detgen
+    cfg = detgen.TINY
+    eng = _engine(cfg, dev)
+    x = torch.from_numpy(detgen.images(1, 64, 64)).to(dev)
+    a = eng.forward(x)["patch_tokens"].clone()
+    with torch.no_grad():
+        eng.params["encoder.proj"].mul_(-1.0)
+    b = eng.forward(x)["patch_tokens"]
+    assert not torch.allclose(a, b)

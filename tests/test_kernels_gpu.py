@@ -1,0 +1,232 @@
+"""-m gpu: every HIP kernel (through the C ABI) against a plain fp32 torch / oracle reference of the same op."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+f16, f32 = torch.float16, torch.float32
+
+
+def _randn(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (442, 768, 768), (100, 1764, 768), (81, 1764, 512), (37, 50, 128)])
+@pytest.mark.parametrize("out_f16", [False, True])
+def test_gemm_plain(dev, M, N, K, out_f16):
+    from zutis_amd import ops
+    A, W = _randn((M, K), 1).to(f16), _randn((N, K), 2).to(f16)
+    ref = A.float() @ W.float().t()
+    out = torch.empty((M, N), dtype=f16 if out_f16 else f32, device=dev)
+    ops.gemm(A.to(dev), W.to(dev), out)
+    tol = 2e-2 * math.sqrt(K / 64) if out_f16 else 1e-3
+    assert torch.allclose(out.float().cpu(), ref, atol=tol, rtol=2e-3 if out_f16 else 1e-4)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_gemm_epilogues(dev, act):
+    from zutis_amd import ops
+    M, N, K = 200, 260, 128
+    A, W = _randn((M, K), 3, 0.5).to(f16), _randn((N, K), 4, 0.2).to(f16)
+    bias, res = _randn((N,), 5), _randn((50, N), 6)
+    y = A.float() @ W.float().t() + bias
+    y = [y, y * torch.sigmoid(1.702 * y), F.relu(y), torch.sigmoid(y), F.gelu(y)][act]
+    ref = y + res[torch.arange(M) % 50]
+    out = torch.empty((M, N), dtype=f32, device=dev)
+    ops.gemm(A.to(dev), W.to(dev), out, bias=bias.to(dev), residual=res.to(dev), res_rows=50, act=act)
+    assert torch.allclose(out.cpu(), ref, atol=2e-4, rtol=1e-4)
+
+
+def test_gemm_inplace_residual_and_batched(dev):
+    from zutis_amd import ops
+    B, M, N, K = 3, 100, 140, 64
+    A, W = _randn((B, M, K), 7).to(f16), _randn((B, N, K), 8).to(f16)
+    X = _randn((B, M, N), 9)
+    ref = torch.einsum("bmk,bnk->bmn", A.float(), W.float()) + X
+    Xd = X.to(dev).contiguous()
+    ops.gemm(A.to(dev), W.to(dev), Xd, residual=Xd, res_rows=M, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldr=N, batch=B,
+             strideA=M * K, strideW=N * K, strideC=M * N, strideR=M * N)
+    assert torch.allclose(Xd.cpu(), ref, atol=1e-3, rtol=1e-4)
+    # shared A (stride 0), unaligned N -> scalar epilogue
+    N2 = 37
+    W2 = _randn((B, N2, K), 10).to(f16)
+    out = torch.empty((B, M, N2), dtype=f32, device=dev)
+    ops.gemm(A[0].to(dev), W2.to(dev), out, M=M, N=N2, K=K, lda=K, ldw=K, ldc=N2, batch=B, strideA=0, strideW=N2 * K, strideC=M * N2)
+    assert torch.allclose(out.cpu(), torch.einsum("mk,bnk->bmn", A[0].float(), W2.float()), atol=1e-3, rtol=1e-4)
+
+
+def test_gemm_rejects_bad_k(dev):
+    from zutis_amd import ops, _lib
+    A, W = torch.zeros((8, 40), dtype=f16, device=dev), torch.zeros((8, 40), dtype=f16, device=dev)
+    with pytest.raises(_lib.ZutisHipError):
+        ops.gemm(A, W, torch.empty((8, 8), dtype=f32, device=dev))
+
+
+@pytest.mark.parametrize("dh,H,Tq,Tk", [(64, 3, 50, 50), (64, 12, 442, 442), (96, 2, 5, 140), (96, 8, 100, 1764), (96, 8, 100, 100), (64, 2, 130, 67)])
+def test_attention(dev, dh, H, Tq, Tk):
+    from zutis_amd import ops
+    B, D = 2, H * dh
+    q, k, v = _randn((B, Tq, D), 11).to(f16), _randn((B, Tk, D), 12).to(f16), _randn((B, Tk, D), 13).to(f16)
+    qh, kh, vh = (t.float().view(B, -1, H, dh).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(dh), -1) @ vh).transpose(1, 2).reshape(B, Tq, D)
+    o = torch.empty((B, Tq, D), dtype=f16, device=dev)
+    ops.attention(q.to(dev), k.to(dev), v.to(dev), o, batch=B, heads=H, Tq=Tq, Tk=Tk, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D,
+                  strideQ=Tq * D, strideK=Tk * D, strideV=Tk * D, strideO=Tq * D)
+    err = (o.float().cpu() - ref).abs().max().item()
+    assert err < 4e-3, err
+
+
+def test_attention_spike_forces_rescale(dev):
+    """One key far above the rest in a LATE tile forces the online-softmax rescale branch (and alpha != 1)."""
+    from zutis_amd import ops
+    B, H, dh, Tq, Tk = 1, 1, 64, 32, 300
+    q, k, v = _randn((B, Tq, dh), 21), _randn((B, Tk, dh), 22) * 0.1, _randn((B, Tk, dh), 23)
+    k[0, 250] = q[0, 3] * 4.0
+    q, k, v = q.to(f16), k.to(f16), v.to(f16)
+    ref = torch.softmax(q.float() @ k.float().transpose(-1, -2) / 8.0, -1) @ v.float()
+    o = torch.empty((B, Tq, dh), dtype=f16, device=dev)
+    ops.attention(q.to(dev), k.to(dev), v.to(dev), o, batch=B, heads=H, Tq=Tq, Tk=Tk, head_dim=dh, ldq=dh, ldk=dh, ldv=dh, ldo=dh,
+                  strideQ=Tq * dh, strideK=Tk * dh, strideV=Tk * dh, strideO=Tq * dh)
+    assert (o.float().cpu() - ref).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("D", [192, 384, 768, 1024])
+def test_layernorm(dev, D):
+    from zutis_amd import ops
+    B, T = 3, 11
+    x, g, b = _randn((B * T, D), 31) * 3 + 1, _randn((D,), 32) * 0.1 + 1, _randn((D,), 33) * 0.1
+    add = _randn((T, D), 34)
+    ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    o32 = torch.empty((B * T, D), dtype=f32, device=dev)
+    o16 = torch.empty((B * T, D), dtype=f16, device=dev)
+    p16 = torch.empty((B * T, D), dtype=f16, device=dev)
+    p32 = torch.empty((B * T, D), dtype=f32, device=dev)
+    ops.layernorm(x.to(dev), g.to(dev), b.to(dev), 1e-5, B * T, D, out_f32=o32, out_f16=o16, out_f16_plus=p16, out_f32_plus=p32,
+                  add=add.to(dev), add_rows=T)
+    assert torch.allclose(o32.cpu(), ref, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(o16.float().cpu(), ref, atol=4e-3, rtol=2e-3)
+    assert torch.allclose(p32.cpu(), ref + add.repeat(B, 1), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(p16.float().cpu(), ref + add.repeat(B, 1), atol=6e-3, rtol=2e-3)
+    # drop-cls input mapping + stacked output mapping, no affine, eps 1e-6
+    o = torch.zeros((B * 2 * (T - 1), D), dtype=f32, device=dev)
+    ops.layernorm(x.to(dev), None, None, 1e-6, B * (T - 1), D, out_f32=o, in_group_rows=T - 1, in_group_stride=T, in_offset=1,
+                  out_group_rows=T - 1, out_group_stride=2 * (T - 1), out_offset=T - 1)
+    ref2 = F.layer_norm(x.view(B, T, D)[:, 1:], (D,), None, None, 1e-6)
+    got = o.cpu().view(B, 2, T - 1, D)
+    assert torch.allclose(got[:, 1], ref2, atol=2e-5, rtol=1e-5)
+    assert torch.all(got[:, 0] == 0)
+
+
+def test_assemble_tokens_ln(dev):
+    from zutis_amd import ops
+    B, hw, D = 2, 35, 192
+    pe, cls, pos = _randn((B * hw, D), 41), _randn((D,), 42), _randn((1 + hw, D), 43)
+    g, b = _randn((D,), 44) * 0.1 + 1, _randn((D,), 45) * 0.1
+    t = torch.cat([cls[None, None].expand(B, 1, D), pe.view(B, hw, D)], 1) + pos[None]
+    ref = F.layer_norm(t, (D,), g, b, 1e-5)
+    out = torch.empty((B, 1 + hw, D), dtype=f32, device=dev)
+    ops.assemble_tokens_ln(pe.to(dev), cls.to(dev), pos.to(dev), g.to(dev), b.to(dev), 1e-5, out, B, 1 + hw, D)
+    assert torch.allclose(out.cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
+def test_l2norm_and_global_ln(dev):
+    from zutis_amd import ops
+    x = _randn((50, 768), 51)
+    o = torch.empty((50, 768), dtype=f32, device=dev)
+    ops.l2norm_rows(x.to(dev), 50, 768, out_f32=o)
+    assert torch.allclose(o.cpu(), x / x.norm(dim=-1, keepdim=True), atol=1e-6, rtol=1e-5)
+    for (B, h, w, C) in [(2, 10, 14, 64), (3, 42, 42, 512)]:
+        t = _randn((B, h, w, C), 52) * 2 + 0.3
+        ref = F.layer_norm(t, t.shape[1:])
+        ref = ref / (ref.norm(dim=-1, keepdim=True) + 1e-7)
+        o = torch.empty((B, h, w, C), dtype=f32, device=dev)
+        o16 = torch.empty((B, h, w, C), dtype=f16, device=dev)
+        ops.global_ln_l2(t.to(dev), B, h * w, C, out_f32=o, out_f16=o16)
+        assert torch.allclose(o.cpu(), ref, atol=2e-6, rtol=1e-5)
+        assert torch.allclose(o16.float().cpu(), ref, atol=1e-3)
+
+
+def test_im2col_matches_conv(dev):
+    from zutis_amd import ops
+    B, p, D = 2, 16, 64
+    x, wc = _randn((B, 3, 80, 117), 61), _randn((D, 3, p, p), 62) * 0.05
+    ref = F.conv2d(x.half().float(), wc.half().float(), stride=p)
+    gh, gw = ref.shape[-2:]
+    col = torch.empty((B * gh * gw, 3 * p * p), dtype=f16, device=dev)
+    ops.im2col(x.to(dev), col, p, 3 * p * p)
+    out = torch.empty((B * gh * gw, D), dtype=f32, device=dev)
+    ops.gemm(col, wc.reshape(D, -1).to(f16).to(dev), out)
+    assert torch.allclose(out.cpu().view(B, gh * gw, D), ref.flatten(2).transpose(1, 2), atol=2e-3, rtol=1e-3)
+
+
+def test_posembed_bicubic_vs_golden_and_oracle(dev, golden_dir):
+    from zutis_amd import ops, detgen
+    from oracle import resample as R
+    g = np.load(f"{golden_dir}/ops.npz")
+    for gr, (h, w) in [(14, (21, 21)), (14, (32, 32)), (7, (7, 7)), (14, (30, 40)), (4, (5, 7))]:
+        pe = detgen.det_normal(f"pe_{gr}", (gr * gr + 1, 48))
+        out = torch.empty((1 + h * w, 48), dtype=f32, device=dev)
+        ops.posembed_bicubic(torch.from_numpy(pe).to(dev), out, gr, h, w, 48, np.float32(1.0 / ((h + 0.1) / gr)),
+                             np.float32(1.0 / ((w + 0.1) / gr)))
+        assert np.abs(out.cpu().numpy() - g[f"posembed_g{gr}_{h}x{w}"]).max() < 5e-6
+        orc = R.bicubic_cl(pe[1:].reshape(gr, gr, 48), h, w, (h + 0.1) / gr, (w + 0.1) / gr).reshape(h * w, 48)
+        assert np.abs(out.cpu().numpy()[1:] - orc).max() < 5e-6
+
+
+def test_upsample2x_and_sine(dev, golden_dir):
+    from zutis_amd import ops, detgen
+    g = np.load(f"{golden_dir}/ops.npz")
+    x = detgen.det_normal("up2", (2, 5, 7, 24))
+    o = torch.empty((2, 10, 14, 24), dtype=f32, device=dev)
+    o16 = torch.empty((2, 10, 14, 24), dtype=f16, device=dev)
+    ops.upsample2x_cl(torch.from_numpy(x).to(dev), 2, 5, 7, 24, out_f32=o, out_f16=o16)
+    assert np.abs(o.cpu().numpy() - g["up2"]).max() < 1e-6
+    assert np.abs(o16.float().cpu().numpy() - g["up2"]).max() < 4e-3
+    for (h, w, D) in [(10, 14, 96), (12, 17, 768)]:
+        pe = torch.empty((h * w, D), dtype=f32, device=dev)
+        ops.sine_pe(pe, h, w, D)
+        assert np.abs(pe.cpu().numpy() - g[f"sine_{h}x{w}"]).max() < 2e-5
+
+
+def test_upsample_argmax_bit_exact(dev, golden_dir):
+    """Integer output: bit-exact against the reference's torch.argmax(F.interpolate(...)) incl. exact ties."""
+    from zutis_amd import ops
+    from oracle import resample as R
+    g = np.load(f"{golden_dir}/ops.npz")
+    lo = torch.from_numpy(g["argmax_lo"]).to(dev)
+    for (H, W) in [(80, 112), (77, 145)]:
+        lab = torch.empty((2, H, W), dtype=torch.int64, device=dev)
+        ops.upsample_argmax(lo, lab, 2, 9, 10, 14, H, W)
+        assert np.array_equal(lab.cpu().numpy(), g[f"argmax_labels_{H}x{W}"])
+        full = torch.empty((2, 9, H, W), dtype=f32, device=dev)
+        m = torch.empty((2, 9, H, W), dtype=torch.uint8, device=dev)
+        ops.upsample_bilinear_nchw(lo, 18, 10, 14, H, W, out=full, mask_u8=m, threshold=0.5)
+        ref = R.bilinear_nchw(g["argmax_lo"], H, W)
+        assert np.array_equal(full.cpu().numpy(), ref)          # fp32 bilinear is bit-identical too
+        assert np.array_equal(m.cpu().numpy().astype(bool), ref > 0.5)
+    # identity size and a big random case against the oracle
+    x = _randn((3, 81, 21, 21), 71).numpy()
+    for (H, W) in [(21, 21), (336, 336), (427, 640)]:
+        lab = torch.empty((3, H, W), dtype=torch.int64, device=dev)
+        ops.upsample_argmax(torch.from_numpy(x).to(dev), lab, 3, 81, 21, 21, H, W)
+        assert np.array_equal(lab.cpu().numpy(), R.bilinear_argmax_nchw(x, H, W))
+
+
+def test_confusion_hist(dev, golden_dir):
+    from zutis_amd import ops
+    g = np.load(f"{golden_dir}/ops.npz")
+    hist = torch.zeros((49,), dtype=torch.int64, device=dev)
+    ops.confusion_hist(torch.from_numpy(g["rs_gt"]).to(dev).contiguous(), torch.from_numpy(g["rs_pred"]).to(dev).contiguous(), hist, 7)
+    assert np.array_equal(hist.cpu().numpy().reshape(7, 7), g["rs_hist"].astype(np.int64))
+    # large class count -> global-atomic path
+    rng = np.random.default_rng(0)
+    gt, pr = rng.integers(-1, 921, (200000,)), rng.integers(0, 920, (200000,))
+    hist = torch.zeros((920 * 920,), dtype=torch.int64, device=dev)
+    ops.confusion_hist(torch.from_numpy(gt).to(dev), torch.from_numpy(pr).to(dev), hist, 920)
+    m = (gt >= 0) & (gt < 920)
+    assert np.array_equal(hist.cpu().numpy(), np.bincount(920 * gt[m] + pr[m], minlength=920 * 920))

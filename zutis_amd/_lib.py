@@ -1,0 +1,80 @@
+"""ctypes binding of libzutis_hip.so (include/zutis_hip.h).  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzutis_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h")
+
+_lib = None
+
+
+class ZutisHipError(RuntimeError):
+    pass
+
+
+def declared_symbols(header: str = HEADER):
+    """Every function name declared in include/zutis_hip.h."""
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(zh_[a-z0-9_]+)\s*\(", txt)))
+
+
+_vp, _l, _i, _f, _sz = C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_size_t
+_SIGS = {
+    "zh_version": (C.c_int, []),
+    "zh_arch": (C.c_char_p, []),
+    "zh_last_error": (C.c_char_p, []),
+    "zh_gemm_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
+    "zh_attention_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _vp]),
+    "zh_layernorm_f32": (_i, [_vp, _l, _l, _l, _l, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "zh_assemble_tokens_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "zh_l2norm_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
+    "zh_global_ln_l2_workspace_size": (_sz, [_i, _i, _i]),
+    "zh_global_ln_l2": (_i, [_vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _sz, _vp]),
+    "zh_im2col_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "zh_posembed_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "zh_upsample2x_bilinear_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "zh_sine_pe": (_i, [_vp, _i, _i, _i, _f, _vp]),
+    "zh_add_rowperiodic_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "zh_cast_f32_f16": (_i, [_vp, _vp, _i, _vp, _l, _i, _vp]),
+    "zh_upsample_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    "zh_upsample_bilinear_nchw": (_i, [_vp, _vp, _vp, _f, _l, _i, _i, _i, _i, _f, _f, _vp]),
+    "zh_confusion_hist": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+}
+
+
+def load():
+    """Load the shared library (building nothing: run `python -m zutis_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZutisHipError(
+            f"{LIB_PATH} is missing: the HIP extension is REQUIRED (no CPU fallback). "
+            "Build it with `python -m zutis_amd.build`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        if not hasattr(lib, name):
+            continue  # symbol check is test_capi's job; optional groups may be absent in partial builds
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def register(name, restype, argtypes):
+    _SIGS[name] = (restype, argtypes)
+    if _lib is not None and hasattr(_lib, name):
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().zh_last_error().decode("utf-8", "replace")
+        raise ZutisHipError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,227 @@
+// Flash attention forward, fp16 operands / fp32 softmax+accumulate, head_dim 64 or 96 (gfx950).
+//
+// Replaces nn.MultiheadAttention's softmax(QK^T/sqrt(dh))V at networks/clip_arch.py:314-316 (12 heads,
+// dh=64, T=1+hw), networks/transformer.py:272-286 (decoder self/cross attention, 8 heads, dh=96) and
+// networks/selfmask/vision_transformer.py:110-133 (dh=64, T up to ~6k; the reference materialises
+// [B,6,T,T]).  Nothing T x T ever reaches HBM here.
+//
+// Design: one workgroup = 4 waves = 128 queries of one (image, head); each wave owns 32 queries.
+// K/V tiles of 64 keys are register-staged HBM -> LDS (issue loads for tile t+1 before computing tile t).
+// "Query on the lane" throughout: S^T = K Q^T via v_mfma_f32_32x32x16_f16 puts query = lane&31 in every
+// accumulator register, so the online-softmax max/sum are in-register (one cross-half shuffle) and the
+// O^T = V^T P^T accumulator rescale is a per-lane scalar.  K rows are fed to the MFMA in an order that swaps
+// key-index bits 2 and 3, which makes the S^T accumulator registers 8s..8s+7 exactly the natural-k fp16
+// B-operand of k-step s of the PV product (no lane movement, no LDS round trip for P).  V stays row-major
+// [key][d] in LDS and is consumed column-wise through ds_read_b64_tr_b16.
+// LDS strides: K rows dh+8 halves (conflict-free ds_read_b128), V rows 96 halves (4 consecutive rows cover
+// disjoint 16-dword bank ranges for the transposed read).
+#include "common.h"
+
+struct AttnArgs {
+  const half_t* Q; long ldq, sQ;
+  const half_t* K; long ldk, sK;
+  const half_t* V; long ldv, sV;
+  half_t* O; long ldo, sO;
+  int Tq, Tk, H;
+  float scale_log2;
+};
+
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
+
+#define KT 64
+#define VS 96
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_f16_kernel(AttnArgs p) {
+  constexpr int KS = DH + 8;          // K row stride (halves)
+  constexpr int NKS = DH / 16;        // k-steps of QK^T
+  constexpr int NDT = DH / 32;        // 32-row d tiles of O^T
+  constexpr int CPR = DH / 8;         // 16-byte chunks per K/V row
+  constexpr int NLD = (KT * CPR) / 256;
+  __shared__ __attribute__((aligned(16))) half_t sK[KT * KS];
+  __shared__ __attribute__((aligned(16))) half_t sV[KT * VS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.y, img = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ql = lane & 31, hh = lane >> 5;
+  const long hoff = (long)head * DH;
+
+  const half_t* Q = p.Q + (long)img * p.sQ + hoff;
+  const half_t* K = p.K + (long)img * p.sK + hoff;
+  const half_t* V = p.V + (long)img * p.sV + hoff;
+
+  // Q fragments (B operand: col = query, k = d)
+  half8_t qf[NKS];
+  {
+    int qr = q0 + ql;
+    qr = qr < p.Tq ? qr : p.Tq - 1;
+    const half_t* qp = Q + (long)qr * p.ldq + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const half8_t*)(qp + 16 * ks);
+  }
+
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // cooperative tile loads: chunk c -> (row = c / CPR, col chunk = c % CPR)
+  half8_t kreg[NLD], vreg[NLD];
+  auto load_tile = [&](int kbase) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / CPR, cc = c - row * CPR;
+      const int key = kbase + row;
+      if (key < p.Tk) {
+        kreg[i] = *(const half8_t*)(K + (long)key * p.ldk + cc * 8);
+        vreg[i] = *(const half8_t*)(V + (long)key * p.ldv + cc * 8);
+      } else {
+        kreg[i] = (half8_t)(half_t)0;
+        vreg[i] = (half8_t)(half_t)0;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / CPR, cc = c - row * CPR;
+      *(half8_t*)(sK + row * KS + cc * 8) = kreg[i];
+      *(half8_t*)(sV + row * VS + cc * 8) = vreg[i];
+    }
+  };
+
+  // K row fed at MFMA row i = lane&31: swap bits 2 and 3 of i
+  const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+  // transposed-read lane address pieces: group g = lane>>4, i = lane&15 -> row +(i>>2), col 16*(g&1)+4*(i&3)
+  const int tr_row = 8 * hh + ((lane & 15) >> 2);
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const int ntiles = (p.Tk + KT - 1) / KT;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kbase = t * KT;
+    if (t + 1 < ntiles) load_tile(kbase + KT);
+
+    // ---- S^T = K Q^T  (two 32-key slot tiles)
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+      const half_t* kp = sK + (32 * u + krow) * KS + 8 * hh;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        half8_t kf = *(const half8_t*)(kp + 16 * ks);
+        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[u], 0, 0, 0);
+      }
+    }
+    // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
+    float mx = -INFINITY;
+    const bool tail = kbase + KT > p.Tk;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[u][r] * p.scale_log2;
+        if (tail) {
+          const int key = kbase + 32 * u + 16 * (r >> 3) + 8 * hh + (r & 7);
+          v = key < p.Tk ? v : -INFINITY;
+        }
+        s[u][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    half8_t pf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp2f(s[u][r] - m_new);
+        psum += e;
+        pf[u][r >> 3][r & 7] = (half_t)e;
+      }
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half_t* vp = sV + (32 * u + 16 * ks + tr_row) * VS + tr_col;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(vp + 32 * d));
+          fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(vp + 32 * d + 4 * VS));
+          half8_t vf;
+          __builtin_memcpy(&vf, &lo, 8);
+          __builtin_memcpy(((char*)&vf) + 8, &hi, 8);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][ks], oacc[d], 0, 0, 0);
+        }
+      }
+
+    __syncthreads();
+    if (t + 1 < ntiles) store_tile();
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qr = q0 + ql;
+  if (qr < p.Tq) {
+    half_t* op = p.O + (long)img * p.sO + (long)qr * p.ldo + hoff + 4 * hh;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4_t o = {(half_t)(oacc[d][4 * g] * inv), (half_t)(oacc[d][4 * g + 1] * inv),
+                     (half_t)(oacc[d][4 * g + 2] * inv), (half_t)(oacc[d][4 * g + 3] * inv)};
+        *(half4_t*)(op + 32 * d + 8 * g) = o;
+      }
+  }
+}
+
+extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                                const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
+                                int batch, int heads, int Tq, int Tk, int head_dim, float scale,
+                                hipStream_t stream) {
+  ZH_CHECK_ARG(Q && K && V && O, "zh_attention_f16: null operand");
+  ZH_CHECK_ARG(batch > 0 && heads > 0 && Tq > 0 && Tk > 0, "zh_attention_f16: bad shape");
+  ZH_CHECK_ARG(head_dim == 64 || head_dim == 96, "zh_attention_f16: head_dim %d not in {64, 96}", head_dim);
+  ZH_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && strideQ % 8 == 0 && strideK % 8 == 0 &&
+                   strideV % 8 == 0 && strideO % 4 == 0,
+               "zh_attention_f16: row/batch strides must keep 16-byte (Q,K,V) / 8-byte (O) alignment");
+  ZH_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 && ((uintptr_t)O & 7) == 0,
+               "zh_attention_f16: misaligned pointer");
+  ZH_CHECK_ARG(heads < 65536 && batch < 65536, "zh_attention_f16: heads/batch exceed grid limits");
+  AttnArgs p;
+  p.Q = (const half_t*)Q; p.ldq = ldq; p.sQ = strideQ;
+  p.K = (const half_t*)K; p.ldk = ldk; p.sK = strideK;
+  p.V = (const half_t*)V; p.ldv = ldv; p.sV = strideV;
+  p.O = (half_t*)O; p.ldo = ldo; p.sO = strideO;
+  p.Tq = Tq; p.Tk = Tk; p.H = heads;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  dim3 grid(zh_cdiv(Tq, 128), heads, batch);
+  if (head_dim == 64) hipLaunchKernelGGL(attn_f16_kernel<64>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(attn_f16_kernel<96>, grid, dim3(256), 0, stream, p);
+  ZH_CHECK_LAUNCH("zh_attention_f16");
+  return ZH_OK;
+}

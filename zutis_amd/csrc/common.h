@@ -1,0 +1,68 @@
+// Shared device/host helpers for libzutis_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ZH_OK 0
+#define ZH_ERR_ARG (-1)
+#define ZH_ERR_HIP (-2)
+#define ZH_ERR_WORKSPACE (-3)
+
+// thread-local last-error text, returned by zh_last_error()
+void zh_set_error(const char* fmt, ...);
+
+#define ZH_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      zh_set_error(__VA_ARGS__);           \
+      return ZH_ERR_ARG;                   \
+    }                                      \
+  } while (0)
+
+#define ZH_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      zh_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return ZH_ERR_HIP;                                                   \
+    }                                                                      \
+  } while (0)
+
+static inline int zh_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 reductions ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// activation codes shared by the GEMM epilogue (include/zutis_hip.h ZH_ACT_*)
+#define ZH_ACT_NONE 0
+#define ZH_ACT_QUICKGELU 1   // x * sigmoid(1.702 x)      networks/clip_arch.py:295-297
+#define ZH_ACT_RELU 2        // networks/zutis.py:546-549, networks/transformer.py:289
+#define ZH_ACT_SIGMOID 3     // networks/zutis.py:209
+#define ZH_ACT_GELU_ERF 4    // nn.GELU, networks/selfmask/vision_transformer.py:79
+
+__device__ __forceinline__ float zh_act(float x, int act) {
+  switch (act) {
+    case ZH_ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));
+    case ZH_ACT_RELU: return fmaxf(x, 0.0f);
+    case ZH_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+    case ZH_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    default: return x;
+  }
+}

@@ -1,0 +1,273 @@
+// Resampling / layout kernels: im2col, bicubic pos-embed, x2 bilinear (channels-last), sine PE,
+// fused bilinear-upsample + argmax, bilinear NCHW, casts (gfx950).  All HBM/L2-bound byte movers.
+//
+// Arithmetic order of the bilinear kernels follows ATen's CPU kernels exactly (explicit __fmaf_rn /
+// __fmul_rn, see oracle/resample.py) so the fused argmax is bit-identical to
+// torch.argmax(F.interpolate(..., mode="bilinear"), dim=1) on the same low-res logits, ties included.
+#include "common.h"
+
+// ---- im2col for the stride==kernel patch-embed conv (networks/clip_arch.py:340,378): pure re-index.
+//      out[(b,py,px)][c*p*p + i*p + j] = x[b,c,py*p+i,px*p+j], zero padded to Kpad columns, fp16.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* x, half_t* out, int B, int Cin, int H, int W, int p,
+                                                     int gh, int gw, int Kpad, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx % Kpad);
+  const long row = idx / Kpad;
+  float v = 0.f;
+  if (k < Cin * p * p) {
+    const int c = k / (p * p), ij = k - c * p * p, i = ij / p, j = ij - i * p;
+    const int px = (int)(row % gw);
+    const long t = row / gw;
+    const int py = (int)(t % gh), b = (int)(t / gh);
+    v = x[(((long)b * Cin + c) * H + (py * p + i)) * W + (px * p + j)];
+  }
+  out[idx] = (half_t)v;
+}
+
+extern "C" int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, hipStream_t stream) {
+  ZH_CHECK_ARG(x && out && B > 0 && Cin > 0 && patch > 0 && H >= patch && W >= patch, "zh_im2col_f16: bad arguments");
+  ZH_CHECK_ARG(Kpad >= Cin * patch * patch, "zh_im2col_f16: Kpad too small");
+  const int gh = (H - patch) / patch + 1, gw = (W - patch) / patch + 1;
+  const long total = (long)B * gh * gw * Kpad;
+  hipLaunchKernelGGL(im2col_kernel, dim3(zh_cdiv(total, 256)), dim3(256), 0, stream, x, (half_t*)out, B, Cin, H, W, patch, gh, gw, Kpad, total);
+  ZH_CHECK_LAUNCH("zh_im2col_f16");
+  return ZH_OK;
+}
+
+// ---- bicubic positional-embedding resample (networks/clip_arch.py:356-374; selfmask/vision_transformer.py:377-401)
+//      pos [1+g*g, D] -> out [1+h*w, D]; row 0 (cls) copied.  Keys cubic A=-0.75, align_corners=False,
+//      src = fma(scale, dst+0.5, -0.5) (no clamp), taps clamped to [0,g-1].  `scale_*` is the float32 coordinate
+//      scale: float(1/scale_factor) for the CLIP form (g/(h+0.1), NOT g/h), in/out for the size= form.
+__device__ __forceinline__ void cubic_coeffs(float t, float w[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ __launch_bounds__(256) void posembed_bicubic_kernel(const float* pos, float* out, int g, int h, int w, int D,
+                                                               float scale_h, float scale_w, int has_cls) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)(h * w + has_cls) * D;
+  if (idx >= total) return;
+  const int d = (int)(idx % D);
+  const int t = (int)(idx / D);
+  if (has_cls && t == 0) { out[idx] = pos[d]; return; }
+  const int oy = (t - has_cls) / w, ox = (t - has_cls) - oy * w;
+  const float sy = __fmaf_rn(scale_h, (float)oy + 0.5f, -0.5f), sx = __fmaf_rn(scale_w, (float)ox + 0.5f, -0.5f);
+  const float fy = floorf(sy), fx = floorf(sx);
+  float wy[4], wx[4];
+  cubic_coeffs(sy - fy, wy);
+  cubic_coeffs(sx - fx, wx);
+  const int iy = (int)fy, ix = (int)fx;
+  const float* base = pos + (long)has_cls * D + d;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int yy = min(max(iy - 1 + a, 0), g - 1);
+    float r = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int xx = min(max(ix - 1 + b, 0), g - 1);
+      const float v = base[(long)(yy * g + xx) * D];
+      r = b == 0 ? __fmul_rn(v, wx[0]) : __fmaf_rn(v, wx[b], r);
+    }
+    acc = a == 0 ? __fmul_rn(r, wy[0]) : __fmaf_rn(r, wy[a], acc);
+  }
+  out[idx] = acc;
+}
+
+extern "C" int zh_posembed_bicubic(const float* pos, float* out, int grid, int h, int w, int D, float scale_h, float scale_w,
+                                   int has_cls, hipStream_t stream) {
+  ZH_CHECK_ARG(pos && out && grid > 0 && h > 0 && w > 0 && D > 0, "zh_posembed_bicubic: bad arguments");
+  const long total = (long)(h * w + (has_cls ? 1 : 0)) * D;
+  hipLaunchKernelGGL(posembed_bicubic_kernel, dim3(zh_cdiv(total, 256)), dim3(256), 0, stream, pos, out, grid, h, w, D, scale_h, scale_w, has_cls ? 1 : 0);
+  ZH_CHECK_LAUNCH("zh_posembed_bicubic");
+  return ZH_OK;
+}
+
+// ---- x2 bilinear upsample, channels-last tokens (networks/zutis.py:491-495): [B,h,w,D] fp32 -> [B,2h,2w,D]
+//      fp16 and/or fp32.  src = max(0.5*(dst+0.5)-0.5, 0); weights {0.25,0.75} (edges clamp).
+__global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* x, float* out_f32, half_t* out_f16, int B, int h, int w, int D) {
+  const int nv = D >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * 4 * h * w * nv;
+  if (idx >= total) return;
+  const int c = (int)(idx % nv);
+  long t = idx / nv;
+  const int ox = (int)(t % (2 * w)); t /= (2 * w);
+  const int oy = (int)(t % (2 * h));
+  const int b = (int)(t / (2 * h));
+  const float sy = fmaxf(__fmaf_rn(0.5f, (float)oy + 0.5f, -0.5f), 0.f), sx = fmaxf(__fmaf_rn(0.5f, (float)ox + 0.5f, -0.5f), 0.f);
+  const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+  const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+  const float ly1 = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+  const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const f32x4* xb = (const f32x4*)(x + (long)b * h * w * D);
+  const f32x4 v00 = xb[(long)(y0 * w + x0) * nv + c], v01 = xb[(long)(y0 * w + x1) * nv + c];
+  const f32x4 v10 = xb[(long)(y1 * w + x0) * nv + c], v11 = xb[(long)(y1 * w + x1) * nv + c];
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float r0 = __fmaf_rn(v00[e], lx0, __fmul_rn(v01[e], lx1));
+    const float r1 = __fmaf_rn(v10[e], lx0, __fmul_rn(v11[e], lx1));
+    o[e] = __fmaf_rn(r0, ly0, __fmul_rn(r1, ly1));
+  }
+  if (out_f32) ((f32x4*)out_f32)[idx] = o;
+  if (out_f16) {
+    half4_t hh = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+    ((half4_t*)out_f16)[idx] = hh;
+  }
+}
+
+extern "C" int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, hipStream_t stream) {
+  ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && h > 0 && w > 0 && D > 0 && D % 4 == 0, "zh_upsample2x_bilinear_cl: bad arguments");
+  const long total = (long)B * 4 * h * w * (D / 4);
+  hipLaunchKernelGGL(upsample2x_cl_kernel, dim3(zh_cdiv(total, 256)), dim3(256), 0, stream, x, out_f32, (half_t*)out_f16, B, h, w, D);
+  ZH_CHECK_LAUNCH("zh_upsample2x_bilinear_cl");
+  return ZH_OK;
+}
+
+// ---- sine positional embedding (networks/positional_embedding.py:29-52, normalize=True, scale=2*pi)
+//      out[(y*w+x)][c], c<D/2: y part, else x part; even c sin, odd c cos; dim_t = T^(2*(c/2)/(D/2)).
+__global__ __launch_bounds__(256) void sine_pe_kernel(float* out, int h, int w, int D, float temperature) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)h * w * D;
+  if (idx >= total) return;
+  const int c = (int)(idx % D);
+  const int t = (int)(idx / D);
+  const int y = t / w, x = t - y * w;
+  const int npf = D >> 1;
+  const int i = c < npf ? c : c - npf;
+  const float e = c < npf ? (float)(y + 1) / ((float)h + 1e-6f) * 6.283185307179586f
+                          : (float)(x + 1) / ((float)w + 1e-6f) * 6.283185307179586f;
+  const float dim_t = powf(temperature, (float)(2 * (i / 2)) / (float)npf);
+  const float a = e / dim_t;
+  out[idx] = (i & 1) ? cosf(a) : sinf(a);
+}
+
+extern "C" int zh_sine_pe(float* out, int h, int w, int D, float temperature, hipStream_t stream) {
+  ZH_CHECK_ARG(out && h > 0 && w > 0 && D > 0 && D % 4 == 0, "zh_sine_pe: bad arguments");
+  hipLaunchKernelGGL(sine_pe_kernel, dim3(zh_cdiv((long)h * w * D, 256)), dim3(256), 0, stream, out, h, w, D, temperature);
+  ZH_CHECK_LAUNCH("zh_sine_pe");
+  return ZH_OK;
+}
+
+// ---- out_f16[r][:] = fp16(a_f16[r][:] + add_f32[r % add_rows][:])   (memory + pos, networks/transformer.py:281)
+__global__ __launch_bounds__(256) void add_rowperiodic_kernel(const half_t* a, const float* add, half_t* out, long rows, int D, int add_rows) {
+  const int nv = D >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * nv) return;
+  const long r = idx / nv;
+  const int c = (int)(idx - r * nv);
+  const half4_t h = ((const half4_t*)a)[idx];
+  const f32x4 p = ((const f32x4*)add)[(r % add_rows) * nv + c];
+  half4_t o = {(half_t)((float)h[0] + p[0]), (half_t)((float)h[1] + p[1]), (half_t)((float)h[2] + p[2]), (half_t)((float)h[3] + p[3])};
+  ((half4_t*)out)[idx] = o;
+}
+
+extern "C" int zh_add_rowperiodic_f16(const void* a, const float* add, void* out, long rows, int D, int add_rows, hipStream_t stream) {
+  ZH_CHECK_ARG(a && add && out && rows > 0 && D > 0 && D % 4 == 0 && add_rows > 0, "zh_add_rowperiodic_f16: bad arguments");
+  hipLaunchKernelGGL(add_rowperiodic_kernel, dim3(zh_cdiv(rows * (D / 4), 256)), dim3(256), 0, stream, (const half_t*)a, add, (half_t*)out, rows, D, add_rows);
+  ZH_CHECK_LAUNCH("zh_add_rowperiodic_f16");
+  return ZH_OK;
+}
+
+// ---- fp32 -> fp16 cast (optionally adding a row-periodic fp32 matrix first)
+__global__ __launch_bounds__(256) void cast_kernel(const float* x, const float* add, half_t* out, long n4, int nv, int add_rows) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n4) return;
+  f32x4 v = ((const f32x4*)x)[idx];
+  if (add) {
+    const long r = idx / nv;
+    v += ((const f32x4*)add)[(r % add_rows) * nv + (idx - r * nv)];
+  }
+  half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  ((half4_t*)out)[idx] = o;
+}
+
+extern "C" int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, hipStream_t stream) {
+  ZH_CHECK_ARG(x && out && rows > 0 && D > 0 && D % 4 == 0, "zh_cast_f32_f16: bad arguments");
+  ZH_CHECK_ARG(!add || add_rows > 0, "zh_cast_f32_f16: add needs add_rows");
+  const long n4 = rows * (D / 4);
+  hipLaunchKernelGGL(cast_kernel, dim3(zh_cdiv(n4, 256)), dim3(256), 0, stream, x, add, (half_t*)out, n4, D / 4, add_rows > 0 ? add_rows : 1);
+  ZH_CHECK_LAUNCH("zh_cast_f32_f16");
+  return ZH_OK;
+}
+
+// ---- bilinear index/weight, ATen compute_source_index_and_lambda (align_corners=False)
+struct LinW { int i0, i1; float l0, l1; };
+__device__ __forceinline__ LinW lin_weights(int dst, int in_size, int out_size, float scale) {
+  LinW r;
+  if (in_size == out_size) { r.i0 = r.i1 = dst; r.l0 = 1.f; r.l1 = 0.f; return r; }
+  const float src = fmaxf(__fmaf_rn(scale, (float)dst + 0.5f, -0.5f), 0.f);
+  r.i0 = min((int)src, in_size - 1);
+  r.i1 = min(r.i0 + 1, in_size - 1);
+  r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+// ---- fused bilinear upsample + argmax over classes (networks/zutis.py:366-372), never materialising
+//      [B,n,H,W].  logits [B,n,h,w] fp32 (NCHW, low-res) -> labels int64 [B,H,W]; first index on ties.
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* lo, long long* labels, int B, int n, int h, int w,
+                                                              int H, int W, float scale_h, float scale_w) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * H * W;
+  if (idx >= total) return;
+  const int ox = (int)(idx % W);
+  const long t = idx / W;
+  const int oy = (int)(t % H), b = (int)(t / H);
+  const LinW wy = lin_weights(oy, h, H, scale_h), wx = lin_weights(ox, w, W, scale_w);
+  const float* p = lo + (long)b * n * h * w;
+  const int o00 = wy.i0 * w + wx.i0, o01 = wy.i0 * w + wx.i1, o10 = wy.i1 * w + wx.i0, o11 = wy.i1 * w + wx.i1;
+  float best = 0.f;
+  int besti = 0;
+  for (int c = 0; c < n; ++c, p += (long)h * w) {
+    const float r0 = __fmaf_rn(p[o00], wx.l0, __fmul_rn(p[o01], wx.l1));
+    const float r1 = __fmaf_rn(p[o10], wx.l0, __fmul_rn(p[o11], wx.l1));
+    const float v = __fmaf_rn(r0, wy.l0, __fmul_rn(r1, wy.l1));
+    // torch.argmax: first maximal index; NaN is treated as maximal (propagates)
+    if (c == 0 || v > best || (v != v && best == best)) { best = v; besti = c; }
+  }
+  labels[idx] = besti;
+}
+
+extern "C" int zh_upsample_argmax(const float* logits_lo, long long* labels, int B, int n, int h, int w, int H, int W,
+                                  float scale_h, float scale_w, hipStream_t stream) {
+  ZH_CHECK_ARG(logits_lo && labels && B > 0 && n > 0 && h > 0 && w > 0 && H > 0 && W > 0, "zh_upsample_argmax: bad arguments");
+  hipLaunchKernelGGL(upsample_argmax_kernel, dim3(zh_cdiv((long)B * H * W, 256)), dim3(256), 0, stream, logits_lo, labels, B, n, h, w, H, W, scale_h, scale_w);
+  ZH_CHECK_LAUNCH("zh_upsample_argmax");
+  return ZH_OK;
+}
+
+// ---- bilinear NCHW upsample (return_logits path zutis.py:368-371 and instance masks zutis.py:422-423);
+//      optional threshold output: mask_u8 = (value > threshold)
+__global__ __launch_bounds__(256) void bilinear_nchw_kernel(const float* x, float* out, unsigned char* mask, float threshold,
+                                                            long planes, int h, int w, int H, int W, float scale_h, float scale_w) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = planes * H * W;
+  if (idx >= total) return;
+  const int ox = (int)(idx % W);
+  const long t = idx / W;
+  const int oy = (int)(t % H);
+  const long pl = t / H;
+  const LinW wy = lin_weights(oy, h, H, scale_h), wx = lin_weights(ox, w, W, scale_w);
+  const float* p = x + pl * h * w;
+  const float r0 = __fmaf_rn(p[wy.i0 * w + wx.i0], wx.l0, __fmul_rn(p[wy.i0 * w + wx.i1], wx.l1));
+  const float r1 = __fmaf_rn(p[wy.i1 * w + wx.i0], wx.l0, __fmul_rn(p[wy.i1 * w + wx.i1], wx.l1));
+  const float v = __fmaf_rn(r0, wy.l0, __fmul_rn(r1, wy.l1));
+  if (out) out[idx] = v;
+  if (mask) mask[idx] = v > threshold ? 1 : 0;
+}
+
+extern "C" int zh_upsample_bilinear_nchw(const float* x, float* out, unsigned char* mask_u8, float threshold, long planes,
+                                         int h, int w, int H, int W, float scale_h, float scale_w, hipStream_t stream) {
+  ZH_CHECK_ARG(x && (out || mask_u8) && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "zh_upsample_bilinear_nchw: bad arguments");
+  hipLaunchKernelGGL(bilinear_nchw_kernel, dim3(zh_cdiv(planes * H * W, 256)), dim3(256), 0, stream, x, out, mask_u8, threshold, planes, h, w, H, W, scale_h, scale_w);
+  ZH_CHECK_LAUNCH("zh_upsample_bilinear_nchw");
+  return ZH_OK;
+}

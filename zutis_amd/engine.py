@@ -1,0 +1,283 @@
+"""ZUTIS forward/predict as a plan over libzutis_hip kernels (MI355X-native; no torch compute ops).
+
+Data layout in HBM (one GPU, B images, T = 1 + h*w encoder tokens, M = 4*h*w decoder memory tokens):
+  X        f32 [B*T, D]        residual stream (fp32 end to end)
+  Y16      f16 [B*T, D]        LayerNorm outputs (GEMM A operands are fp16, accumulate fp32)
+  QKV16    f16 [B*T, 3D]       packed q|k|v, consumed in place by flash attention (strided heads)
+  H16      f16 [B*T, 4D]       QuickGELU(c_fc) — never stored in fp32
+  TOK16    f16 [B*M, D]        x2-upsampled patch tokens (A operand of ffn1 and of the text-space projection)
+  DEC16    f16 [B*M, D]        decoder_input (ffn1 output) = V-projection input and mask-einsum operand
+  KIN16    f16 [B*M, D]        decoder_input + sine PE = K-projection input
+  KALL/VALL f16 [B*M, L*D]     cross-attention K / V of all L decoder layers from ONE GEMM each
+  weights  f16, packed once per parameter version ([N,K] row-major = torch Linear layout, K contiguous)
+
+Reference call sites are cited per step (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import ZutisHipError
+
+f16, f32 = torch.float16, torch.float32
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class ZutisEngine:
+    """Inference engine for one ZUTIS network.  `params` maps reference state_dict keys to fp32 CUDA tensors
+    (typically the nn.Parameters of the drop-in module, so load_state_dict() is picked up via version counters)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int, dec_heads: int = 8):
+        self.params = params
+        self.patch = patch
+        self.D = params["encoder.class_embedding"].shape[0]
+        self.heads = self.D // 64                                              # clip_arch.py:606
+        self.layers = 1 + max(int(k.split(".")[3]) for k in params if k.startswith("encoder.transformer.resblocks."))
+        self.dec_layers = 1 + max(int(k.split(".")[2]) for k in params if k.startswith("decoder.layers."))
+        self.dec_heads = dec_heads
+        self.dec_dh = self.D // dec_heads
+        self.Q = params["query_embed"].shape[0]
+        self.E = params["encoder.proj"].shape[1]
+        self.grid = int(math.isqrt(params["encoder.positional_embedding"].shape[0] - 1))
+        if self.dec_dh not in (64, 96):
+            raise ZutisHipError(f"decoder head_dim {self.dec_dh} unsupported by zh_attention_f16 (64 or 96)")
+        self._packed_key = None
+        self._w: Dict[str, torch.Tensor] = {}
+        self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ packing
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.params.values())
+
+    def _pack(self):
+        key = self._version_key()
+        if key == self._packed_key:
+            return
+        P, D, w = self.params, self.D, {}
+        dev = P["query_embed"].device
+        if dev.type != "cuda":
+            raise ZutisHipError("ZutisEngine needs parameters on a GPU (no CPU fallback)")
+        h = lambda t: t.detach().to(f16).contiguous()
+        c32 = lambda t: t.detach().to(f32).contiguous()
+        kc = 3 * self.patch * self.patch
+        self.Kc = _rup(kc, 64)
+        wc = torch.zeros((D, self.Kc), dtype=f16, device=dev)
+        wc[:, :kc] = P["encoder.conv1.weight"].detach().reshape(D, kc).to(f16)
+        w["conv"] = wc
+        for name in ("encoder.class_embedding", "encoder.positional_embedding", "encoder.ln_pre.weight", "encoder.ln_pre.bias",
+                     "encoder.ln_post.weight", "encoder.ln_post.bias", "decoder.norm.weight", "decoder.norm.bias", "query_embed"):
+            w[name] = c32(P[name])
+        for i in range(self.layers):
+            p = f"encoder.transformer.resblocks.{i}."
+            w[p + "qkv_w"], w[p + "qkv_b"] = h(P[p + "attn.in_proj_weight"]), c32(P[p + "attn.in_proj_bias"])
+            w[p + "out_w"], w[p + "out_b"] = h(P[p + "attn.out_proj.weight"]), c32(P[p + "attn.out_proj.bias"])
+            w[p + "fc_w"], w[p + "fc_b"] = h(P[p + "mlp.c_fc.weight"]), c32(P[p + "mlp.c_fc.bias"])
+            w[p + "proj_w"], w[p + "proj_b"] = h(P[p + "mlp.c_proj.weight"]), c32(P[p + "mlp.c_proj.bias"])
+            for ln in ("ln_1", "ln_2"):
+                w[p + ln + ".w"], w[p + ln + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
+        for ffn in ("ffn1", "ffn2"):
+            for j in range(3):
+                w[f"{ffn}.{j}.w"], w[f"{ffn}.{j}.b"] = h(P[f"{ffn}.layers.{j}.weight"]), c32(P[f"{ffn}.layers.{j}.bias"])
+        kw, kb, vw, vb = [], [], [], []
+        for i in range(self.dec_layers):
+            p = f"decoder.layers.{i}."
+            sw, sb = P[p + "self_attn.in_proj_weight"].detach(), P[p + "self_attn.in_proj_bias"].detach()
+            w[p + "sa_qk_w"], w[p + "sa_qk_b"] = h(sw[:2 * D]), c32(sb[:2 * D])
+            w[p + "sa_v_w"], w[p + "sa_v_b"] = h(sw[2 * D:]), c32(sb[2 * D:])
+            w[p + "sa_o_w"], w[p + "sa_o_b"] = h(P[p + "self_attn.out_proj.weight"]), c32(P[p + "self_attn.out_proj.bias"])
+            cw, cb = P[p + "multihead_attn.in_proj_weight"].detach(), P[p + "multihead_attn.in_proj_bias"].detach()
+            w[p + "ca_q_w"], w[p + "ca_q_b"] = h(cw[:D]), c32(cb[:D])
+            kw.append(cw[D:2 * D]); kb.append(cb[D:2 * D]); vw.append(cw[2 * D:]); vb.append(cb[2 * D:])
+            w[p + "ca_o_w"], w[p + "ca_o_b"] = h(P[p + "multihead_attn.out_proj.weight"]), c32(P[p + "multihead_attn.out_proj.bias"])
+            w[p + "l1_w"], w[p + "l1_b"] = h(P[p + "linear1.weight"]), c32(P[p + "linear1.bias"])
+            w[p + "l2_w"], w[p + "l2_b"] = h(P[p + "linear2.weight"]), c32(P[p + "linear2.bias"])
+            for n in ("norm1", "norm2", "norm3"):
+                w[p + n + ".w"], w[p + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
+        w["ca_k_w"], w["ca_k_b"] = h(torch.cat(kw, 0)), c32(torch.cat(kb, 0))       # [L*D, D]
+        w["ca_v_w"], w["ca_v_b"] = h(torch.cat(vw, 0)), c32(torch.cat(vb, 0))
+        w["projT"] = h(P["encoder.proj"].detach().t())                                 # [E, D]
+        self._w, self._packed_key = w, key
+        self._geo.clear()
+
+    def _buf(self, name: str, shape, dtype) -> torch.Tensor:
+        k = (name, tuple(shape), dtype)
+        b = self._bufs.get(k)
+        if b is None:
+            for kk in [kk for kk in self._bufs if kk[0] == name]:
+                del self._bufs[kk]
+            b = torch.empty(shape, dtype=dtype, device=self._w["conv"].device)
+            self._bufs[k] = b
+        return b
+
+    def _geometry(self, h: int, w: int):
+        """Input-independent tables per token grid: bicubic pos-embed (clip_arch.py:356-374) and sine PE
+        (positional_embedding.py:29-52) — computed once on device, cached."""
+        g = self._geo.get((h, w))
+        if g is None:
+            D, dev = self.D, self._w["conv"].device
+            pos = torch.empty((1 + h * w, D), dtype=f32, device=dev)
+            sh = np.float32(1.0 / ((h + 0.1) / self.grid))
+            sw = np.float32(1.0 / ((w + 0.1) / self.grid))
+            ops.posembed_bicubic(self._w["encoder.positional_embedding"], pos, self.grid, h, w, D, sh, sw, True)
+            pe = torch.empty((4 * h * w, D), dtype=f32, device=dev)
+            ops.sine_pe(pe, 2 * h, 2 * w, D)
+            g = {"pos": pos, "pe": pe}
+            self._geo[(h, w)] = g
+        return g
+
+    # ------------------------------------------------------------------ encoder
+    def encode(self, x: torch.Tensor):
+        """clip_arch.py:377-411 -> (patch tokens f32 [B,hw,D] (ln_post applied, cls dropped), h, w)."""
+        self._pack()
+        if not (x.is_cuda and x.dtype == f32 and x.dim() == 4 and x.shape[1] == 3):
+            raise ZutisHipError("encode: expected float32 CUDA tensor [B,3,H,W]")
+        x = x.contiguous()
+        W_, D, p = self._w, self.D, self.patch
+        B, _, H, Wd = x.shape
+        h, w = (H - p) // p + 1, (Wd - p) // p + 1
+        T, R = 1 + h * w, B * (1 + h * w)
+        geo = self._geometry(h, w)
+        col = self._buf("col", (B * h * w, self.Kc), f16)
+        ops.im2col(x, col, p, self.Kc)                                                   # :378 conv1 as GEMM
+        pe32 = self._buf("patch_emb", (B * h * w, D), f32)
+        ops.gemm(col, W_["conv"], pe32)
+        X = self._buf("X", (R, D), f32)
+        ops.assemble_tokens_ln(pe32, W_["encoder.class_embedding"], geo["pos"], W_["encoder.ln_pre.weight"],
+                               W_["encoder.ln_pre.bias"], 1e-5, X, B, T, D)                # :384-397
+        Y = self._buf("Y16", (R, D), f16)
+        QKV = self._buf("QKV16", (R, 3 * D), f16)
+        O = self._buf("O16", (R, D), f16)
+        Hh = self._buf("H16", (R, 4 * D), f16)
+        for i in range(self.layers):                                                       # :318-321
+            pp = f"encoder.transformer.resblocks.{i}."
+            ops.layernorm(X, W_[pp + "ln_1.w"], W_[pp + "ln_1.b"], 1e-5, R, D, out_f16=Y)
+            ops.gemm(Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
+            ops.attention(QKV, QKV[:, D:], QKV[:, 2 * D:], O, batch=B, heads=self.heads, Tq=T, Tk=T, head_dim=64,
+                          ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
+                          strideO=T * D)
+            ops.gemm(O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
+            ops.layernorm(X, W_[pp + "ln_2.w"], W_[pp + "ln_2.b"], 1e-5, R, D, out_f16=Y)
+            ops.gemm(Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=ops.ACT_QUICKGELU)
+            ops.gemm(Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
+        tok = self._buf("tok", (B, h * w, D), f32)
+        ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B * h * w, D, out_f32=tok,
+                      in_group_rows=h * w, in_group_stride=T, in_offset=1)                 # :403-404
+        return tok, h, w
+
+    # ------------------------------------------------------------------ full forward
+    def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """networks/zutis.py:472-532."""
+        tok, h, w = self.encode(x)
+        W_, D, B, Q, L = self._w, self.D, x.shape[0], self.Q, self.dec_layers
+        h2, w2 = 2 * h, 2 * w
+        M = h2 * w2
+        geo = self._geometry(h, w)
+        TOK = self._buf("TOK16", (B * M, D), f16)
+        ops.upsample2x_cl(tok, B, h, w, D, out_f16=TOK)                                     # :491-495
+        Fh = W_["ffn1.0.w"].shape[0]
+        f1 = self._buf("ffn_h1", (B * M, Fh), f16)
+        f2 = self._buf("ffn_h2", (B * M, Fh), f16)
+        DEC = self._buf("DEC16", (B * M, D), f16)
+        ops.gemm(TOK, W_["ffn1.0.w"], f1, bias=W_["ffn1.0.b"], act=ops.ACT_RELU)            # :500-503
+        ops.gemm(f1, W_["ffn1.1.w"], f2, bias=W_["ffn1.1.b"], act=ops.ACT_RELU)
+        ops.gemm(f2, W_["ffn1.2.w"], DEC, bias=W_["ffn1.2.b"])
+        KIN = self._buf("KIN16", (B * M, D), f16)
+        ops.add_rowperiodic_f16(DEC, geo["pe"], KIN, B * M, D, M)                           # transformer.py:281 memory+pos
+        KALL = self._buf("KALL", (B * M, L * D), f16)
+        VALL = self._buf("VALL", (B * M, L * D), f16)
+        ops.gemm(KIN, W_["ca_k_w"], KALL, bias=W_["ca_k_b"])                                # all layers' K / V at once
+        ops.gemm(DEC, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
+
+        # decoder (transformer.py:114-152 over :262-291), tgt = zeros, query_pos = query_embed
+        R = B * Q
+        dh, Hd = self.dec_dh, self.dec_heads
+        qpos = W_["query_embed"]
+        tgt = self._buf("tgt", (R, D), f32)
+        t1 = self._buf("t1", (R, D), f32)
+        tgt16 = self._buf("tgt16", (R, D), f16)
+        qin16 = self._buf("qin16", (R, D), f16)
+        qk16 = self._buf("qk16", (R, 2 * D), f16)
+        v16 = self._buf("v16", (R, D), f16)
+        qc16 = self._buf("qc16", (R, D), f16)
+        o16 = self._buf("do16", (R, D), f16)
+        ff16 = self._buf("ff16", (R, W_["decoder.layers.0.l1_w"].shape[0]), f16)
+        inter16 = self._buf("inter16", (B * L * Q, D), f16)
+        tgt.zero_()
+        ops.cast_f16(tgt, tgt16, R, D)
+        ops.cast_f16(tgt, qin16, R, D, add=qpos, add_rows=Q)
+        for l in range(L):
+            pp = f"decoder.layers.{l}."
+            ops.gemm(qin16, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])             # q = k = tgt + query_pos
+            ops.gemm(tgt16, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])                 # v = tgt
+            ops.attention(qk16, qk16[:, D:], v16, o16, batch=B, heads=Hd, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D, ldk=2 * D,
+                          ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D)
+            ops.gemm(o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=tgt)
+            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=tgt, out_f16_plus=qin16,
+                          add=qpos, add_rows=Q)
+            ops.gemm(qin16, W_[pp + "ca_q_w"], qc16, bias=W_[pp + "ca_q_b"])
+            ops.attention(qc16, KALL[:, l * D:], VALL[:, l * D:], o16, batch=B, heads=Hd, Tq=Q, Tk=M, head_dim=dh, ldq=D,
+                          ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D, strideO=Q * D)
+            ops.gemm(o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt)
+            ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
+            ops.gemm(tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
+            ops.gemm(ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
+            ops.layernorm(t1, W_[pp + "norm3.w"], W_[pp + "norm3.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16,
+                          out_f16_plus=qin16, add=qpos, add_rows=Q)
+            ops.layernorm(tgt, W_["decoder.norm.weight"], W_["decoder.norm.bias"], 1e-5, R, D, out_f16=inter16,
+                          out_group_rows=Q, out_group_stride=L * Q, out_offset=l * Q)       # :140-150, stacked [B,L,Q,D]
+
+        RQ = B * L * Q
+        g1 = self._buf("ffn2_h1", (RQ, Fh), f16)
+        g2 = self._buf("ffn2_h2", (RQ, Fh), f16)
+        q32 = self._buf("q32", (RQ, D), f32)
+        q16 = self._buf("q16", (RQ, D), f16)
+        ops.gemm(inter16, W_["ffn2.0.w"], g1, bias=W_["ffn2.0.b"], act=ops.ACT_RELU)        # zutis.py:514
+        ops.gemm(g1, W_["ffn2.1.w"], g2, bias=W_["ffn2.1.b"], act=ops.ACT_RELU)
+        ops.gemm(g2, W_["ffn2.2.w"], q32, bias=W_["ffn2.2.b"])
+        ops.l2norm_rows(q32, RQ, D, out_f16=q16)                                            # :515
+        masks = torch.empty((B, L, Q, h2, w2), dtype=f32, device=x.device)
+        ops.gemm(q16, DEC, masks, act=ops.ACT_SIGMOID, M=L * Q, N=M, K=D, lda=D, ldw=D, ldc=M, batch=B,
+                 strideA=L * Q * D, strideW=M * D, strideC=L * Q * M)                       # :196-198,209
+        ts = self._buf("textspace", (B * M, self.E), f32)
+        ops.gemm(TOK, W_["projT"], ts)                                                      # :319
+        pt = torch.empty((B, h2, w2, self.E), dtype=f32, device=x.device)
+        ops.global_ln_l2(ts, B, M, self.E, out_f32=pt, eps=1e-5, l2_eps=1e-7)               # :320-322
+        return {"mask_proposals": masks, "patch_tokens": pt}
+
+    # ------------------------------------------------------------------ predict (semantic)
+    def semantic_logits_lowres(self, patch_tokens: torch.Tensor, text: torch.Tensor) -> torch.Tensor:
+        """einsum("nc,bchw->bnhw") zutis.py:361-365 -> f32 [B,n,h,w]."""
+        B, h, w, E = patch_tokens.shape
+        n = text.shape[0]
+        pt16 = self._buf("pt16", (B * h * w, E), f16)
+        ops.cast_f16(patch_tokens.contiguous(), pt16, B * h * w, E)
+        t16 = text.detach().to(device=patch_tokens.device, dtype=f16).contiguous()
+        lo = torch.empty((B, n, h, w), dtype=f32, device=patch_tokens.device)
+        ops.gemm(t16, pt16, lo, M=n, N=h * w, K=E, lda=E, ldw=E, ldc=h * w, batch=B, strideA=0, strideW=h * w * E,
+                 strideC=n * h * w)
+        return lo
+
+    def predict_semantic(self, patch_tokens: torch.Tensor, text: torch.Tensor, size: Optional[Tuple[int, int]],
+                         return_logits: bool = False):
+        """zutis.py:355-372.  Labels come from the fused upsample+argmax kernel; [B,n,H,W] is never materialised."""
+        lo = self.semantic_logits_lowres(patch_tokens, text)
+        B, n, h, w = lo.shape
+        if return_logits:
+            if size is None:
+                return lo
+            out = torch.empty((B, n, size[0], size[1]), dtype=f32, device=lo.device)
+            ops.upsample_bilinear_nchw(lo, B * n, h, w, size[0], size[1], out=out)
+            return out
+        H, Wd = (h, w) if size is None else (int(size[0]), int(size[1]))
+        labels = torch.empty((B, H, Wd), dtype=torch.int64, device=lo.device)
+        ops.upsample_argmax(lo, labels, B, n, h, w, H, Wd)
+        return labels

@@ -1,0 +1,160 @@
+"""Thin torch-tensor -> raw-pointer wrappers over the C ABI (include/zutis_hip.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream.  Every op launches a hand-written HIP
+kernel from libzutis_hip.so; a missing library or a non-GPU tensor is an error, never a fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_GELU_ERF = 0, 1, 2, 3, 4
+f16, f32 = torch.float16, torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.ZutisHipError("zutis_amd ops need GPU tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.ZutisHipError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residual=None, res_rows: int = 0,
+         act: int = ACT_NONE, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, batch: int = 1,
+         strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None, strideR: int = 0):
+    """out = act(A @ W^T + bias) + residual[m % res_rows].  A [M,K] f16, W [N,K] f16, out f32|f16 [M,N]."""
+    L = _lib.load()
+    M = A.shape[-2] if M is None else M
+    K = A.shape[-1] if K is None else K
+    N = W.shape[-2] if N is None else N
+    lda = A.stride(-2) if lda is None else lda
+    ldw = W.stride(-2) if ldw is None else ldw
+    ldc = out.stride(-2) if ldc is None else ldc
+    assert A.dtype == f16 and W.dtype == f16 and out.dtype in (f16, f32)
+    if residual is not None:
+        assert residual.dtype == f32
+        ldr = residual.stride(-2) if ldr is None else ldr
+        res_rows = res_rows or M
+    if bias is not None:
+        assert bias.dtype == f32 and bias.numel() >= N
+    _lib.check(L.zh_gemm_f16(_p(A), lda, strideA, _p(W), ldw, strideW, _p(out), ldc, strideC, int(out.dtype == f16),
+                             _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream()),
+               "zh_gemm_f16")
+    return out
+
+
+def attention(Q, K, V, O, *, batch, heads, Tq, Tk, head_dim, ldq, ldk, ldv, ldo, strideQ, strideK, strideV, strideO,
+              scale=None):
+    L = _lib.load()
+    scale = 1.0 / math.sqrt(head_dim) if scale is None else scale
+    _lib.check(L.zh_attention_f16(_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
+                                  batch, heads, Tq, Tk, head_dim, float(scale), _stream()), "zh_attention_f16")
+    return O
+
+
+def layernorm(x, gamma, beta, eps, rows, D, *, out_f32=None, out_f16=None, out_f16_plus=None, out_f32_plus=None,
+              add=None, add_rows=0, in_group_rows=None, in_group_stride=None, in_offset=0,
+              out_group_rows=None, out_group_stride=None, out_offset=0):
+    L = _lib.load()
+    in_group_rows = rows if in_group_rows is None else in_group_rows
+    in_group_stride = in_group_rows if in_group_stride is None else in_group_stride
+    out_group_rows = rows if out_group_rows is None else out_group_rows
+    out_group_stride = out_group_rows if out_group_stride is None else out_group_stride
+    _lib.check(L.zh_layernorm_f32(_p(x), in_group_rows, in_group_stride, in_offset,
+                                  out_group_rows, out_group_stride, out_offset, _p(gamma), _p(beta), float(eps),
+                                  _p(out_f32), _p(out_f16), _p(out_f16_plus), _p(out_f32_plus), _p(add), add_rows,
+                                  rows, D, _stream()), "zh_layernorm_f32")
+
+
+def assemble_tokens_ln(patch_emb, cls, pos, gamma, beta, eps, out, B, T, D):
+    L = _lib.load()
+    _lib.check(L.zh_assemble_tokens_ln(_p(patch_emb), _p(cls), _p(pos), _p(gamma), _p(beta), float(eps), _p(out),
+                                       B, T, D, _stream()), "zh_assemble_tokens_ln")
+
+
+def l2norm_rows(x, rows, D, out_f32=None, out_f16=None, eps=0.0):
+    L = _lib.load()
+    _lib.check(L.zh_l2norm_rows(_p(x), _p(out_f32), _p(out_f16), float(eps), rows, D, _stream()), "zh_l2norm_rows")
+
+
+def global_ln_l2(x, B, M, Cc, out_f32=None, out_f16=None, eps=1e-5, l2_eps=1e-7, workspace=None):
+    L = _lib.load()
+    need = L.zh_global_ln_l2_workspace_size(B, M, Cc)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    _lib.check(L.zh_global_ln_l2(_p(x), _p(out_f32), _p(out_f16), float(eps), float(l2_eps), B, M, Cc, _p(workspace),
+                                 workspace.numel() * workspace.element_size(), _stream()), "zh_global_ln_l2")
+
+
+def im2col(x, out, patch, Kpad):
+    L = _lib.load()
+    B, Cin, H, W = x.shape
+    _chk(x, f32, "im2col x")
+    _lib.check(L.zh_im2col_f16(_p(x), _p(out), B, Cin, H, W, patch, Kpad, _stream()), "zh_im2col_f16")
+
+
+def posembed_bicubic(pos, out, grid, h, w, D, scale_h, scale_w, has_cls=True):
+    L = _lib.load()
+    _lib.check(L.zh_posembed_bicubic(_p(pos), _p(out), grid, h, w, D, float(np.float32(scale_h)), float(np.float32(scale_w)),
+                                     int(has_cls), _stream()), "zh_posembed_bicubic")
+
+
+def upsample2x_cl(x, B, h, w, D, out_f32=None, out_f16=None):
+    L = _lib.load()
+    _lib.check(L.zh_upsample2x_bilinear_cl(_p(x), _p(out_f32), _p(out_f16), B, h, w, D, _stream()), "zh_upsample2x_bilinear_cl")
+
+
+def sine_pe(out, h, w, D, temperature=10000.0):
+    L = _lib.load()
+    _lib.check(L.zh_sine_pe(_p(out), h, w, D, float(temperature), _stream()), "zh_sine_pe")
+
+
+def add_rowperiodic_f16(a, add, out, rows, D, add_rows):
+    L = _lib.load()
+    _lib.check(L.zh_add_rowperiodic_f16(_p(a), _p(add), _p(out), rows, D, add_rows, _stream()), "zh_add_rowperiodic_f16")
+
+
+def cast_f16(x, out, rows, D, add=None, add_rows=0):
+    L = _lib.load()
+    _lib.check(L.zh_cast_f32_f16(_p(x), _p(add), add_rows, _p(out), rows, D, _stream()), "zh_cast_f32_f16")
+
+
+def lin_scale(in_size: int, out_size: int) -> float:
+    """ATen area_pixel_compute_scale for size= calls: float32(in)/float32(out)."""
+    return float(np.float32(in_size) / np.float32(out_size))
+
+
+def upsample_argmax(logits_lo, labels, B, n, h, w, H, W):
+    L = _lib.load()
+    _lib.check(L.zh_upsample_argmax(_p(logits_lo), _p(labels), B, n, h, w, H, W, lin_scale(h, H), lin_scale(w, W), _stream()),
+               "zh_upsample_argmax")
+
+
+def upsample_bilinear_nchw(x, planes, h, w, H, W, out=None, mask_u8=None, threshold=0.5):
+    L = _lib.load()
+    _lib.check(L.zh_upsample_bilinear_nchw(_p(x), _p(out), _p(mask_u8), float(threshold), planes, h, w, H, W,
+                                           lin_scale(h, H), lin_scale(w, W), _stream()), "zh_upsample_bilinear_nchw")
+
+
+def confusion_hist(label_true, label_pred, hist, n_class):
+    L = _lib.load()
+    _chk(label_true, torch.int64, "label_true")
+    _chk(label_pred, torch.int64, "label_pred")
+    _chk(hist, torch.int64, "hist")
+    _lib.check(L.zh_confusion_hist(_p(label_true), _p(label_pred), _p(hist), label_true.numel(), n_class, _stream()),
+               "zh_confusion_hist")
