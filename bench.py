@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric of BASELINE.json on MI355X: images/sec of ZUTIS ViT-B/16 dense semantic
+segmentation @336px (forward + semantic predict), synthetic data, random-init weights of the real architecture.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch per GPU: ZutisEngine.forward (encoder, x2 upsample, ffn1,
+6-layer decoder, ffn2, mask einsum, text-space projection) + predict_semantic (class-logit GEMM + fused
+bilinear-upsample/argmax to 336x336 labels).  Inputs are resident in HBM before the timed region.
+For N > 1 images are sharded by rank (weak scaling, 32 per GPU) and each step all-gathers the low-res class
+logits over RCCL/xGMI (north_star: "RCCL all-gather of logits for evaluation"), overlapped with the next step.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) incl. `roofline` (dominant kernel = the fp16 MFMA
+GEMM, measured with HIP events around every launch of an instrumented step) and `cpu_baseline` (the oracle = CPU
+port of the reference path, timed on the host cores on a bounded sample, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+FLOPS_PER_IMAGE_C2 = 124.4e9 + 0.146e9  # forward + semantic predict
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE config[1]: batch 32)")
+    ap.add_argument("--size", type=int, default=336)
+    ap.add_argument("--classes", type=int, default=81)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch intra-op threads of the CPU baseline (16 was the fastest of 8..128 on the 2x64-core GPU box)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    from zutis_amd import detgen, ops
+    from zutis_amd.engine import ZutisEngine
+
+    cfg = detgen.VIT_B16
+    B, S, n = args.batch, args.size, args.classes
+    P = {k: torch.from_numpy(v).to(dev) for k, v in detgen.zutis_state_dict(cfg).items()}
+    eng = ZutisEngine(P, cfg.patch, cfg.dec_heads)
+    text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
+    # rank r owns global images [r*B, (r+1)*B): contiguous shards so a gather reproduces reference order
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    x = torch.randn((B, 3, S, S), generator=g).to(dev)
+    hw2 = (2 * ((S - cfg.patch) // cfg.patch + 1)) ** 2
+    gathered = [torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None]
+
+    def step(i: int):
+        out = eng.forward(x)
+        lo = eng.semantic_logits_lowres(out["patch_tokens"], text)
+        labels = torch.empty((B, S, S), dtype=torch.int64, device=dev)
+        ops.upsample_argmax(lo, labels, B, n, lo.shape[2], lo.shape[3], S, S)
+        if world > 1:
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = dist.all_gather_into_tensor(gathered[i & 1], lo.view(B, n, hw2), async_op=True)
+        return labels
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        if pending[0] is not None:
+            pending[0].wait()
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        labels = step(i)
+    if world > 1 and pending[0] is not None:
+        pending[0].wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel: HIP events (torch current stream == launch stream) around every launch
+    prof = {}
+
+    def profiler(name, work, launch):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = launch()
+        e1.record()
+        prof.setdefault(name, []).append((work, e0, e1))
+        return r
+
+    roof = None
+    if rank == 0:
+        ops.PROFILER = profiler
+        for i in range(2):
+            prof.clear()
+            out = eng.forward(x)
+            eng.predict_semantic(out["patch_tokens"], text, (S, S))
+        torch.cuda.synchronize()
+        ops.PROFILER = None
+        stats = {k: (len(v), sum(w for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
+        nl, fl, tt = stats["gemm_f16"]
+        ach = fl / tt / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_f16_kernel", "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
+                "gemm_share_of_step": round(tt / (elapsed / args.steps), 3)}
+        if "attention_f16" in stats:
+            na, fa, ta = stats["attention_f16"]
+            roof["attention_tflops"] = round(fa / ta / 1e12, 1)
+            roof["attention_share_of_step"] = round(ta / (elapsed / args.steps), 3)
+
+    # ---- CPU baseline: the oracle (CPU port of the reference path) on a bounded sample, rank 0 at N=1 only
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import zutis_ref as O
+        torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+        Pc = O.to_torch_params(detgen.zutis_state_dict(cfg))
+        ns = max(1, min(args.cpu_sample, B))
+        xs = x[:ns].cpu()
+        tc = text.cpu()
+
+        def cpu_pass(xi):
+            with torch.no_grad():
+                o = O.zutis_forward(Pc, xi, cfg.patch, cfg.dec_heads)
+                return o, O.predict_semantic(o["patch_tokens"], tc, size=(S, S))
+        cpu_pass(xs[:1])                                  # warm-up
+        t1 = time.perf_counter()
+        chunks = [cpu_pass(xs[i:i + 8]) for i in range(0, ns, 8)]
+        dt = time.perf_counter() - t1
+        o_ref = {"patch_tokens": torch.cat([c[0]["patch_tokens"] for c in chunks])}
+        lab_ref = np.concatenate([c[1] for c in chunks])
+        cpu = {"value": round(ns / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{ns} of the {B} step images in chunks of 8, oracle forward + semantic predict after a 1-image warm-up, "
+                         f"{dt:.1f}s; host has {os.cpu_count()} hardware threads"}
+        lo_ref = O.semantic_logits_lowres(o_ref["patch_tokens"], tc).numpy()
+        out = eng.forward(x[:ns])
+        lo = eng.semantic_logits_lowres(out["patch_tokens"], text).cpu().numpy()
+        lab = eng.predict_semantic(out["patch_tokens"], text, (S, S)).cpu().numpy()
+        hist = O.confusion_hist(lab_ref, lab, n)
+        parity = {"logit_max_abs_err": float(np.abs(lo - lo_ref).max()), "label_agreement": float((lab == lab_ref).mean()),
+                  "miou_vs_oracle_labels": float(O.scores_from_hist(hist)[0]["Mean IoU"]), "tolerance": 1e-3}
+
+    if rank == 0:
+        total_images = world * B * args.steps
+        line = {
+            "metric": "images/sec, COCO2017-val-shaped ViT-B/16 dense semantic segmentation @336px (ZUTIS forward + semantic predict)",
+            "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"C2: ViT-B/16 CLIP encoder + ZUTIS head, {B}x3x{S}x{S} per GPU, {n} classes, "
+                                   f"predict(semantic,size=({S},{S}))", "global_batch": world * B, "image_size": S,
+                       "n_classes": n, "parallelism": f"dp{world}", "accumulate": "f32", "residual_stream": "f32",
+                       "collective": "all_gather(low-res logits) per step, overlapped" if world > 1 else "none",
+                       "flops_per_image": FLOPS_PER_IMAGE_C2},
+            "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1),
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

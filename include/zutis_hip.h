@@ -118,6 +118,24 @@ int zh_upsample_bilinear_nchw(const float* x, float* out, unsigned char* mask_u8
 int zh_confusion_hist(const long long* label_true, const long long* label_pred, long long* hist_accum, long total,
                       int n_class, zh_stream_t stream);
 
+/* ---- instance prediction, zutis.py:374-420 ---- */
+/* binary = p > threshold; size = sum(binary); confidence = sum(p*binary)/(size+1e-7)   (zutis.py:390-397).
+ * mask_proposals f32: image b at + b*stride_image, [Q, M] contiguous inside (last decoder layer slice). */
+int zh_instance_mask_stats(const float* mask_proposals, long stride_image, float threshold, int B, int Q, int M,
+                           float* sizes, float* confidence, unsigned char* binary, zh_stream_t stream);
+/* avg[b,q,:] = sum_m binary[b,q,m]*tokens[b,m,:] / (size+1e-7)  (zutis.py:404-406; the reference materialises
+ * B x Q x hw x E). */
+int zh_masked_mean_tokens(const float* tokens, const unsigned char* binary, const float* sizes, float* avg,
+                          int B, int Q, int M, int E, zh_stream_t stream);
+/* category = argmax_n sigmoid(T * text_n . avg/(||avg||+1e-7)); score = confidence * max  (zutis.py:409-420). */
+int zh_instance_classify(const float* avg, const float* text, const float* confidence, float temperature,
+                         int rows, int n_classes, int E, long long* category, float* score, zh_stream_t stream);
+/* pairwise |a&b|, |a|b| of n {0,1} u8 masks (bit-packed popcount): utils/iou.py:6-37 inside the NMS loop
+ * zutis.py:245-278. */
+size_t zh_mask_iou_workspace_size(int n, long pixels);
+int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels, int* inter, int* uni,
+                       void* workspace, size_t workspace_bytes, zh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

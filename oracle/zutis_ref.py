@@ -278,7 +278,7 @@ def mask_nms(masks: np.ndarray, scores: np.ndarray, cats: np.ndarray, nms_type: 
                 if s > threshold:
                     nc.append(m)
                     ns.append(s)
-            cand, cs = nc, np.array(ns, dtype=scores.dtype)
+            cand, cs = nc, np.array(ns)
         for m, s in sel:
             if masks[m].sum() == 0:
                 continue

@@ -44,6 +44,11 @@ _SIGS = {
     "zh_upsample_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "zh_upsample_bilinear_nchw": (_i, [_vp, _vp, _vp, _f, _l, _i, _i, _i, _i, _f, _f, _vp]),
     "zh_confusion_hist": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "zh_instance_mask_stats": (_i, [_vp, _l, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "zh_masked_mean_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "zh_instance_classify": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "zh_mask_iou_workspace_size": (_sz, [_i, _l]),
+    "zh_mask_iou_counts": (_i, [_vp, _i, _l, _vp, _vp, _vp, _sz, _vp]),
 }
 
 
@@ -56,6 +61,7 @@ def load():
         raise ZutisHipError(
             f"{LIB_PATH} is missing: the HIP extension is REQUIRED (no CPU fallback). "
             "Build it with `python -m zutis_amd.build`.")
+    import torch  # noqa: F401  (first: the process must use ONE HIP runtime — the one torch loads; libzutis_hip binds to it)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         if not hasattr(lib, name):

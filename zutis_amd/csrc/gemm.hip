@@ -3,24 +3,31 @@
 //   C[b][m][n] = act( sum_k A[b][m][k] * W[b][n][k] + bias[n] ) + R[b][m % res_rows][n]
 //
 // Both operands are K-contiguous ("NT" form = torch Linear layout, networks/clip_arch.py:304-310),
-// so one kernel serves every contraction on the hot path: patch-embed conv-as-GEMM
+// so one kernel family serves every contraction on the hot path: patch-embed conv-as-GEMM
 // (clip_arch.py:378), QKV/out-proj/MLP (clip_arch.py:314-320), ffn1/ffn2 (zutis.py:546-549),
 // decoder projections/FFN (transformer.py:272-290), the mask einsum (zutis.py:196-198, batched, sigmoid
 // epilogue), the text-space projection (zutis.py:319) and the class-logit einsum (zutis.py:361-365).
 //
-// Design (MI355X): 128x128x64 block tile, 4 waves in 2x2, each wave 64x64 = 4x4 tiles of
-// v_mfma_f32_16x16x32_f16.  Operand roles are swapped (MFMA-A = W rows, MFMA-B = A rows) so a lane's
-// 4 accumulator registers are 4 consecutive n of one output row -> 16-byte row-major stores and
-// float4 bias/residual loads.  Tiles are staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round
-// trip), double-buffered; the LDS image is lane-linear, bank conflicts are removed by XOR-ing the
-// 16-byte chunk index with (row & 7) on the *source* address and on the ds_read_b128 address
-// (conflict-free for the 16x16x32 operand maps).  Block ids are remapped so each XCD's L2 sees a
-// contiguous range of tiles.
+// Design (MI355X):
+//  * v_mfma_f32_16x16x32_f16; operand roles swapped (MFMA-A = W rows, MFMA-B = A rows) so a lane's 4
+//    accumulator registers are 4 consecutive n of one output row -> 16-byte row-major stores and float4
+//    bias/residual loads.
+//  * Block tiles 256x256 / 256x192 (8 waves, 2x4) for the big GEMMs, 128x128 (4 waves) for small ones; the
+//    first profile showed the 128x128x64 double-buffered version was load-LATENCY bound (K-step time == loaded
+//    L2 latency ~1.2 us), so the K loop is now a 4-stage ring of BK=32 slices: HBM/L2 -> LDS by
+//    global_load_lds_dwordx4 issued THREE slices ahead, retired by a counted s_waitcnt vmcnt(N) + one raw
+//    s_barrier per slice (never vmcnt(0) in the steady state).  Per-lane source pointers are advanced by a
+//    constant, so a slice costs 4 DMA issues + 4 pointer adds per wave.
+//  * LDS image is lane-linear (64-byte rows, 16 rows per 1-KiB DMA piece); ds_read_b128 bank conflicts are
+//    removed by XOR-ing the 16-byte chunk index with (-(row>>2))&3 on the DMA *source* address and on the read
+//    address (conflict-free for the 16x16x32 operand lane groups).
+//  * Block ids: XCD-aware bijective remap, then 8-row super-tiles so one XCD's concurrent tiles share panels in
+//    its 4 MiB L2 (measured L2 hit rate 82 %).
 #include "common.h"
 
-#define BM 128
-#define BN 128
-#define BK 64
+#define BK 32
+#define STAGES 4
+#define GROUP_M 8
 
 struct GemmArgs {
   const half_t* A; long lda, sA;
@@ -34,122 +41,184 @@ struct GemmArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-__device__ __forceinline__ void stage_tile(const half_t* __restrict__ g, long ld, int row0, int nrows, int k0,
-                                           half_t* s, int wave, int lane) {
-  // tile = 128 rows x 64 halves (128 B per row); one wave-instruction fills 8 rows (1 KiB).
-  const int rsub = lane >> 3;
-  const int kc = (lane & 7) ^ rsub;  // logical 16-B chunk stored at physical chunk (lane&7) of row (..&7)==rsub
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int rg = wave * 4 + t;
-    int row = row0 + rg * 8 + rsub;
-    row = row < nrows ? row : nrows - 1;
-    const half_t* src = g + (long)row * ld + k0 + kc * 8;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(s + rg * 8 * BK), 16, 0, 0);
-  }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+  static_assert(N == 0 || N == 4 || N == 8, "unsupported vmcnt");
+  if (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int OUT_F16>
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) half_t smem[2 * (BM + BN) * BK];  // 64 KiB
+// WM x WN waves; each wave owns TM x TN subtiles of 16x16.  Block tile = (WM*TM*16) x (WN*TN*16).
+template <int WM, int WN, int TM, int TN, int OUT_F16>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int ROWS = BM + BN;             // LDS rows per stage (A rows then W rows), 64 B each
+  constexpr int PIECES = ROWS / 16;         // 1-KiB DMA pieces per stage
+  constexpr int NP = 4;                     // DMA issues per wave per stage (duplicates pad uneven splits)
+  static_assert((PIECES + NW - 1) / NW <= NP, "tile needs more than 4 pieces per wave");
+  constexpr int STAGE_HALVES = ROWS * BK;
+  __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE_HALVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
-  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous tile range
+  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous id range
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tiles = p.nbm * p.nbn;
   const int batch = wg / tiles;
   const int trem = wg - batch * tiles;
-  const int tm = trem / p.nbn, tn = trem - tm * p.nbn;
+  // super-tile order: GROUP_M consecutive ids walk GROUP_M m-tiles of one n-tile
+  const int gsz = GROUP_M * p.nbn;
+  const int gid = trem / gsz;
+  const int gfirst = gid * GROUP_M;
+  const int grows = min(p.nbm - gfirst, GROUP_M);
+  const int gl = trem - gid * gsz;
+  const int tm = gfirst + gl % grows, tn = gl / grows;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const half_t* A = p.A + (long)batch * p.sA;
   const half_t* W = p.W + (long)batch * p.sW;
 
-  f32x4 acc[4][4];
+  // per-lane DMA source pointers: piece pc covers LDS rows [16*pc, 16*pc+16); lane -> row (lane>>2), phys chunk lane&3
+  const half_t* gp[NP];
+  int lds_piece[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NP; ++i) {
+    int pc = wave + i * NW;
+    pc = pc < PIECES ? pc : PIECES - 1;
+    lds_piece[i] = pc * 16 * BK;
+    const int R = pc * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((-(R >> 2)) & 3);
+    if (R < BM) {
+      int row = m0 + R;
+      row = row < p.M ? row : p.M - 1;
+      gp[i] = A + (long)row * p.lda + c * 8;
+    } else {
+      int row = n0 + (R - BM);
+      row = row < p.N ? row : p.N - 1;
+      gp[i] = W + (long)row * p.ldw + c * 8;
+    }
+  }
+  auto issue_stage = [&](int slot) {
+    half_t* sb = smem + slot * STAGE_HALVES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NP; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(sb + lds_piece[i]), 16, 0, 0);
+      gp[i] += BK;
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  stage_tile(A, p.lda, m0, p.M, 0, smem, wave, lane);
-  stage_tile(W, p.ldw, n0, p.N, 0, smem + BM * BK, wave, lane);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue_stage(s);
 
   const int frow = lane & 15, fk = lane >> 4;
-  int cur = 0;
+  const int foff = frow * BK + ((fk ^ ((-(frow >> 2)) & 3)) * 8);   // per-lane offset inside a 16-row subtile
+  const half_t* rdA = smem + (wr * TM * 16) * BK + foff;
+  const half_t* rdW = smem + (BM + wc * TN * 16) * BK + foff;
+
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      half_t* nxt = smem + (cur ^ 1) * (BM + BN) * BK;
-      stage_tile(A, p.lda, m0, p.M, (kt + 1) * BK, nxt, wave, lane);
-      stage_tile(W, p.ldw, n0, p.N, (kt + 1) * BK, nxt + BM * BK, wave, lane);
-    }
-    const half_t* sA = smem + cur * (BM + BN) * BK;
-    const half_t* sW = sA + BM * BK;
+    const int ahead = nk - 1 - kt;            // stages issued after the one we are about to read
+    if (ahead >= 2) wait_vmcnt_barrier<8>();
+    else if (ahead == 1) wait_vmcnt_barrier<4>();
+    else wait_vmcnt_barrier<0>();
+    if (kt + STAGES - 1 < nk) issue_stage((kt + STAGES - 1) % STAGES);
+    const int so = (kt % STAGES) * STAGE_HALVES;
+    half8_t fa[TM], fw[TN];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8_t fa[4], fw[4];
-      const int kc = ks * 4 + fk;
-      const int sw = (kc ^ (frow & 7)) * 8;
+    for (int t = 0; t < TM; ++t) fa[t] = *(const half8_t*)(rdA + so + t * 16 * BK);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fa[t] = *(const half8_t*)(sA + (wr * 64 + t * 16 + frow) * BK + sw);
-        fw[t] = *(const half8_t*)(sW + (wc * 64 + t * 16 + frow) * BK + sw);
-      }
+    for (int t = 0; t < TN; ++t) fw[t] = *(const half8_t*)(rdW + so + t * 16 * BK);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    cur ^= 1;
+      for (int mt = 0; mt < TM; ++mt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
   }
 
   // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4)
   const long cb = (long)batch * p.sC;
   const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wr * 64 + mt * 16 + frow;
-    if (m >= p.M) continue;
-    const long rrow = R ? (long)(m % p.res_rows) * p.ldr : 0;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wc * 64 + nt * 16 + fk * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[nt][mt];
-      if (p.vec_ok) {
-        if (p.bias) v += *(const f32x4*)(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = zh_act(v[e], p.act);
-        if (R) v += *(const f32x4*)(R + rrow + n);
-        if (OUT_F16) {
-          half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *(half4_t*)((half_t*)p.C + cb + (long)m * p.ldc + n) = h;
-        } else {
-          *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = v;
+  const int act = p.act;
+  if (p.vec_ok) {
+#pragma clang loop unroll(full)
+    for (int mt = 0; mt < TM; ++mt) {
+      const int m = m0 + (wr * TM + mt) * 16 + frow;
+      const bool mok = m < p.M;
+      const long rrow = R ? (long)(m % p.res_rows) * p.ldr : 0;
+#pragma clang loop unroll(full)
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+        if (mok && n < p.N) {
+          f32x4 v = acc[nt][mt];
+          if (p.bias) v += *(const f32x4*)(p.bias + n);
+          if (act != ZH_ACT_NONE) {
+            v[0] = zh_act(v[0], act); v[1] = zh_act(v[1], act); v[2] = zh_act(v[2], act); v[3] = zh_act(v[3], act);
+          }
+          if (R) v += *(const f32x4*)(R + rrow + n);
+          if (OUT_F16) {
+            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *(half4_t*)((half_t*)p.C + cb + (long)m * p.ldc + n) = h;
+          } else {
+            *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = v;
+          }
         }
-      } else {
-#pragma unroll
+      }
+    }
+  } else {   // unaligned / odd-N fallback: scalar stores (rare: class-logit GEMMs with odd pixel counts)
+#pragma clang loop unroll(full)
+    for (int mt = 0; mt < TM; ++mt) {
+      const int m = m0 + (wr * TM + mt) * 16 + frow;
+      const long rrow = R ? (long)(m % p.res_rows) * p.ldr : 0;
+#pragma clang loop unroll(full)
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+#pragma clang loop unroll(full)
         for (int e = 0; e < 4; ++e) {
-          if (n + e >= p.N) break;
-          float x = v[e];
-          if (p.bias) x += p.bias[n + e];
-          x = zh_act(x, p.act);
-          if (R) x += R[rrow + n + e];
-          if (OUT_F16) ((half_t*)p.C)[cb + (long)m * p.ldc + n + e] = (half_t)x;
-          else ((float*)p.C)[cb + (long)m * p.ldc + n + e] = x;
+          if (m < p.M && n + e < p.N) {
+            float x = acc[nt][mt][e];
+            if (p.bias) x += p.bias[n + e];
+            x = zh_act(x, act);
+            if (R) x += R[rrow + n + e];
+            if (OUT_F16) ((half_t*)p.C)[cb + (long)m * p.ldc + n + e] = (half_t)x;
+            else ((float*)p.C)[cb + (long)m * p.ldc + n + e] = x;
+          }
         }
       }
     }
   }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_gemm(const GemmArgs& p0, int batch, int out_f16, hipStream_t stream) {
+  GemmArgs p = p0;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  p.nbm = zh_cdiv(p.M, BM);
+  p.nbn = zh_cdiv(p.N, BN);
+  const unsigned nblk = (unsigned)((long)p.nbm * p.nbn * batch);
+  if (out_f16) hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, 1>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
+  else hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, 0>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
+}
+
+// Relative time estimate of a tiling: rounds of the 256-CU chip x time of one round.  With `bpc` blocks resident
+// per CU a round takes bpc x the tile's own time; `eff` is the measured relative speed of the tile shape at
+// K=768 (256x256: 1.0, 256x192: 0.95, 128x128: 0.8 — tools/gemm_bench.py on MI355X).
+static double tiling_cost(long M, long N, int batch, int BM, int BN, int bpc, double eff) {
+  const long tiles = (long)zh_cdiv(M, BM) * zh_cdiv(N, BN) * batch;
+  const long slots = 256L * bpc;
+  const long rounds = (tiles + slots - 1) / slots;
+  return (double)rounds * BM * BN * bpc / eff;
 }
 
 extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, long strideW,
@@ -158,7 +227,7 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
                            int act, int M, int N, int K, int batch, hipStream_t stream) {
   ZH_CHECK_ARG(A && W && C, "zh_gemm_f16: null operand");
   ZH_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "zh_gemm_f16: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
-  ZH_CHECK_ARG(K % BK == 0, "zh_gemm_f16: K=%d must be a multiple of %d", K, BK);
+  ZH_CHECK_ARG(K % 64 == 0, "zh_gemm_f16: K=%d must be a multiple of 64", K);
   ZH_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && strideA % 8 == 0 && strideW % 8 == 0,
                "zh_gemm_f16: lda/ldw/strides must be multiples of 8 halves (16-byte rows)");
   ZH_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "zh_gemm_f16: A/W must be 16-byte aligned");
@@ -169,16 +238,21 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   p.W = (const half_t*)W; p.ldw = ldw; p.sW = strideW;
   p.C = C; p.ldc = ldc; p.sC = strideC;
   p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
-  p.M = M; p.N = N; p.K = K; p.act = act;
-  p.nbm = zh_cdiv(M, BM); p.nbn = zh_cdiv(N, BN);
+  p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
   const int esz = out_f16 ? 2 : 4;
   p.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && (strideC % 4 == 0) && (((uintptr_t)C & (4 * esz - 1)) == 0) &&
              (!bias || ((uintptr_t)bias & 15) == 0) &&
              (!residual || (ldr % 4 == 0 && strideR % 4 == 0 && ((uintptr_t)residual & 15) == 0));
-  const long nblk = (long)p.nbm * p.nbn * batch;
-  ZH_CHECK_ARG(nblk < (1L << 31), "zh_gemm_f16: grid too large");
-  if (out_f16) hipLaunchKernelGGL(gemm_f16_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(gemm_f16_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  ZH_CHECK_ARG((long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch < (1L << 31), "zh_gemm_f16: grid too large");
+  const char* force = getenv("ZH_GEMM_TILE");   // developer override: 128 | 192 | 256
+  const double c256 = tiling_cost(M, N, batch, 256, 256, 1, 1.0);
+  const double c192 = tiling_cost(M, N, batch, 256, 192, 1, 0.95);
+  const double c128 = tiling_cost(M, N, batch, 128, 128, 2, 0.8);
+  int pick = (c128 < c256 && c128 < c192) ? 128 : (c192 < c256 ? 192 : 256);
+  if (force) pick = atoi(force);
+  if (pick == 128) launch_gemm<2, 2, 4, 4>(p, batch, out_f16, stream);
+  else if (pick == 192) launch_gemm<2, 4, 8, 3>(p, batch, out_f16, stream);
+  else launch_gemm<2, 4, 8, 4>(p, batch, out_f16, stream);
   ZH_CHECK_LAUNCH("zh_gemm_f16");
   return ZH_OK;
 }

@@ -1,0 +1,199 @@
+// Instance-prediction kernels (networks/zutis.py:374-420): per-query mask statistics, masked mean of the
+// text-space patch tokens, and the per-query class / score.  The reference materialises
+// patch_tokens[:,None] * binary_masks[...,None] = B x Q x hw x 512 fp32 (2.9 GB at B=8, zutis.py:404-406);
+// here the masked mean is a streaming reduction that reads each image's tokens from L2.
+#include "common.h"
+
+// ---- per (image, query): size = #(p > thr), conf = sum(p * (p > thr)) / (size + 1e-7)   (zutis.py:390-397)
+__global__ __launch_bounds__(256) void instance_stats_kernel(const float* mp, long stride_b, float thr, long rows, int Q, int M,
+                                                             float* sizes, float* conf, unsigned char* binary) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // r = b*Q + q
+  if (r >= rows) return;
+  const int b = (int)(r / Q), q = (int)(r % Q);
+  const float* p = mp + (long)b * stride_b + (long)q * M;
+  float cnt = 0.f, s = 0.f;
+  for (int m = lane; m < M; m += 64) {
+    const float v = p[m];
+    const bool on = v > thr;
+    cnt += on ? 1.f : 0.f;
+    s += on ? v : 0.f;
+    binary[r * M + m] = on ? 1 : 0;
+  }
+  cnt = wave_sum(cnt);
+  s = wave_sum(s);
+  if (lane == 0) { sizes[r] = cnt; conf[r] = s / (cnt + 1e-7f); }
+}
+
+extern "C" int zh_instance_mask_stats(const float* mask_proposals, long stride_image, float threshold, int B, int Q, int M,
+                                      float* sizes, float* confidence, unsigned char* binary, hipStream_t stream) {
+  ZH_CHECK_ARG(mask_proposals && sizes && confidence && binary && B > 0 && Q > 0 && M > 0, "zh_instance_mask_stats: bad arguments");
+  const long rows = (long)B * Q;
+  hipLaunchKernelGGL(instance_stats_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, mask_proposals, stride_image, threshold, rows, Q, M,
+                     sizes, confidence, binary);
+  ZH_CHECK_LAUNCH("zh_instance_mask_stats");
+  return ZH_OK;
+}
+
+// ---- avg[b,q,:] = sum_m binary[b,q,m] * tokens[b,m,:] / (size[b,q] + 1e-7)   (zutis.py:404-406)
+// block = (image, tile of QT queries); thread owns CPT channels; masks of the tile are staged in LDS by chunks.
+#define QT 10
+#define MCH 512
+template <int CPT>
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float* tokens, const unsigned char* binary, const float* sizes,
+                                                          float* avg, int Q, int M, int E) {
+  __shared__ unsigned char sm[QT][MCH];
+  const int b = blockIdx.y, q0 = blockIdx.x * QT;
+  const int nq = min(QT, Q - q0);
+  const float* tk = tokens + (long)b * M * E;
+  float acc[QT][CPT];
+#pragma unroll
+  for (int q = 0; q < QT; ++q)
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[q][c] = 0.f;
+  for (int m0 = 0; m0 < M; m0 += MCH) {
+    const int mc = min(MCH, M - m0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < QT * MCH; i += 256) {
+      const int q = i / MCH, m = i - q * MCH;
+      sm[q][m] = (q < nq && m < mc) ? binary[((long)b * Q + q0 + q) * M + m0 + m] : 0;
+    }
+    __syncthreads();
+    for (int m = 0; m < mc; ++m) {
+      float v[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const int ch = threadIdx.x + 256 * c;
+        v[c] = ch < E ? tk[(long)(m0 + m) * E + ch] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < QT; ++q) {
+        const float f = sm[q][m] ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) acc[q][c] += f * v[c];
+      }
+    }
+  }
+  for (int q = 0; q < nq; ++q) {
+    const float inv = 1.0f / (sizes[(long)b * Q + q0 + q] + 1e-7f);
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int ch = threadIdx.x + 256 * c;
+      if (ch < E) avg[((long)b * Q + q0 + q) * E + ch] = acc[q][c] * inv;
+    }
+  }
+}
+
+extern "C" int zh_masked_mean_tokens(const float* tokens, const unsigned char* binary, const float* sizes, float* avg,
+                                     int B, int Q, int M, int E, hipStream_t stream) {
+  ZH_CHECK_ARG(tokens && binary && sizes && avg && B > 0 && Q > 0 && M > 0 && E > 0, "zh_masked_mean_tokens: bad arguments");
+  ZH_CHECK_ARG(E <= 1024 && B < 65536, "zh_masked_mean_tokens: E=%d > 1024 unsupported", E);
+  dim3 grid(zh_cdiv(Q, QT), B);
+  if (E <= 256) hipLaunchKernelGGL(masked_mean_kernel<1>, grid, dim3(256), 0, stream, tokens, binary, sizes, avg, Q, M, E);
+  else if (E <= 512) hipLaunchKernelGGL(masked_mean_kernel<2>, grid, dim3(256), 0, stream, tokens, binary, sizes, avg, Q, M, E);
+  else hipLaunchKernelGGL(masked_mean_kernel<4>, grid, dim3(256), 0, stream, tokens, binary, sizes, avg, Q, M, E);
+  ZH_CHECK_LAUNCH("zh_masked_mean_tokens");
+  return ZH_OK;
+}
+
+// ---- per (image, query): v = avg / (||avg|| + 1e-7); prob_n = sigmoid(T * text_n . v);
+//      category = argmax_n (first max), score = conf * max_n prob      (zutis.py:409-420)
+__global__ __launch_bounds__(256) void instance_classify_kernel(const float* avg, const float* text, const float* conf, float temperature,
+                                                                int n, int E, long long* category, float* score) {
+  __shared__ float sv[1024];
+  __shared__ float red[4];
+  __shared__ float bestv[4];
+  __shared__ int besti[4];
+  const long r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* a = avg + r * E;
+  float q = 0.f;
+  for (int c = threadIdx.x; c < E; c += 256) { const float v = a[c]; sv[c] = v; q += v * v; }
+  q = wave_sum(q);
+  if (lane == 0) red[wave] = q;
+  __syncthreads();
+  const float inv = 1.0f / (sqrtf((red[0] + red[1]) + (red[2] + red[3])) + 1e-7f);
+  float bv = -1.f;
+  int bi = 0x7fffffff;
+  for (int cls = wave; cls < n; cls += 4) {
+    const float* t = text + (long)cls * E;
+    float d = 0.f;
+    for (int c = lane; c < E; c += 64) d += t[c] * (sv[c] * inv);
+    d = wave_sum(d);
+    const float pr = 1.0f / (1.0f + expf(-temperature * d));
+    if (pr > bv) { bv = pr; bi = cls; }          // classes ascend within a wave -> first max kept
+  }
+  if (lane == 0) { bestv[wave] = bv; besti[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = bestv[0];
+    int i = besti[0];
+    for (int w = 1; w < 4; ++w)
+      if (bestv[w] > v || (bestv[w] == v && besti[w] < i)) { v = bestv[w]; i = besti[w]; }
+    category[r] = i;
+    score[r] = conf[r] * v;
+  }
+}
+
+extern "C" int zh_instance_classify(const float* avg, const float* text, const float* confidence, float temperature,
+                                    int rows, int n_classes, int E, long long* category, float* score, hipStream_t stream) {
+  ZH_CHECK_ARG(avg && text && confidence && category && score && rows > 0 && n_classes > 0 && E > 0 && E <= 1024,
+               "zh_instance_classify: bad arguments");
+  hipLaunchKernelGGL(instance_classify_kernel, dim3(rows), dim3(256), 0, stream, avg, text, confidence, temperature, n_classes, E,
+                     category, score);
+  ZH_CHECK_LAUNCH("zh_instance_classify");
+  return ZH_OK;
+}
+
+// ---- pairwise mask IoU on bit-packed masks: iou[i][j] = |a_i & a_j| / (|a_i | a_j| + 1e-7)  (utils/iou.py:6-37)
+//      masks u8 {0,1} [n, P] -> inter/union counts int32 [n, n] (exact integers; the float divide happens on the host
+//      in float64 exactly as numpy does).
+__global__ __launch_bounds__(256) void mask_pack_kernel(const unsigned char* masks, unsigned long long* packed, long P, long W64, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per 64-bit word
+  if (idx >= total) return;
+  const long n = idx / W64, w = idx - n * W64;
+  const unsigned char* m = masks + n * P + w * 64;
+  unsigned long long bits = 0;
+  const long lim = P - w * 64 < 64 ? P - w * 64 : 64;
+  for (long i = 0; i < lim; ++i) bits |= (unsigned long long)(m[i] != 0) << i;
+  packed[idx] = bits;
+}
+
+__global__ __launch_bounds__(256) void mask_iou_counts_kernel(const unsigned long long* packed, int n, long W64, int* inter, int* uni) {
+  const int i = blockIdx.x, j = blockIdx.y;
+  if (j < i) return;
+  const unsigned long long* a = packed + (long)i * W64;
+  const unsigned long long* b = packed + (long)j * W64;
+  int ci = 0, cu = 0;
+  for (long w = threadIdx.x; w < W64; w += 256) {
+    const unsigned long long x = a[w], y = b[w];
+    ci += __popcll(x & y);
+    cu += __popcll(x | y);
+  }
+  __shared__ int ri[4], ru[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o, 64); cu += __shfl_xor(cu, o, 64); }
+  if ((threadIdx.x & 63) == 0) { ri[threadIdx.x >> 6] = ci; ru[threadIdx.x >> 6] = cu; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int I = ri[0] + ri[1] + ri[2] + ri[3], U = ru[0] + ru[1] + ru[2] + ru[3];
+    inter[(long)i * n + j] = I; inter[(long)j * n + i] = I;
+    uni[(long)i * n + j] = U; uni[(long)j * n + i] = U;
+  }
+}
+
+extern "C" size_t zh_mask_iou_workspace_size(int n, long pixels) { return (size_t)n * ((pixels + 63) / 64) * 8; }
+
+extern "C" int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels, int* inter, int* uni,
+                                  void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  ZH_CHECK_ARG(masks && inter && uni && n > 0 && pixels > 0 && n < 65536, "zh_mask_iou_counts: bad arguments");
+  const long W64 = (pixels + 63) / 64;
+  if (!workspace || workspace_bytes < zh_mask_iou_workspace_size(n, pixels)) {
+    zh_set_error("zh_mask_iou_counts: workspace too small");
+    return ZH_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(mask_pack_kernel, dim3(zh_cdiv((long)n * W64, 256)), dim3(256), 0, stream, masks, (unsigned long long*)workspace, pixels, W64, (long)n * W64);
+  hipLaunchKernelGGL(mask_iou_counts_kernel, dim3(n, n), dim3(256), 0, stream, (const unsigned long long*)workspace, n, W64, inter, uni);
+  ZH_CHECK_LAUNCH("zh_mask_iou_counts");
+  return ZH_OK;
+}

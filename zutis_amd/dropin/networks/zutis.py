@@ -1,0 +1,323 @@
+"""Drop-in replacement for the reference's networks/zutis.py (ZUTIS, MLP) on MI355X.
+
+Same constructor signature, attributes, state_dict keys/shapes (275 for ViT-B/16), forward() and predict()
+contract as the reference (networks/zutis.py:15-549), so main.py / trainer.py / coco20k_eval.py /
+utils.utils.get_network run unchanged.  The *insides* are different: torch modules are used only as parameter
+containers; forward()/predict() execute hand-written HIP kernels from libzutis_hip.so through
+zutis_amd.engine.ZutisEngine.  There is no torch-op or CPU fallback: without the HIP library or a GPU the calls
+raise.  Training (autograd) is out of scope and refused explicitly.
+
+Differences a maintainer should know:
+  * `clip` is optional.  If it is importable the constructor does what the reference does (clip.load, encode_text,
+    build the visual tower from its state_dict).  Otherwise pass `text_embeddings=` (and optionally
+    `clip_state_dict=`); the architecture comes from the clip_arch name.
+  * pycocotools / torchvision are optional (zutis_amd.rle restates encode / masks_to_boxes).
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from zutis_amd import ops as _ops
+from zutis_amd import rle as _rle
+from zutis_amd.engine import ZutisEngine
+
+try:  # optional third-party pieces of the reference environment
+    import clip as _clip
+except ImportError:  # pragma: no cover - absent in this image
+    _clip = None
+try:
+    from pycocotools.mask import encode as _coco_encode
+except ImportError:  # pragma: no cover
+    _coco_encode = None
+
+# clip_arch name -> (width, layers, patch, grid, embed_dim)   (openai/CLIP model cards; clip_arch.py:590-627 infers the same)
+_VIT_ARCHS = {
+    "ViT-B/32": (768, 12, 32, 7, 512),
+    "ViT-B/16": (768, 12, 16, 14, 512),
+    "ViT-L/14": (1024, 24, 14, 16, 768),
+    "ViT-L/14@336px": (1024, 24, 14, 24, 768),
+}
+
+
+class MLP(nn.Module):
+    """Parameter container with the reference's keys `layers.{i}.weight/bias` (networks/zutis.py:535-549)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        raise RuntimeError("MLP is executed inside the fused HIP plan (zutis_amd.engine); call ZUTIS.forward")
+
+
+class _ResidualAttentionBlock(nn.Module):
+    """Keys of clip_arch.ResidualAttentionBlock (clip_arch.py:300-321): attn.*, ln_1.*, mlp.c_fc.*, mlp.c_proj.*, ln_2.*"""
+
+    def __init__(self, d_model: int, n_head: int):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, n_head)
+        self.ln_1 = nn.LayerNorm(d_model)
+        self.mlp = nn.Module()
+        self.mlp.c_fc = nn.Linear(d_model, d_model * 4)
+        self.mlp.c_proj = nn.Linear(d_model * 4, d_model)
+        self.ln_2 = nn.LayerNorm(d_model)
+
+
+class _Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.Sequential(*[_ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+
+class VisionTransformer(nn.Module):
+    """Parameter container with clip_arch.VisionTransformer's keys and init (clip_arch.py:335-354)."""
+
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int, output_dim: int):
+        super().__init__()
+        self.input_resolution, self.output_dim, self.patch_size = input_resolution, output_dim, patch_size
+        self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = nn.LayerNorm(width)
+        self.transformer = _Transformer(width, layers, heads)
+        self.ln_post = nn.LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self.width = width
+
+
+class _DecoderLayer(nn.Module):
+    """Keys of transformer.TransformerDecoderLayer (networks/transformer.py:231-251)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+
+
+class _Decoder(nn.Module):
+    def __init__(self, d_model, nhead, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(_DecoderLayer(d_model, nhead) for _ in range(num_layers))
+        self.num_layers = num_layers
+        self.norm = nn.LayerNorm(d_model)
+        self.return_intermediate = True
+
+
+class ZUTIS(nn.Module):
+    def __init__(
+            self,
+            categories: List[str],
+            segmentation_type: str = "semantic",
+            clip_arch: str = "ViT-B/16",
+            n_queries: int = 100,
+            n_decoder_layers: int = 6,
+            n_heads: int = 8,
+            device: torch.device = torch.device("cuda:0"),
+            encoder_type: str = "clip",
+            frozen_bn: Optional[bool] = True,
+            stop_gradient: Optional[bool] = True,
+            decoder_image_n_dims: Optional[int] = None,
+            *,
+            text_embeddings: Optional[torch.Tensor] = None,
+            clip_state_dict: Optional[dict] = None,
+            vision_config: Optional[Tuple[int, int, int, int, int]] = None,
+    ):
+        super(ZUTIS, self).__init__()
+        assert segmentation_type in ["semantic", "instance"], f"Invalid segmentation type: {segmentation_type}."
+        if encoder_type is None:
+            encoder_type = "clip"
+        if encoder_type != "clip":
+            raise ValueError(encoder_type)      # reference zutis.py:105-106 (its "dino" branch imports a missing module)
+        arch = clip_arch.lstrip("dilated")
+        if "ViT" not in arch:
+            raise NotImplementedError(f"{clip_arch}: only the CLIP-ViT encoders are on the MI355X hot path (SURVEY.md §2)")
+
+        model = None
+        if text_embeddings is None or (clip_state_dict is None and vision_config is None and arch not in _VIT_ARCHS):
+            if _clip is None:
+                raise ImportError("`clip` is not installed: pass text_embeddings= (unit-norm [n_categories, dim]) "
+                                  "and, for non-standard towers, vision_config=/clip_state_dict=")
+            model, _ = _clip.load(arch, device=device)                                   # zutis.py:35
+        if text_embeddings is None:
+            te = model.encode_text(_clip.tokenize(categories).to(device)).to(dtype=torch.float32).detach()  # :36
+            te = te / te.norm(dim=1, keepdim=True)                                          # :37
+        else:
+            te = torch.as_tensor(text_embeddings, dtype=torch.float32).detach().to(device)
+        self.text_embeddings = te.requires_grad_(False)
+        self.category_to_text_embedding: Dict[str, torch.Tensor] = {
+            category: text_embedding for category, text_embedding in zip(categories, self.text_embeddings)
+        }
+        self.n_dims_text: int = self.text_embeddings.shape[1]
+        self.frozen_bn: bool = True if frozen_bn is None else frozen_bn
+        self.stop_gradient: bool = True if stop_gradient is None else stop_gradient
+        self.decoder_image_n_dims = decoder_image_n_dims
+
+        sd = clip_state_dict if clip_state_dict is not None else (model.state_dict() if model is not None else None)
+        if vision_config is not None:
+            width, layers, patch, grid, embed = vision_config
+        elif sd is not None:                                                               # clip_arch.py:595-600
+            width = sd["visual.conv1.weight"].shape[0]
+            layers = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+            patch = sd["visual.conv1.weight"].shape[-1]
+            grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+            embed = sd["visual.proj"].shape[1]
+        else:
+            width, layers, patch, grid, embed = _VIT_ARCHS[arch]
+        self.encoder = VisionTransformer(patch * grid, patch, width, layers, width // 64, embed)
+        if sd is not None:                                                                 # clip_arch.py:620-627 + zutis.py:55
+            vis = {k[len("visual."):]: v.float() for k, v in sd.items() if k.startswith("visual.")}
+            self.encoder.load_state_dict(vis, strict=True)
+        self.encoder.requires_grad_(True)
+
+        self.ffn1 = MLP(input_dim=width, hidden_dim=256, output_dim=width, num_layers=3)   # zutis.py:59-64
+        self.ffn2 = MLP(input_dim=width, hidden_dim=256, output_dim=width, num_layers=3)   # zutis.py:66-71
+        print(f"{encoder_type} is loaded.")
+        self.decoder = _Decoder(width, n_heads, n_decoder_layers)                           # zutis.py:114-126
+        self.query_embed = nn.Embedding(n_queries, width).weight                            # zutis.py:131-134
+
+        self.n_queries: int = n_queries
+        self.n_heads: int = n_heads
+        self.device: torch.device = device
+        self.clip_arch: str = clip_arch
+        self.encoder_type: str = encoder_type
+        self._engine: Optional[ZutisEngine] = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _get_engine(self) -> ZutisEngine:
+        if self._engine is None:
+            self._engine = ZutisEngine(dict(self.named_parameters()), self.encoder.patch_size, self.n_heads)
+        return self._engine
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._engine = None                      # parameters may have moved: rebuild the plan lazily
+        return out
+
+    def update_text_embeddings(self, categories):
+        if _clip is None:
+            raise ImportError("update_text_embeddings needs the `clip` package (reference zutis.py:333-338)")
+        model, _ = _clip.load(self.clip_arch.lstrip("dilated"), device=self.device)
+        te = model.encode_text(_clip.tokenize(categories).to(self.device)).to(dtype=torch.float32).detach()
+        self.text_embeddings = (te / te.norm(dim=1, keepdim=True)).requires_grad_(False)
+        print(f"text embeddings have been changed for {', '.join(categories)}")
+
+    # ------------------------------------------------------------------ forward
+    def forward_transformer_encoder(self, x: torch.Tensor):
+        return self._get_engine().encode(x.float())
+
+    def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """x: b x 3 x h x w  ->  {"mask_proposals": b x L x Q x 2h' x 2w' (sigmoid), "patch_tokens": b x 2h' x 2w' x dim}"""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "ZUTIS on MI355X is inference-only (the training loop is out of scope): wrap the call in "
+                "torch.no_grad() or call .requires_grad_(False) as trainer.evaluate / coco20k_eval.py do")
+        return self._get_engine().forward(x.float())
+
+    # ------------------------------------------------------------------ predict
+    @torch.no_grad()
+    def predict(
+            self,
+            dict_outputs: dict,
+            mask_type: str,
+            threshold: float = 0.5,
+            image_ids: Optional[List[int]] = None,
+            size: Optional[Tuple[int, int]] = None,
+            label_id_to_category: Optional[Dict[int, str]] = None,
+            new_label_id_to_old_label_id: Optional[Dict[int, int]] = None,
+            temperature: float = 5,
+            nms_type: str = "hard",
+            return_logits: bool = False
+    ):
+        assert mask_type in ["semantic", "instance"]
+        eng = self._get_engine()
+        if mask_type == "semantic":                                                        # zutis.py:355-372
+            size = None if size is None else (int(size[0]), int(size[1]))
+            out = eng.predict_semantic(dict_outputs["patch_tokens"], self.text_embeddings, size, return_logits)
+            return out if return_logits else out.cpu().numpy()
+
+        # instance prediction                                                              # zutis.py:374-470
+        mask_proposals: torch.Tensor = dict_outputs["mask_proposals"]
+        if len(mask_proposals.shape) == 5:
+            mask_proposals = mask_proposals[:, -1, ...]
+        assert 0 <= torch.min(mask_proposals) <= 1
+        assert 0 <= torch.max(mask_proposals) <= 1
+        size = None if size is None else (int(size[0]), int(size[1]))
+        masks_dev, scores, category_ids = eng.instance_candidates(
+            mask_proposals, dict_outputs["patch_tokens"], self.text_embeddings, threshold, temperature, size)
+        binary_masks: np.ndarray = masks_dev.cpu().numpy().astype(bool)
+        confidence_scores: np.ndarray = scores.cpu().numpy()
+        category_ids: np.ndarray = category_ids.cpu().numpy()
+        if image_ids is None:
+            image_ids = [0 for _ in range(len(binary_masks))]
+
+        predictions: List[dict] = list()
+        for bi, (m_img, s_img, c_img, image_id) in enumerate(zip(binary_masks, confidence_scores, category_ids, image_ids)):
+            if nms_type is None:
+                keep = [(int(c), q, s) for q, (s, c) in enumerate(zip(s_img, c_img)) if c != 0 and m_img[q].any()]
+            else:
+                iou = eng.mask_iou_matrix(masks_dev[bi]) if nms_type is not None else None
+                keep = self.non_maximum_suppression_indices(m_img, s_img, c_img, nms_type=nms_type, iou=iou)
+            for c, q, s in keep:
+                m = m_img[q]
+                label_id = new_label_id_to_old_label_id[c] if new_label_id_to_old_label_id is not None else c
+                prediction = {
+                    "category_id": label_id,
+                    "segmentation": (_coco_encode(np.asfortranarray(m)) if _coco_encode is not None else _rle.encode(m)),
+                    "score": float(s),
+                    "image_id": image_id,
+                    "image_size": m_img[0].shape[-2:],
+                    "bbox": _rle.mask_to_box(m),
+                }
+                if label_id_to_category is not None:
+                    prediction["pred_class"] = label_id_to_category[label_id]
+                predictions.append(prediction)
+        return predictions
+
+    @staticmethod
+    def non_maximum_suppression_indices(binary_masks, scores, category_ids, nms_type="hard", nms_threshold=0.3,
+                                        sigma=0.5, threshold=0.001, iou=None):
+        """Greedy per-category mask NMS with the reference's control flow (zutis.py:211-299), returning
+        (category, query index, score) in its emission order.  `iou` is the Q x Q matrix from the bit-packed
+        popcount kernel (exact integer counts / float64 divide = utils/iou.py on boolean masks)."""
+        assert nms_type in ["hard", "linear", "gaussian"]
+        out = []
+        for c in sorted(set(int(v) for v in category_ids)):
+            if c == 0:
+                continue
+            cand = list(np.nonzero(category_ids == c)[0])
+            cs = scores[cand].copy()
+            selected = []
+            while len(cand) > 0:
+                order = np.argsort(cs)
+                cand, cs = [cand[i] for i in order], cs[order]
+                best, best_s = cand[-1], cs[-1]
+                selected.append((best, best_s))
+                nc, ns = [], []
+                for m, s in zip(cand[:-1], cs[:-1]):
+                    v = iou[m, best] if iou is not None else (
+                        np.logical_and(binary_masks[m], binary_masks[best]).sum()
+                        / (np.logical_or(binary_masks[m], binary_masks[best]).sum() + 1e-7))
+                    if nms_type == "hard":
+                        wgt = 0 if v > nms_threshold else 1
+                    elif nms_type == "linear":
+                        wgt = (1 - v) if v > nms_threshold else 1
+                    else:
+                        wgt = np.exp(-(v * v) / sigma)
+                    s = s * wgt
+                    if s > threshold:
+                        nc.append(m)
+                        ns.append(s)
+                cand, cs = nc, np.array(ns)
+            for m, s in selected:
+                if binary_masks[m].any():
+                    out.append((c, int(m), s.item() if hasattr(s, "item") else float(s)))
+        return out

@@ -281,3 +281,40 @@ class ZutisEngine:
         labels = torch.empty((B, H, Wd), dtype=torch.int64, device=lo.device)
         ops.upsample_argmax(lo, labels, B, n, h, w, H, Wd)
         return labels
+
+    # ------------------------------------------------------------------ predict (instance)
+    def instance_candidates(self, mask_proposals_last: torch.Tensor, patch_tokens: torch.Tensor, text: torch.Tensor,
+                            threshold: float = 0.5, temperature: float = 5.0, size: Optional[Tuple[int, int]] = None):
+        """zutis.py:376-423 on device: binary masks, sizes, confidence, masked-mean tokens, class + score, and the
+        full-resolution thresholded masks.  Returns (masks u8 [B,Q,H,W], scores f32 [B,Q], category int64 [B,Q])."""
+        self._pack()
+        mp = mask_proposals_last.contiguous()
+        B, Q, h, w = mp.shape
+        M, E, dev = h * w, patch_tokens.shape[-1], mp.device
+        pt = patch_tokens.contiguous()
+        t32 = text.detach().to(device=dev, dtype=f32).contiguous()
+        sizes = torch.empty((B * Q,), dtype=f32, device=dev)
+        conf = torch.empty((B * Q,), dtype=f32, device=dev)
+        binary = torch.empty((B, Q, h, w), dtype=torch.uint8, device=dev)
+        ops.instance_mask_stats(mp, Q * M, threshold, B, Q, M, sizes, conf, binary)
+        avg = torch.empty((B * Q, E), dtype=f32, device=dev)
+        ops.masked_mean_tokens(pt, binary, sizes, avg, B, Q, M, E)
+        cat = torch.empty((B, Q), dtype=torch.int64, device=dev)
+        score = torch.empty((B, Q), dtype=f32, device=dev)
+        ops.instance_classify(avg, t32, conf, temperature, B * Q, t32.shape[0], E, cat, score)
+        if size is not None:
+            masks = torch.empty((B, Q, size[0], size[1]), dtype=torch.uint8, device=dev)
+            ops.upsample_bilinear_nchw(mp, B * Q, h, w, size[0], size[1], mask_u8=masks, threshold=threshold)
+        else:
+            masks = binary
+        return masks, score, cat
+
+    def mask_iou_matrix(self, masks_u8: torch.Tensor) -> np.ndarray:
+        """Pairwise IoU of one image's [Q,H,W] u8 masks: exact popcounts on device, float64 divide on the host
+        (= utils/iou.py:30-32 on boolean masks)."""
+        n = masks_u8.shape[0]
+        px = masks_u8[0].numel()
+        inter = torch.empty((n, n), dtype=torch.int32, device=masks_u8.device)
+        uni = torch.empty((n, n), dtype=torch.int32, device=masks_u8.device)
+        ops.mask_iou_counts(masks_u8.contiguous(), n, px, inter, uni)
+        return inter.cpu().numpy() / (uni.cpu().numpy() + 1e-7)

@@ -17,6 +17,17 @@ ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_GELU_ERF = 0, 1, 2, 3, 4
 f16, f32 = torch.float16, torch.float32
 
 
+# Optional per-launch profiler (bench.py): PROFILER(name, work, launch) must call launch() and may bracket it with
+# HIP events on the current stream.  None in production: zero overhead.
+PROFILER = None
+
+
+def _launch(name, work, fn):
+    if PROFILER is None:
+        return fn()
+    return PROFILER(name, work, fn)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -52,9 +63,9 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
         res_rows = res_rows or M
     if bias is not None:
         assert bias.dtype == f32 and bias.numel() >= N
-    _lib.check(L.zh_gemm_f16(_p(A), lda, strideA, _p(W), ldw, strideW, _p(out), ldc, strideC, int(out.dtype == f16),
-                             _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream()),
-               "zh_gemm_f16")
+    args = (_p(A), lda, strideA, _p(W), ldw, strideW, _p(out), ldc, strideC, int(out.dtype == f16),
+            _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream())
+    _lib.check(_launch("gemm_f16", 2.0 * M * N * K * batch, lambda: L.zh_gemm_f16(*args)), "zh_gemm_f16")
     return out
 
 
@@ -62,8 +73,10 @@ def attention(Q, K, V, O, *, batch, heads, Tq, Tk, head_dim, ldq, ldk, ldv, ldo,
               scale=None):
     L = _lib.load()
     scale = 1.0 / math.sqrt(head_dim) if scale is None else scale
-    _lib.check(L.zh_attention_f16(_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
-                                  batch, heads, Tq, Tk, head_dim, float(scale), _stream()), "zh_attention_f16")
+    args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
+            batch, heads, Tq, Tk, head_dim, float(scale), _stream())
+    _lib.check(_launch("attention_f16", 4.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_f16(*args)),
+               "zh_attention_f16")
     return O
 
 
@@ -158,3 +171,27 @@ def confusion_hist(label_true, label_pred, hist, n_class):
     _chk(hist, torch.int64, "hist")
     _lib.check(L.zh_confusion_hist(_p(label_true), _p(label_pred), _p(hist), label_true.numel(), n_class, _stream()),
                "zh_confusion_hist")
+
+
+def instance_mask_stats(mask_proposals_last, stride_image, threshold, B, Q, M, sizes, conf, binary):
+    L = _lib.load()
+    _lib.check(L.zh_instance_mask_stats(_p(mask_proposals_last), stride_image, float(threshold), B, Q, M, _p(sizes), _p(conf),
+                                        _p(binary), _stream()), "zh_instance_mask_stats")
+
+
+def masked_mean_tokens(tokens, binary, sizes, avg, B, Q, M, E):
+    L = _lib.load()
+    _lib.check(L.zh_masked_mean_tokens(_p(tokens), _p(binary), _p(sizes), _p(avg), B, Q, M, E, _stream()), "zh_masked_mean_tokens")
+
+
+def instance_classify(avg, text, conf, temperature, rows, n, E, category, score):
+    L = _lib.load()
+    _lib.check(L.zh_instance_classify(_p(avg), _p(text), _p(conf), float(temperature), rows, n, E, _p(category), _p(score),
+                                      _stream()), "zh_instance_classify")
+
+
+def mask_iou_counts(masks_u8, n, pixels, inter, uni):
+    L = _lib.load()
+    need = L.zh_mask_iou_workspace_size(n, pixels)
+    ws = torch.empty(need, dtype=torch.uint8, device=masks_u8.device)
+    _lib.check(L.zh_mask_iou_counts(_p(masks_u8), n, pixels, _p(inter), _p(uni), _p(ws), need, _stream()), "zh_mask_iou_counts")

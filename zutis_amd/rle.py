@@ -1,0 +1,88 @@
+"""COCO run-length encoding and mask boxes without pycocotools / torchvision.
+
+The reference calls pycocotools.mask.encode(np.asfortranarray(m)) (networks/zutis.py:290,448) and
+torchvision.ops.masks_to_boxes (zutis.py:294,452).  Neither package is in this image, so their published
+algorithms are restated here (pycocotools 2.0 maskApi.c: rleEncode + rleToString; torchvision.ops.boxes.masks_to_boxes).
+PARITY UNPINNED for the RLE byte string: no pycocotools to compare with; pinned only by decode(encode(m)) == m and
+the format invariants in tests/test_rle.py.  When pycocotools IS importable, networks.zutis uses it instead.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+
+
+def _counts(mask: np.ndarray) -> np.ndarray:
+    """Run lengths of the column-major flattened mask, starting with the run of zeros (may be 0)."""
+    flat = np.asarray(mask, dtype=np.uint8).reshape(-1, order="F")
+    if flat.size == 0:
+        return np.zeros((0,), np.int64)
+    change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    bounds = np.concatenate(([0], change, [flat.size]))
+    runs = np.diff(bounds)
+    if flat[0] != 0:
+        runs = np.concatenate(([0], runs))
+    return runs.astype(np.int64)
+
+
+def _to_string(cnts: np.ndarray) -> bytes:
+    out = bytearray()
+    for i, c in enumerate(cnts.tolist()):
+        x = int(c)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(ch + 48)
+    return bytes(out)
+
+
+def _from_string(s: bytes) -> List[int]:
+    cnts: List[int] = []
+    p = 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return cnts
+
+
+def encode(mask: np.ndarray) -> Dict:
+    """mask [H,W] {0,1}/bool -> {"size": [H, W], "counts": bytes} (pycocotools.mask.encode for one mask)."""
+    assert mask.ndim == 2
+    h, w = mask.shape
+    return {"size": [int(h), int(w)], "counts": _to_string(_counts(mask))}
+
+
+def decode(rle: Dict) -> np.ndarray:
+    h, w = rle["size"]
+    cnts = _from_string(rle["counts"] if isinstance(rle["counts"], (bytes, bytearray)) else rle["counts"].encode("ascii"))
+    flat = np.zeros(h * w, np.uint8)
+    pos, val = 0, 0
+    for c in cnts:
+        if val:
+            flat[pos:pos + c] = 1
+        pos += c
+        val ^= 1
+    return flat.reshape((h, w), order="F")
+
+
+def mask_to_box(mask: np.ndarray) -> List[float]:
+    """torchvision.ops.masks_to_boxes for one mask: [xmin, ymin, xmax, ymax] of the non-zero pixels (float32 values)."""
+    ys, xs = np.nonzero(mask)
+    return [float(np.float32(xs.min())), float(np.float32(ys.min())), float(np.float32(xs.max())), float(np.float32(ys.max()))]
