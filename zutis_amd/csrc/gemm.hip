@@ -50,7 +50,7 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
 }
 
 // WM x WN waves; each wave owns TM x TN subtiles of 16x16.  Block tile = (WM*TM*16) x (WN*TN*16).
-template <int WM, int WN, int TM, int TN, int OUT_F16>
+template <int WM, int WN, int TM, int TN, int OUT_F16, int ACT, int VEC>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -147,26 +147,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(G
         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
   }
 
-  // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4)
+  // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4).  ACT / VEC are template
+  // parameters: a runtime switch unrolled 32x blew the instruction cache (fc GEMM 1.4x slower in the model).
   const long cb = (long)batch * p.sC;
   const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
-  const int act = p.act;
-  if (p.vec_ok) {
+  if (VEC) {
 #pragma clang loop unroll(full)
-    for (int mt = 0; mt < TM; ++mt) {
-      const int m = m0 + (wr * TM + mt) * 16 + frow;
-      const bool mok = m < p.M;
-      const long rrow = R ? (long)(m % p.res_rows) * p.ldr : 0;
+    for (int nt = 0; nt < TN; ++nt) {
+      const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+      const bool nok = n < p.N;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && nok) bv = *(const f32x4*)(p.bias + n);
 #pragma clang loop unroll(full)
-      for (int nt = 0; nt < TN; ++nt) {
-        const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
-        if (mok && n < p.N) {
-          f32x4 v = acc[nt][mt];
-          if (p.bias) v += *(const f32x4*)(p.bias + n);
-          if (act != ZH_ACT_NONE) {
-            v[0] = zh_act(v[0], act); v[1] = zh_act(v[1], act); v[2] = zh_act(v[2], act); v[3] = zh_act(v[3], act);
+      for (int mt = 0; mt < TM; ++mt) {
+        const int m = m0 + (wr * TM + mt) * 16 + frow;
+        if (nok && m < p.M) {
+          f32x4 v = acc[nt][mt] + bv;
+          if (ACT != ZH_ACT_NONE) {
+            v[0] = zh_act(v[0], ACT); v[1] = zh_act(v[1], ACT); v[2] = zh_act(v[2], ACT); v[3] = zh_act(v[3], ACT);
           }
-          if (R) v += *(const f32x4*)(R + rrow + n);
+          if (R) v += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
           if (OUT_F16) {
             half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             *(half4_t*)((half_t*)p.C + cb + (long)m * p.ldc + n) = h;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(G
         }
       }
     }
-  } else {   // unaligned / odd-N fallback: scalar stores (rare: class-logit GEMMs with odd pixel counts)
+  } else {   // unaligned / odd-N fallback: scalar stores (rare: odd pixel counts)
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < TM; ++mt) {
       const int m = m0 + (wr * TM + mt) * 16 + frow;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(G
           if (m < p.M && n + e < p.N) {
             float x = acc[nt][mt][e];
             if (p.bias) x += p.bias[n + e];
-            x = zh_act(x, act);
+            x = zh_act(x, ACT);
             if (R) x += R[rrow + n + e];
             if (OUT_F16) ((half_t*)p.C)[cb + (long)m * p.ldc + n + e] = (half_t)x;
             else ((float*)p.C)[cb + (long)m * p.ldc + n + e] = x;
@@ -200,15 +200,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(G
   }
 }
 
-template <int WM, int WN, int TM, int TN>
-static void launch_gemm(const GemmArgs& p0, int batch, int out_f16, hipStream_t stream) {
-  GemmArgs p = p0;
+template <int WM, int WN, int TM, int TN, int OUT_F16, int ACT, int VEC>
+static void launch_one(GemmArgs p, int batch, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   p.nbm = zh_cdiv(p.M, BM);
   p.nbn = zh_cdiv(p.N, BN);
   const unsigned nblk = (unsigned)((long)p.nbm * p.nbn * batch);
-  if (out_f16) hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, 1>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
-  else hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, 0>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
+  hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, OUT_F16, ACT, VEC>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
+}
+
+// Instantiated (out type, activation) pairs = the ones the hot path uses; anything else is an argument error.
+template <int WM, int WN, int TM, int TN, int VEC>
+static bool launch_gemm(const GemmArgs& p, int batch, int out_f16, hipStream_t stream) {
+  const int key = out_f16 * 8 + p.act;
+  switch (key) {
+    case 0 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, 0, ZH_ACT_NONE, VEC>(p, batch, stream); return true;
+    case 0 + ZH_ACT_SIGMOID: launch_one<WM, WN, TM, TN, 0, ZH_ACT_SIGMOID, VEC>(p, batch, stream); return true;
+    case 8 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, 1, ZH_ACT_NONE, VEC>(p, batch, stream); return true;
+    case 8 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, 1, ZH_ACT_QUICKGELU, VEC>(p, batch, stream); return true;
+    case 8 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, 1, ZH_ACT_RELU, VEC>(p, batch, stream); return true;
+    case 8 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, 1, ZH_ACT_GELU_ERF, VEC>(p, batch, stream); return true;
+    default: return false;
+  }
 }
 
 // Relative time estimate of a tiling: rounds of the 256-CU chip x time of one round.  With `bpc` blocks resident
@@ -250,9 +263,13 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   const double c128 = tiling_cost(M, N, batch, 128, 128, 2, 0.8);
   int pick = (c128 < c256 && c128 < c192) ? 128 : (c192 < c256 ? 192 : 256);
   if (force) pick = atoi(force);
-  if (pick == 128) launch_gemm<2, 2, 4, 4>(p, batch, out_f16, stream);
-  else if (pick == 192) launch_gemm<2, 4, 8, 3>(p, batch, out_f16, stream);
-  else launch_gemm<2, 4, 8, 4>(p, batch, out_f16, stream);
+  bool ok;
+  if (!p.vec_ok) ok = launch_gemm<2, 2, 4, 4, 0>(p, batch, out_f16, stream);      // scalar-store fallback: small tile only
+  else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 1>(p, batch, out_f16, stream);
+  else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 1>(p, batch, out_f16, stream);
+  else ok = launch_gemm<2, 4, 8, 4, 1>(p, batch, out_f16, stream);
+  ZH_CHECK_ARG(ok, "zh_gemm_f16: (out_f16=%d, act=%d) is not an instantiated epilogue (f32: none|sigmoid; f16: none|quickgelu|relu|gelu_erf)",
+               out_f16, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16");
   return ZH_OK;
 }
