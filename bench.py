@@ -61,6 +61,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     from zutis_amd import detgen, ops
+    from zutis_amd import distributed as zd
     from zutis_amd.engine import ZutisEngine
 
     cfg = detgen.VIT_B16
@@ -83,7 +84,7 @@ def main():
         if world > 1:
             if pending[0] is not None:
                 pending[0].wait()
-            pending[0] = dist.all_gather_into_tensor(gathered[i & 1], lo.view(B, n, hw2), async_op=True)
+            _, pending[0] = zd.all_gather_logits(lo.view(B, n, hw2), out=gathered[i & 1], async_op=True)
         return labels
 
     for i in range(args.warmup):

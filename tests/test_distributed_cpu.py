@@ -1,0 +1,64 @@
+"""CPU, world_size 2, gloo: the N>1 bookkeeping of the sharded evaluation (shards, gather order, metric reduce)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from zutis_amd import distributed as zd
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_images, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        full = torch.randn((n_images, 5, 6, 7), generator=g)            # "low-res logits" of the whole eval set
+        labels = torch.randint(0, 5, (n_images, 12, 9), generator=g)
+        preds = torch.randint(0, 5, (n_images, 12, 9), generator=g)
+        lo, hi = zd.shard_range(n_images, rank, world)
+        ragged = zd.all_gather_ragged(full[lo:hi], n_images)
+        assert torch.equal(ragged, full)
+        b = n_images // world                                            # equal shards -> plain gather, async as in bench.py
+        out, work = zd.all_gather_logits(full[rank * b:(rank + 1) * b], async_op=True)
+        work.wait()
+        assert torch.equal(out, full[: world * b])
+        hist = torch.bincount((5 * labels[lo:hi] + preds[lo:hi]).reshape(-1), minlength=25).reshape(5, 5)
+        zd.all_reduce_confusion(hist)
+        ref = torch.bincount((5 * labels + preds).reshape(-1), minlength=25).reshape(5, 5)
+        assert torch.equal(hist, ref)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [zd.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_two_rank_gloo_gather_and_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, "ok"), (1, "ok")], res
