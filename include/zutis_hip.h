@@ -70,7 +70,8 @@ int zh_layernorm_f32(const float* x, long in_group_rows, long in_group_stride, l
                      float* out_f32, void* out_f16, void* out_f16_plus, float* out_f32_plus,
                      const float* add, int add_rows, int rows, int D, zh_stream_t stream);
 
-/* cat(class_embedding, patch_emb) + pos_embed, then ln_pre: clip_arch.py:384-397.  out [B,T,D] f32. */
+/* cat(class_embedding, patch_emb) + pos_embed, then ln_pre: clip_arch.py:384-397.  out [B,T,D] f32.
+ * gamma = beta = NULL: no LayerNorm (DINO ViT prepare_tokens, selfmask/vision_transformer.py:269-281). */
 int zh_assemble_tokens_ln(const float* patch_emb, const float* class_embedding, const float* pos_embed,
                           const float* gamma, const float* beta, float eps, float* out,
                           int B, int T, int D, zh_stream_t stream);
@@ -84,8 +85,10 @@ int zh_global_ln_l2(const float* x, float* out_f32, void* out_f16, float eps, fl
                     int B, int M, int C, void* workspace, size_t workspace_bytes, zh_stream_t stream);
 
 /* im2col of the stride==kernel patch conv (pure re-index): clip_arch.py:340,378; selfmask/vision_transformer.py:182.
- * out f16 [B*gh*gw, Kpad], k = c*p*p + i*p + j, zero padded. */
-int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, zh_stream_t stream);
+ * out f16 [B*gh*gw, Kpad], k = c*p*p + i*p + j, zero padded.  pad_to_patch = 0: gh = floor((H-p)/p)+1 (CLIP, trailing
+ * pixels dropped); 1: gh = ceil(H/p) with zero pixels (make_input_divisible, selfmask/vision_transformer.py:260-267). */
+int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, int pad_to_patch,
+                  zh_stream_t stream);
 
 /* Bicubic positional-embedding resample: clip_arch.py:356-374 (scale = float(1/((h+0.1)/g))) and
  * selfmask/vision_transformer.py:377-401 (scale = g/h).  pos [has_cls + g*g, D] -> out [has_cls + h*w, D]. */

@@ -150,11 +150,41 @@ def gen_ops():
     print("ops:", {k: v.shape for k, v in d.items()})
 
 
+def gen_selfmask():
+    """SelfMask reference (random init + deterministic weights), train-mode dict and inference masks."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for m in [k for k in sys.modules if k.startswith("networks") or k.startswith("utils")]:
+        del sys.modules[m]
+    from networks.selfmask.selfmask import SelfMask
+    net = SelfMask()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.selfmask_state_dict().items()}, strict=True)
+    net.eval().requires_grad_(False)
+    d = {}
+    for tag, (b, H, W) in {"small": (2, 72, 100), "full": (1, 224, 300)}.items():
+        x = torch.from_numpy(detgen.images(b, H, W, seed=11))
+        with torch.no_grad():
+            o = net(x)
+            inf = net(x, inference=True, bilateral_solver=False)
+            # encoder_only=True is broken in the reference (selfmask.py:162 views a non-contiguous [b,D,hw] as [b,h,w,D])
+        d[f"{tag}_shape"] = np.array([b, H, W])
+        d[f"{tag}_objectness"] = o["objectness"].numpy()
+        d[f"{tag}_mask_pred"] = o["mask_pred"].numpy() if tag == "small" else o["mask_pred"].numpy()[:, :, :, ::2, ::2]
+        d[f"{tag}_dts"] = np.packbits(np.stack([t.numpy() for t in inf["dts"]]).astype(bool), axis=-1)
+        print("selfmask", tag, {k: v.shape for k, v in d.items() if k.startswith(tag)}, "fg frac",
+              float(np.mean([t.float().mean() for t in inf["dts"]])))
+    np.savez_compressed(os.path.join(GOLD, "selfmask.npz"), **d)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if "--selfmask-only" in sys.argv:
+        gen_selfmask()
+        sys.exit(0)
     gen_ops()
+    gen_selfmask()
     gen_e2e("tiny", detgen.TINY, b=2, H=80, W=112, n_cat=7, size=(80, 112), full=True)
     gen_e2e("vitb16_336", detgen.VIT_B16, b=1, H=336, W=336, n_cat=81, size=(336, 336), full=False)
     gen_e2e("vitb32_224", detgen.VIT_B32, b=1, H=224, W=224, n_cat=81, size=(224, 224), full=False)

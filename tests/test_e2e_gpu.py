@@ -154,3 +154,46 @@ def test_instance_kernels_vs_oracle_exact_inputs(dev, golden_dir):
     for i in range(up.shape[1]):
         for j in range(up.shape[1]):
             assert iou[i, j] == O.compute_iou(up[0, i], up[0, j])
+
+
+def test_selfmask_engine_vs_reference_golden(dev, golden_dir):
+    """SelfMask (DINO ViT-S/8 + decoder + objectness) on the HIP path against the reference's outputs."""
+    from zutis_amd import detgen
+    from zutis_amd.engine import SelfMaskEngine
+    g = np.load(f"{golden_dir}/selfmask.npz")
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()})
+    for tag in ("small", "full"):
+        b, H, W = (int(v) for v in g[f"{tag}_shape"])
+        x = torch.from_numpy(detgen.images(b, H, W, seed=11)).to(dev)
+        out = eng.forward(x)
+        mp = out["mask_pred"].cpu().numpy()
+        if tag == "full":
+            mp = mp[:, :, :, ::2, ::2]
+        assert np.abs(out["objectness"].cpu().numpy() - g[f"{tag}_objectness"]).max() < 2e-3
+        assert np.abs(mp - g[f"{tag}_mask_pred"]).max() < 2e-2      # un-normalised queries: |logit| ~ 30, fp16 operands => 1e-3 relative on the logit
+        inf = eng.forward(x, inference=True)
+        ref = np.unpackbits(g[f"{tag}_dts"], axis=-1)[..., :W].astype(bool)
+        got = inf["dts"].cpu().numpy().astype(bool)
+        assert got.shape == (b, H, W)
+        assert (got != ref).mean() < 5e-3, (got != ref).mean()
+
+
+def test_selfmask_dropin_module(dev, golden_dir):
+    import os, sys
+    from zutis_amd import detgen
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    from networks.selfmask.selfmask import SelfMask
+    net = SelfMask()
+    assert len(net.state_dict()) == 267                      # SURVEY.md §8b
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.selfmask_state_dict().items()}, strict=True)
+    net = net.to(dev).eval()
+    g = np.load(f"{golden_dir}/selfmask.npz")
+    b, H, W = (int(v) for v in g["small_shape"])
+    x = torch.from_numpy(detgen.images(b, H, W, seed=11)).to(dev)
+    with torch.no_grad():
+        out = net(x, inference=True)
+    assert isinstance(out["dts"], list) and out["dts"][0].dtype == torch.uint8 and out["dts"][0].device.type == "cpu"
+    ref = np.unpackbits(g["small_dts"], axis=-1)[..., :W].astype(bool)
+    assert (torch.stack(out["dts"]).numpy().astype(bool) != ref).mean() < 5e-3

@@ -98,3 +98,17 @@ def test_detgen_is_deterministic_and_complete():
     assert np.array_equal(a, detgen.det_normal("x", (1000,), seed=3))
     assert abs(a.mean()) < 0.15 and abs(a.std() - 1) < 0.1
     assert abs(float(a[0]) - float(detgen.det_normal("x", (1,), seed=3)[0])) == 0
+
+
+def test_selfmask_oracle_matches_reference(golden_dir):
+    from oracle import selfmask_ref as S
+    g = np.load(f"{golden_dir}/selfmask.npz")
+    P = O.to_torch_params(detgen.selfmask_state_dict())
+    b, H, W = (int(v) for v in g["small_shape"])
+    x = torch.from_numpy(detgen.images(b, H, W, seed=11))
+    with torch.no_grad():
+        o = S.selfmask_forward(P, x)
+        dts, idx, _ = S.selfmask_inference(P, x)
+    assert np.abs(o["objectness"].numpy() - g["small_objectness"]).max() < 2e-6
+    assert np.abs(o["mask_pred"].numpy() - g["small_mask_pred"]).max() < 5e-5
+    assert np.array_equal(np.stack(dts).astype(bool), np.unpackbits(g["small_dts"], axis=-1)[..., :W].astype(bool))

@@ -111,18 +111,19 @@ __global__ __launch_bounds__(256) void assemble_ln_kernel(AsmArgs p) {
 #pragma unroll
   for (int j = 0; j < LN_MAXV; ++j)
     if (lane + 64 * j < nv) row.v[j] = src[lane + 64 * j] + pos[lane + 64 * j];
-  ln_normalize(row, nv, lane, p.D, p.eps);
+  if (p.gamma) ln_normalize(row, nv, lane, p.D, p.eps);     // gamma == NULL: plain cat + pos (DINO ViT has no ln_pre)
 #pragma unroll
   for (int j = 0; j < LN_MAXV; ++j) {
     const int c = lane + 64 * j;
-    if (c < nv) ((f32x4*)(p.out + r * p.D))[c] = row.v[j] * ((const f32x4*)p.gamma)[c] + ((const f32x4*)p.beta)[c];
+    if (c < nv) ((f32x4*)(p.out + r * p.D))[c] = p.gamma ? row.v[j] * ((const f32x4*)p.gamma)[c] + ((const f32x4*)p.beta)[c] : row.v[j];
   }
 }
 
 extern "C" int zh_assemble_tokens_ln(const float* patch_emb, const float* class_embedding, const float* pos_embed,
                                      const float* gamma, const float* beta, float eps, float* out,
                                      int B, int T, int D, hipStream_t stream) {
-  ZH_CHECK_ARG(patch_emb && class_embedding && pos_embed && gamma && beta && out, "zh_assemble_tokens_ln: null pointer");
+  ZH_CHECK_ARG(patch_emb && class_embedding && pos_embed && out, "zh_assemble_tokens_ln: null pointer");
+  ZH_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "zh_assemble_tokens_ln: gamma and beta must both be given or both null");
   ZH_CHECK_ARG(B > 0 && T > 1 && D % 4 == 0 && D <= 256 * LN_MAXV, "zh_assemble_tokens_ln: bad shape B=%d T=%d D=%d", B, T, D);
   AsmArgs p{patch_emb, class_embedding, pos_embed, gamma, beta, out, B, T, D, eps};
   hipLaunchKernelGGL(assemble_ln_kernel, dim3(zh_cdiv((long)B * T, 4)), dim3(256), 0, stream, p);

@@ -20,15 +20,19 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* x, half_t* out
     const int px = (int)(row % gw);
     const long t = row / gw;
     const int py = (int)(t % gh), b = (int)(t / gh);
-    v = x[(((long)b * Cin + c) * H + (py * p + i)) * W + (px * p + j)];
+    const int yy = py * p + i, xx = px * p + j;     // beyond the image only with pad_to_patch (zero padding,
+    if (yy < H && xx < W) v = x[(((long)b * Cin + c) * H + yy) * W + xx];   // selfmask/vision_transformer.py:260-267)
   }
   out[idx] = (half_t)v;
 }
 
-extern "C" int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, hipStream_t stream) {
-  ZH_CHECK_ARG(x && out && B > 0 && Cin > 0 && patch > 0 && H >= patch && W >= patch, "zh_im2col_f16: bad arguments");
+extern "C" int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, int pad_to_patch,
+                             hipStream_t stream) {
+  ZH_CHECK_ARG(x && out && B > 0 && Cin > 0 && patch > 0 && H > 0 && W > 0, "zh_im2col_f16: bad arguments");
+  ZH_CHECK_ARG(pad_to_patch || (H >= patch && W >= patch), "zh_im2col_f16: image smaller than one patch");
   ZH_CHECK_ARG(Kpad >= Cin * patch * patch, "zh_im2col_f16: Kpad too small");
-  const int gh = (H - patch) / patch + 1, gw = (W - patch) / patch + 1;
+  const int gh = pad_to_patch ? (H + patch - 1) / patch : (H - patch) / patch + 1;
+  const int gw = pad_to_patch ? (W + patch - 1) / patch : (W - patch) / patch + 1;
   const long total = (long)B * gh * gw * Kpad;
   hipLaunchKernelGGL(im2col_kernel, dim3(zh_cdiv(total, 256)), dim3(256), 0, stream, x, (half_t*)out, B, Cin, H, W, patch, gh, gw, Kpad, total);
   ZH_CHECK_LAUNCH("zh_im2col_f16");

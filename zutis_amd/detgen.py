@@ -139,6 +139,60 @@ def zutis_state_dict(cfg: ZutisConfig, seed: int = 1234) -> "OrderedDict[str, np
                        for k, (shp, std, mean) in zutis_param_shapes(cfg).items())
 
 
+def selfmask_param_shapes(n_queries: int = 20, D: int = 384, depth: int = 12, patch: int = 8, dec_layers: int = 6,
+                          pos_grid: int = 28):
+    """SelfMask state_dict (267 keys): DINO ViT-S/8 encoder + 6-layer decoder + objectness MLP
+    (networks/selfmask/selfmask.py:14-48, vision_transformer.py:191-258,513-525)."""
+    P = OrderedDict()
+    P["query_embed"] = ((n_queries, D), 1.0, 0.0)
+    P["encoder.cls_token"] = ((1, 1, D), 0.02, 0.0)
+    P["encoder.pos_embed"] = ((1, pos_grid * pos_grid + 1, D), 0.02, 0.0)
+    P["encoder.patch_embed.proj.weight"] = ((D, 3, patch, patch), (3 * patch * patch) ** -0.5, 0.0)
+    P["encoder.patch_embed.proj.bias"] = ((D,), 0.02, 0.0)
+    for i in range(depth):
+        p = f"encoder.blocks.{i}."
+        for n in ("norm1", "norm2"):
+            P[p + n + ".weight"] = ((D,), 0.1, 1.0)
+            P[p + n + ".bias"] = ((D,), 0.1, 0.0)
+        P[p + "attn.qkv.weight"] = ((3 * D, D), D ** -0.5, 0.0)
+        P[p + "attn.qkv.bias"] = ((3 * D,), 0.02, 0.0)
+        P[p + "attn.proj.weight"] = ((D, D), (D ** -0.5) * ((2 * depth) ** -0.5), 0.0)
+        P[p + "attn.proj.bias"] = ((D,), 0.02, 0.0)
+        P[p + "mlp.fc1.weight"] = ((4 * D, D), (2 * D) ** -0.5, 0.0)
+        P[p + "mlp.fc1.bias"] = ((4 * D,), 0.02, 0.0)
+        P[p + "mlp.fc2.weight"] = ((D, 4 * D), (D ** -0.5) * ((2 * depth) ** -0.5), 0.0)
+        P[p + "mlp.fc2.bias"] = ((D,), 0.02, 0.0)
+    P["encoder.norm.weight"] = ((D,), 0.1, 1.0)
+    P["encoder.norm.bias"] = ((D,), 0.1, 0.0)
+    F = 4 * D
+    for i in range(dec_layers):
+        p = f"decoder.layers.{i}."
+        for a in ("self_attn", "multihead_attn"):
+            P[p + a + ".in_proj_weight"] = ((3 * D, D), (2.0 / (4 * D)) ** 0.5, 0.0)
+            P[p + a + ".in_proj_bias"] = ((3 * D,), 0.02, 0.0)
+            P[p + a + ".out_proj.weight"] = ((D, D), D ** -0.5, 0.0)
+            P[p + a + ".out_proj.bias"] = ((D,), 0.02, 0.0)
+        P[p + "linear1.weight"] = ((F, D), (2.0 / (D + F)) ** 0.5, 0.0)
+        P[p + "linear1.bias"] = ((F,), 0.02, 0.0)
+        P[p + "linear2.weight"] = ((D, F), (2.0 / (D + F)) ** 0.5, 0.0)
+        P[p + "linear2.bias"] = ((D,), 0.02, 0.0)
+        for n in ("norm1", "norm2", "norm3"):
+            P[p + n + ".weight"] = ((D,), 0.1, 1.0)
+            P[p + n + ".bias"] = ((D,), 0.1, 0.0)
+    P["decoder.norm.weight"] = ((D,), 0.1, 1.0)
+    P["decoder.norm.bias"] = ((D,), 0.1, 0.0)
+    dims = [D, D, D, 1]
+    for j in range(3):
+        P[f"ffn.layers.{j}.weight"] = ((dims[j + 1], dims[j]), (2.0 / (dims[j] + dims[j + 1])) ** 0.5, 0.0)
+        P[f"ffn.layers.{j}.bias"] = ((dims[j + 1],), 0.05, 0.0)
+    return P
+
+
+def selfmask_state_dict(seed: int = 4321) -> "OrderedDict[str, np.ndarray]":
+    return OrderedDict((k, det_normal("selfmask." + k, shp, std, mean, seed))
+                       for k, (shp, std, mean) in selfmask_param_shapes().items())
+
+
 def text_embeddings(n_categories: int, dim: int, seed: int = 7) -> np.ndarray:
     """Unit-norm rows standing in for CLIP text embeddings (networks/zutis.py:36-37)."""
     t = det_normal("text_embeddings", (n_categories, dim), seed=seed).astype(np.float64)

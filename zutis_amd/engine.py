@@ -31,7 +31,141 @@ def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-class ZutisEngine:
+class _EngineBase:
+    """Shared plumbing: fp16 weight packing keyed on parameter versions, shape-keyed buffer cache, and the two
+    kernel sequences both networks share — pre-LN ViT blocks and the post-norm DETR-style decoder."""
+
+    params: Dict[str, torch.Tensor]
+
+    def _init_base(self):
+        self._packed_key = None
+        self._w: Dict[str, torch.Tensor] = {}
+        self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.params.values())
+
+    def _device(self):
+        dev = next(iter(self.params.values())).device
+        if dev.type != "cuda":
+            raise ZutisHipError("engine parameters must live on a GPU (no CPU fallback)")
+        return dev
+
+    def _buf(self, name: str, shape, dtype) -> torch.Tensor:
+        k = (name, tuple(shape), dtype)
+        b = self._bufs.get(k)
+        if b is None:
+            for kk in [kk for kk in self._bufs if kk[0] == name]:
+                del self._bufs[kk]
+            b = torch.empty(shape, dtype=dtype, device=self._device())
+            self._bufs[k] = b
+        return b
+
+    @staticmethod
+    def _h(t):
+        return t.detach().to(f16).contiguous()
+
+    @staticmethod
+    def _c32(t):
+        return t.detach().to(f32).contiguous()
+
+    def _pack_decoder(self, w, P, D, n_layers):
+        """decoder.layers.{i}.* (transformer.py:231-251) -> dec.{i}.*; the cross-attention K / V weights of all layers
+        are concatenated so the memory tokens are projected by ONE GEMM each."""
+        h, c32 = self._h, self._c32
+        kw, kb, vw, vb = [], [], [], []
+        for i in range(n_layers):
+            p, q = f"decoder.layers.{i}.", f"dec.{i}."
+            sw, sb = P[p + "self_attn.in_proj_weight"].detach(), P[p + "self_attn.in_proj_bias"].detach()
+            w[q + "sa_qk_w"], w[q + "sa_qk_b"] = h(sw[:2 * D]), c32(sb[:2 * D])
+            w[q + "sa_v_w"], w[q + "sa_v_b"] = h(sw[2 * D:]), c32(sb[2 * D:])
+            w[q + "sa_o_w"], w[q + "sa_o_b"] = h(P[p + "self_attn.out_proj.weight"]), c32(P[p + "self_attn.out_proj.bias"])
+            cw, cb = P[p + "multihead_attn.in_proj_weight"].detach(), P[p + "multihead_attn.in_proj_bias"].detach()
+            w[q + "ca_q_w"], w[q + "ca_q_b"] = h(cw[:D]), c32(cb[:D])
+            kw.append(cw[D:2 * D]); kb.append(cb[D:2 * D]); vw.append(cw[2 * D:]); vb.append(cb[2 * D:])
+            w[q + "ca_o_w"], w[q + "ca_o_b"] = h(P[p + "multihead_attn.out_proj.weight"]), c32(P[p + "multihead_attn.out_proj.bias"])
+            w[q + "l1_w"], w[q + "l1_b"] = h(P[p + "linear1.weight"]), c32(P[p + "linear1.bias"])
+            w[q + "l2_w"], w[q + "l2_b"] = h(P[p + "linear2.weight"]), c32(P[p + "linear2.bias"])
+            for n in ("norm1", "norm2", "norm3"):
+                w[q + n + ".w"], w[q + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
+        w["ca_k_w"], w["ca_k_b"] = h(torch.cat(kw, 0)), c32(torch.cat(kb, 0))       # [L*D, D]
+        w["ca_v_w"], w["ca_v_b"] = h(torch.cat(vw, 0)), c32(torch.cat(vb, 0))
+        w["dec.norm.w"], w["dec.norm.b"] = c32(P["decoder.norm.weight"]), c32(P["decoder.norm.bias"])
+        w["query_embed"] = c32(P["query_embed"])
+
+    def _vit_blocks(self, X, B, T, D, heads, n_layers, eps, act):
+        """Pre-LN transformer blocks on the fp32 residual stream X [B*T, D] (in place).
+        clip_arch.py:318-321 (QuickGELU, eps 1e-5) and selfmask/vision_transformer.py:160-170 (erf GELU, eps 1e-6)."""
+        W_, R = self._w, B * T
+        Y = self._buf("Y16", (R, D), f16)
+        QKV = self._buf("QKV16", (R, 3 * D), f16)
+        O = self._buf("O16", (R, D), f16)
+        Hh = self._buf("H16", (R, W_["enc.0.fc_w"].shape[0]), f16)
+        for i in range(n_layers):
+            pp = f"enc.{i}."
+            ops.layernorm(X, W_[pp + "ln1.w"], W_[pp + "ln1.b"], eps, R, D, out_f16=Y)
+            ops.gemm(Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
+            ops.attention(QKV, QKV[:, D:], QKV[:, 2 * D:], O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=D // heads,
+                          ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
+                          strideO=T * D)
+            ops.gemm(O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
+            ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y)
+            ops.gemm(Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
+            ops.gemm(Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
+
+    def _decoder(self, MEM16, KIN16, B, M, D, Q, L, heads, stack_all: bool):
+        """transformer.py:114-152 over :262-291 (post-norm), tgt = zeros, query_pos = query_embed.
+        MEM16 f16 [B*M, D] = value input, KIN16 = key input (memory + pos, or memory itself).  Returns f16 rows with
+        decoder.norm applied: every layer stacked as [B,L,Q,D] (stack_all) or the last layer only [B*Q, D]; the fp32
+        copy of the last layer's normed output is left in buffer "dec_out32"."""
+        W_, dh, R = self._w, D // heads, B * Q
+        KALL = self._buf("KALL", (B * M, L * D), f16)
+        VALL = self._buf("VALL", (B * M, L * D), f16)
+        ops.gemm(KIN16, W_["ca_k_w"], KALL, bias=W_["ca_k_b"])                             # all layers' K / V at once
+        ops.gemm(MEM16, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
+        qpos = W_["query_embed"]
+        tgt = self._buf("tgt", (R, D), f32)
+        t1 = self._buf("t1", (R, D), f32)
+        tgt16 = self._buf("tgt16", (R, D), f16)
+        qin16 = self._buf("qin16", (R, D), f16)
+        qk16 = self._buf("qk16", (R, 2 * D), f16)
+        v16 = self._buf("v16", (R, D), f16)
+        qc16 = self._buf("qc16", (R, D), f16)
+        o16 = self._buf("do16", (R, D), f16)
+        ff16 = self._buf("ff16", (R, W_["dec.0.l1_w"].shape[0]), f16)
+        inter16 = self._buf("inter16", (B * (L if stack_all else 1) * Q, D), f16)
+        out32 = self._buf("dec_out32", (R, D), f32)
+        tgt.zero_()
+        ops.cast_f16(tgt, tgt16, R, D)
+        ops.cast_f16(tgt, qin16, R, D, add=qpos, add_rows=Q)
+        for l in range(L):
+            pp = f"dec.{l}."
+            ops.gemm(qin16, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])             # q = k = tgt + query_pos
+            ops.gemm(tgt16, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])                 # v = tgt
+            ops.attention(qk16, qk16[:, D:], v16, o16, batch=B, heads=heads, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D, ldk=2 * D,
+                          ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D)
+            ops.gemm(o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=tgt)
+            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=tgt, out_f16_plus=qin16,
+                          add=qpos, add_rows=Q)
+            ops.gemm(qin16, W_[pp + "ca_q_w"], qc16, bias=W_[pp + "ca_q_b"])
+            ops.attention(qc16, KALL[:, l * D:], VALL[:, l * D:], o16, batch=B, heads=heads, Tq=Q, Tk=M, head_dim=dh, ldq=D,
+                          ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D, strideO=Q * D)
+            ops.gemm(o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt)
+            ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
+            ops.gemm(tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
+            ops.gemm(ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
+            ops.layernorm(t1, W_[pp + "norm3.w"], W_[pp + "norm3.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16,
+                          out_f16_plus=qin16, add=qpos, add_rows=Q)
+            if stack_all:                                                                   # :140-150, stacked [B,L,Q,D]
+                ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16,
+                              out_group_rows=Q, out_group_stride=L * Q, out_offset=l * Q)
+            elif l == L - 1:
+                ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16, out_f32=out32)
+        return inter16
+
+
+class ZutisEngine(_EngineBase):
     """Inference engine for one ZUTIS network.  `params` maps reference state_dict keys to fp32 CUDA tensors
     (typically the nn.Parameters of the drop-in module, so load_state_dict() is picked up via version counters)."""
 
@@ -49,81 +183,46 @@ class ZutisEngine:
         self.grid = int(math.isqrt(params["encoder.positional_embedding"].shape[0] - 1))
         if self.dec_dh not in (64, 96):
             raise ZutisHipError(f"decoder head_dim {self.dec_dh} unsupported by zh_attention_f16 (64 or 96)")
-        self._packed_key = None
-        self._w: Dict[str, torch.Tensor] = {}
-        self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
-        self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._init_base()
 
     # ------------------------------------------------------------------ packing
-    def _version_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.params.values())
-
     def _pack(self):
         key = self._version_key()
         if key == self._packed_key:
             return
         P, D, w = self.params, self.D, {}
-        dev = P["query_embed"].device
-        if dev.type != "cuda":
-            raise ZutisHipError("ZutisEngine needs parameters on a GPU (no CPU fallback)")
-        h = lambda t: t.detach().to(f16).contiguous()
-        c32 = lambda t: t.detach().to(f32).contiguous()
+        dev = self._device()
+        h, c32 = self._h, self._c32
         kc = 3 * self.patch * self.patch
         self.Kc = _rup(kc, 64)
         wc = torch.zeros((D, self.Kc), dtype=f16, device=dev)
         wc[:, :kc] = P["encoder.conv1.weight"].detach().reshape(D, kc).to(f16)
         w["conv"] = wc
         for name in ("encoder.class_embedding", "encoder.positional_embedding", "encoder.ln_pre.weight", "encoder.ln_pre.bias",
-                     "encoder.ln_post.weight", "encoder.ln_post.bias", "decoder.norm.weight", "decoder.norm.bias", "query_embed"):
+                     "encoder.ln_post.weight", "encoder.ln_post.bias"):
             w[name] = c32(P[name])
         for i in range(self.layers):
-            p = f"encoder.transformer.resblocks.{i}."
-            w[p + "qkv_w"], w[p + "qkv_b"] = h(P[p + "attn.in_proj_weight"]), c32(P[p + "attn.in_proj_bias"])
-            w[p + "out_w"], w[p + "out_b"] = h(P[p + "attn.out_proj.weight"]), c32(P[p + "attn.out_proj.bias"])
-            w[p + "fc_w"], w[p + "fc_b"] = h(P[p + "mlp.c_fc.weight"]), c32(P[p + "mlp.c_fc.bias"])
-            w[p + "proj_w"], w[p + "proj_b"] = h(P[p + "mlp.c_proj.weight"]), c32(P[p + "mlp.c_proj.bias"])
-            for ln in ("ln_1", "ln_2"):
-                w[p + ln + ".w"], w[p + ln + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
+            p, q = f"encoder.transformer.resblocks.{i}.", f"enc.{i}."
+            w[q + "qkv_w"], w[q + "qkv_b"] = h(P[p + "attn.in_proj_weight"]), c32(P[p + "attn.in_proj_bias"])
+            w[q + "out_w"], w[q + "out_b"] = h(P[p + "attn.out_proj.weight"]), c32(P[p + "attn.out_proj.bias"])
+            w[q + "fc_w"], w[q + "fc_b"] = h(P[p + "mlp.c_fc.weight"]), c32(P[p + "mlp.c_fc.bias"])
+            w[q + "proj_w"], w[q + "proj_b"] = h(P[p + "mlp.c_proj.weight"]), c32(P[p + "mlp.c_proj.bias"])
+            for ln, ln2 in (("ln_1", "ln1"), ("ln_2", "ln2")):
+                w[q + ln2 + ".w"], w[q + ln2 + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
         for ffn in ("ffn1", "ffn2"):
             for j in range(3):
                 w[f"{ffn}.{j}.w"], w[f"{ffn}.{j}.b"] = h(P[f"{ffn}.layers.{j}.weight"]), c32(P[f"{ffn}.layers.{j}.bias"])
-        kw, kb, vw, vb = [], [], [], []
-        for i in range(self.dec_layers):
-            p = f"decoder.layers.{i}."
-            sw, sb = P[p + "self_attn.in_proj_weight"].detach(), P[p + "self_attn.in_proj_bias"].detach()
-            w[p + "sa_qk_w"], w[p + "sa_qk_b"] = h(sw[:2 * D]), c32(sb[:2 * D])
-            w[p + "sa_v_w"], w[p + "sa_v_b"] = h(sw[2 * D:]), c32(sb[2 * D:])
-            w[p + "sa_o_w"], w[p + "sa_o_b"] = h(P[p + "self_attn.out_proj.weight"]), c32(P[p + "self_attn.out_proj.bias"])
-            cw, cb = P[p + "multihead_attn.in_proj_weight"].detach(), P[p + "multihead_attn.in_proj_bias"].detach()
-            w[p + "ca_q_w"], w[p + "ca_q_b"] = h(cw[:D]), c32(cb[:D])
-            kw.append(cw[D:2 * D]); kb.append(cb[D:2 * D]); vw.append(cw[2 * D:]); vb.append(cb[2 * D:])
-            w[p + "ca_o_w"], w[p + "ca_o_b"] = h(P[p + "multihead_attn.out_proj.weight"]), c32(P[p + "multihead_attn.out_proj.bias"])
-            w[p + "l1_w"], w[p + "l1_b"] = h(P[p + "linear1.weight"]), c32(P[p + "linear1.bias"])
-            w[p + "l2_w"], w[p + "l2_b"] = h(P[p + "linear2.weight"]), c32(P[p + "linear2.bias"])
-            for n in ("norm1", "norm2", "norm3"):
-                w[p + n + ".w"], w[p + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
-        w["ca_k_w"], w["ca_k_b"] = h(torch.cat(kw, 0)), c32(torch.cat(kb, 0))       # [L*D, D]
-        w["ca_v_w"], w["ca_v_b"] = h(torch.cat(vw, 0)), c32(torch.cat(vb, 0))
+        self._pack_decoder(w, P, D, self.dec_layers)
         w["projT"] = h(P["encoder.proj"].detach().t())                                 # [E, D]
         self._w, self._packed_key = w, key
         self._geo.clear()
-
-    def _buf(self, name: str, shape, dtype) -> torch.Tensor:
-        k = (name, tuple(shape), dtype)
-        b = self._bufs.get(k)
-        if b is None:
-            for kk in [kk for kk in self._bufs if kk[0] == name]:
-                del self._bufs[kk]
-            b = torch.empty(shape, dtype=dtype, device=self._w["conv"].device)
-            self._bufs[k] = b
-        return b
 
     def _geometry(self, h: int, w: int):
         """Input-independent tables per token grid: bicubic pos-embed (clip_arch.py:356-374) and sine PE
         (positional_embedding.py:29-52) — computed once on device, cached."""
         g = self._geo.get((h, w))
         if g is None:
-            D, dev = self.D, self._w["conv"].device
+            D, dev = self.D, self._device()
             pos = torch.empty((1 + h * w, D), dtype=f32, device=dev)
             sh = np.float32(1.0 / ((h + 0.1) / self.grid))
             sw = np.float32(1.0 / ((w + 0.1) / self.grid))
@@ -153,21 +252,7 @@ class ZutisEngine:
         X = self._buf("X", (R, D), f32)
         ops.assemble_tokens_ln(pe32, W_["encoder.class_embedding"], geo["pos"], W_["encoder.ln_pre.weight"],
                                W_["encoder.ln_pre.bias"], 1e-5, X, B, T, D)                # :384-397
-        Y = self._buf("Y16", (R, D), f16)
-        QKV = self._buf("QKV16", (R, 3 * D), f16)
-        O = self._buf("O16", (R, D), f16)
-        Hh = self._buf("H16", (R, 4 * D), f16)
-        for i in range(self.layers):                                                       # :318-321
-            pp = f"encoder.transformer.resblocks.{i}."
-            ops.layernorm(X, W_[pp + "ln_1.w"], W_[pp + "ln_1.b"], 1e-5, R, D, out_f16=Y)
-            ops.gemm(Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
-            ops.attention(QKV, QKV[:, D:], QKV[:, 2 * D:], O, batch=B, heads=self.heads, Tq=T, Tk=T, head_dim=64,
-                          ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
-                          strideO=T * D)
-            ops.gemm(O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
-            ops.layernorm(X, W_[pp + "ln_2.w"], W_[pp + "ln_2.b"], 1e-5, R, D, out_f16=Y)
-            ops.gemm(Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=ops.ACT_QUICKGELU)
-            ops.gemm(Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
+        self._vit_blocks(X, B, T, D, self.heads, self.layers, 1e-5, ops.ACT_QUICKGELU)     # :318-321
         tok = self._buf("tok", (B, h * w, D), f32)
         ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B * h * w, D, out_f32=tok,
                       in_group_rows=h * w, in_group_stride=T, in_offset=1)                 # :403-404
@@ -192,49 +277,7 @@ class ZutisEngine:
         ops.gemm(f2, W_["ffn1.2.w"], DEC, bias=W_["ffn1.2.b"])
         KIN = self._buf("KIN16", (B * M, D), f16)
         ops.add_rowperiodic_f16(DEC, geo["pe"], KIN, B * M, D, M)                           # transformer.py:281 memory+pos
-        KALL = self._buf("KALL", (B * M, L * D), f16)
-        VALL = self._buf("VALL", (B * M, L * D), f16)
-        ops.gemm(KIN, W_["ca_k_w"], KALL, bias=W_["ca_k_b"])                                # all layers' K / V at once
-        ops.gemm(DEC, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
-
-        # decoder (transformer.py:114-152 over :262-291), tgt = zeros, query_pos = query_embed
-        R = B * Q
-        dh, Hd = self.dec_dh, self.dec_heads
-        qpos = W_["query_embed"]
-        tgt = self._buf("tgt", (R, D), f32)
-        t1 = self._buf("t1", (R, D), f32)
-        tgt16 = self._buf("tgt16", (R, D), f16)
-        qin16 = self._buf("qin16", (R, D), f16)
-        qk16 = self._buf("qk16", (R, 2 * D), f16)
-        v16 = self._buf("v16", (R, D), f16)
-        qc16 = self._buf("qc16", (R, D), f16)
-        o16 = self._buf("do16", (R, D), f16)
-        ff16 = self._buf("ff16", (R, W_["decoder.layers.0.l1_w"].shape[0]), f16)
-        inter16 = self._buf("inter16", (B * L * Q, D), f16)
-        tgt.zero_()
-        ops.cast_f16(tgt, tgt16, R, D)
-        ops.cast_f16(tgt, qin16, R, D, add=qpos, add_rows=Q)
-        for l in range(L):
-            pp = f"decoder.layers.{l}."
-            ops.gemm(qin16, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])             # q = k = tgt + query_pos
-            ops.gemm(tgt16, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])                 # v = tgt
-            ops.attention(qk16, qk16[:, D:], v16, o16, batch=B, heads=Hd, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D, ldk=2 * D,
-                          ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D)
-            ops.gemm(o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=tgt)
-            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=tgt, out_f16_plus=qin16,
-                          add=qpos, add_rows=Q)
-            ops.gemm(qin16, W_[pp + "ca_q_w"], qc16, bias=W_[pp + "ca_q_b"])
-            ops.attention(qc16, KALL[:, l * D:], VALL[:, l * D:], o16, batch=B, heads=Hd, Tq=Q, Tk=M, head_dim=dh, ldq=D,
-                          ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D, strideO=Q * D)
-            ops.gemm(o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt)
-            ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
-            ops.gemm(tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
-            ops.gemm(ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
-            ops.layernorm(t1, W_[pp + "norm3.w"], W_[pp + "norm3.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16,
-                          out_f16_plus=qin16, add=qpos, add_rows=Q)
-            ops.layernorm(tgt, W_["decoder.norm.weight"], W_["decoder.norm.bias"], 1e-5, R, D, out_f16=inter16,
-                          out_group_rows=Q, out_group_stride=L * Q, out_offset=l * Q)       # :140-150, stacked [B,L,Q,D]
-
+        inter16 = self._decoder(DEC, KIN, B, M, D, Q, L, self.dec_heads, stack_all=True)    # transformer.py:114-152
         RQ = B * L * Q
         g1 = self._buf("ffn2_h1", (RQ, Fh), f16)
         g2 = self._buf("ffn2_h2", (RQ, Fh), f16)
@@ -318,3 +361,112 @@ class ZutisEngine:
         uni = torch.empty((n, n), dtype=torch.int32, device=masks_u8.device)
         ops.mask_iou_counts(masks_u8.contiguous(), n, px, inter, uni)
         return inter.cpu().numpy() / (uni.cpu().numpy() + 1e-7)
+
+
+class SelfMaskEngine(_EngineBase):
+    """SelfMask pseudo-labeller (networks/selfmask/selfmask.py:137-245): DINO ViT-S/8 encoder
+    (vision_transformer.py:260-304) -> 6-layer decoder, 20 queries, no memory pos -> x2 upsampled tokens . queries ->
+    objectness MLP; inference picks the argmax-objectness query, x4 bilinear, crop, > 0.5."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int = 8, heads: int = 6):
+        self.params = params
+        self.patch, self.heads = patch, heads
+        self.D = params["encoder.cls_token"].shape[-1]
+        self.layers = 1 + max(int(k.split(".")[2]) for k in params if k.startswith("encoder.blocks."))
+        self.dec_layers = 1 + max(int(k.split(".")[2]) for k in params if k.startswith("decoder.layers."))
+        self.Q = params["query_embed"].shape[0]
+        self.n_pos = params["encoder.pos_embed"].shape[1] - 1
+        self.grid = int(math.isqrt(self.n_pos))
+        if self.D // heads != 64:
+            raise ZutisHipError("SelfMaskEngine: head_dim must be 64")
+        self._init_base()
+
+    def _pack(self):
+        key = self._version_key()
+        if key == self._packed_key:
+            return
+        P, D, w = self.params, self.D, {}
+        dev = self._device()
+        h, c32 = self._h, self._c32
+        kc = 3 * self.patch * self.patch
+        self.Kc = _rup(kc, 64)
+        wc = torch.zeros((D, self.Kc), dtype=f16, device=dev)
+        wc[:, :kc] = P["encoder.patch_embed.proj.weight"].detach().reshape(D, kc).to(f16)
+        w["conv"], w["conv_b"] = wc, c32(P["encoder.patch_embed.proj.bias"])
+        w["cls"] = c32(P["encoder.cls_token"].reshape(D))
+        w["pos"] = c32(P["encoder.pos_embed"].reshape(-1, D))
+        w["norm.w"], w["norm.b"] = c32(P["encoder.norm.weight"]), c32(P["encoder.norm.bias"])
+        for i in range(self.layers):
+            p, q = f"encoder.blocks.{i}.", f"enc.{i}."
+            w[q + "qkv_w"], w[q + "qkv_b"] = h(P[p + "attn.qkv.weight"]), c32(P[p + "attn.qkv.bias"])
+            w[q + "out_w"], w[q + "out_b"] = h(P[p + "attn.proj.weight"]), c32(P[p + "attn.proj.bias"])
+            w[q + "fc_w"], w[q + "fc_b"] = h(P[p + "mlp.fc1.weight"]), c32(P[p + "mlp.fc1.bias"])
+            w[q + "proj_w"], w[q + "proj_b"] = h(P[p + "mlp.fc2.weight"]), c32(P[p + "mlp.fc2.bias"])
+            for ln, ln2 in (("norm1", "ln1"), ("norm2", "ln2")):
+                w[q + ln2 + ".w"], w[q + ln2 + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
+        self._pack_decoder(w, P, D, self.dec_layers)
+        for j in range(3):
+            w[f"ffn.{j}.w"], w[f"ffn.{j}.b"] = h(P[f"ffn.layers.{j}.weight"]), c32(P[f"ffn.layers.{j}.bias"])
+        self._w, self._packed_key = w, key
+        self._geo.clear()
+
+    def _pos(self, h: int, w: int) -> torch.Tensor:
+        """vision_transformer.py:377-401: bicubic `size=` resample of the 28x28 grid (scale = g/h); returned
+        unchanged when h*w equals the stored patch COUNT (the reference compares counts only, :385-388)."""
+        g = self._geo.get((h, w))
+        if g is None:
+            if h * w == self.n_pos:
+                pos = self._w["pos"]
+            else:
+                pos = torch.empty((1 + h * w, self.D), dtype=f32, device=self._device())
+                ops.posembed_bicubic(self._w["pos"], pos, self.grid, h, w, self.D, np.float32(self.grid) / np.float32(h),
+                                     np.float32(self.grid) / np.float32(w), True)
+            g = {"pos": pos}
+            self._geo[(h, w)] = g
+        return g["pos"]
+
+    def forward(self, x: torch.Tensor, inference: bool = False):
+        """Returns {"objectness" [B,1,Q,1] (sigmoid), "mask_pred" [B,1,Q,2h,2w]} or, with inference=True,
+        {"dts": uint8 [B,H,W] on device, "index": int64 [B]} (selfmask.py:204-224)."""
+        self._pack()
+        if not (x.is_cuda and x.dtype == f32 and x.dim() == 4 and x.shape[1] == 3):
+            raise ZutisHipError("SelfMaskEngine.forward: expected float32 CUDA tensor [B,3,H,W]")
+        x = x.contiguous()
+        W_, D, p, Q, L = self._w, self.D, self.patch, self.Q, self.dec_layers
+        B, _, H, Wd = x.shape
+        h, w = (H + p - 1) // p, (Wd + p - 1) // p                                       # make_input_divisible :260-267
+        T, R, M = 1 + h * w, B * (1 + h * w), 4 * h * w
+        col = self._buf("col", (B * h * w, self.Kc), f16)
+        ops.im2col(x, col, p, self.Kc, pad_to_patch=True)
+        pe32 = self._buf("patch_emb", (B * h * w, D), f32)
+        ops.gemm(col, W_["conv"], pe32, bias=W_["conv_b"])                               # PatchEmbed :182 (conv WITH bias)
+        X = self._buf("X", (R, D), f32)
+        ops.assemble_tokens_ln(pe32, W_["cls"], self._pos(h, w), None, None, 0.0, X, B, T, D)   # prepare_tokens :269-281
+        self._vit_blocks(X, B, T, D, self.heads, self.layers, 1e-6, ops.ACT_GELU_ERF)    # Block :160-170
+        tok = self._buf("tok", (B, h * w, D), f32)
+        tok16 = self._buf("tok16", (B * h * w, D), f16)
+        ops.layernorm(X, W_["norm.w"], W_["norm.b"], 1e-6, B * h * w, D, out_f32=tok, out_f16=tok16,
+                      in_group_rows=h * w, in_group_stride=T, in_offset=1)               # norm(x)[:, 1:]  :298, selfmask.py:94-100
+        q16 = self._decoder(tok16, tok16, B, h * w, D, Q, L, self.heads, stack_all=False)    # selfmask.py:110-116 (pos=None)
+        FEAT = self._buf("FEAT16", (B * M, D), f16)
+        ops.upsample2x_cl(tok, B, h, w, D, out_f16=FEAT)                                 # forward_pixel_decoder :131-135
+        masks = torch.empty((B, 1, Q, 2 * h, 2 * w), dtype=f32, device=x.device)
+        ops.gemm(q16, FEAT, masks, act=ops.ACT_SIGMOID, M=Q, N=M, K=D, lda=D, ldw=D, ldc=M, batch=B,
+                 strideA=Q * D, strideW=M * D, strideC=Q * M)                             # einsum("bqn,bnhw->bqhw") + sigmoid :181
+        o1 = self._buf("obj_h1", (B * Q, D), f16)
+        o2 = self._buf("obj_h2", (B * Q, D), f16)
+        ops.gemm(q16, W_["ffn.0.w"], o1, bias=W_["ffn.0.b"], act=ops.ACT_RELU)           # objectness MLP :182
+        ops.gemm(o1, W_["ffn.1.w"], o2, bias=W_["ffn.1.b"], act=ops.ACT_RELU)
+        obj = torch.empty((B, 1, Q, 1), dtype=f32, device=x.device)
+        if not inference:
+            ops.gemm(o2, W_["ffn.2.w"], obj, bias=W_["ffn.2.b"], act=ops.ACT_SIGMOID, M=B * Q, N=1, K=D, ldc=1)
+            return {"objectness": obj, "mask_pred": masks}
+        ops.gemm(o2, W_["ffn.2.w"], obj, bias=W_["ffn.2.b"], M=B * Q, N=1, K=D, ldc=1)
+        # Q logits per image: the host picks WHICH plane to upsample (first max, as torch.argmax on CPU)
+        sel = obj.view(B, Q).cpu().numpy().argmax(axis=1).tolist()
+        idx = torch.tensor(sel, dtype=torch.int64)
+        dts = torch.empty((B, H, Wd), dtype=torch.uint8, device=x.device)
+        for b in range(B):                            # x4 bilinear of the selected query only, cropped to [:H,:W], > 0.5
+            plane = masks[b, 0, sel[b]]
+            ops.upsample_bilinear_nchw(plane, 1, 2 * h, 2 * w, H, Wd, mask_u8=dts[b], threshold=0.5, scale_h=0.25, scale_w=0.25)
+        return {"dts": dts, "index": idx}

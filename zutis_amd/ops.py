@@ -114,11 +114,11 @@ def global_ln_l2(x, B, M, Cc, out_f32=None, out_f16=None, eps=1e-5, l2_eps=1e-7,
                                  workspace.numel() * workspace.element_size(), _stream()), "zh_global_ln_l2")
 
 
-def im2col(x, out, patch, Kpad):
+def im2col(x, out, patch, Kpad, pad_to_patch=False):
     L = _lib.load()
     B, Cin, H, W = x.shape
     _chk(x, f32, "im2col x")
-    _lib.check(L.zh_im2col_f16(_p(x), _p(out), B, Cin, H, W, patch, Kpad, _stream()), "zh_im2col_f16")
+    _lib.check(L.zh_im2col_f16(_p(x), _p(out), B, Cin, H, W, patch, Kpad, int(pad_to_patch), _stream()), "zh_im2col_f16")
 
 
 def posembed_bicubic(pos, out, grid, h, w, D, scale_h, scale_w, has_cls=True):
@@ -158,10 +158,13 @@ def upsample_argmax(logits_lo, labels, B, n, h, w, H, W):
                "zh_upsample_argmax")
 
 
-def upsample_bilinear_nchw(x, planes, h, w, H, W, out=None, mask_u8=None, threshold=0.5):
+def upsample_bilinear_nchw(x, planes, h, w, H, W, out=None, mask_u8=None, threshold=0.5, scale_h=None, scale_w=None):
+    """scale_* default to in/out (size= form); pass 1/scale_factor for the scale_factor form with a cropped output."""
     L = _lib.load()
+    sh = lin_scale(h, H) if scale_h is None else float(np.float32(scale_h))
+    sw = lin_scale(w, W) if scale_w is None else float(np.float32(scale_w))
     _lib.check(L.zh_upsample_bilinear_nchw(_p(x), _p(out), _p(mask_u8), float(threshold), planes, h, w, H, W,
-                                           lin_scale(h, H), lin_scale(w, W), _stream()), "zh_upsample_bilinear_nchw")
+                                           sh, sw, _stream()), "zh_upsample_bilinear_nchw")
 
 
 def confusion_hist(label_true, label_pred, hist, n_class):
