@@ -139,6 +139,25 @@ size_t zh_mask_iou_workspace_size(int n, long pixels);
 int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels, int* inter, int* uni,
                        void* workspace, size_t workspace_bytes, zh_stream_t stream);
 
+/* ---- bilateral solver (SelfMask refinement), utils/bilateral_solver.py:40-195; float64 ---- */
+/* convert_tensor_to_pil_image, utils/utils.py:261-273: fp32 x*std+mean, *255, clip, TRUNCATE.  x f32 [3,H,W] (device)
+ * -> rgb u8 [H,W,3] (device).  mean3/std3 are HOST float[3]. */
+int zh_denormalize_u8(const float* x, unsigned char* rgb, int H, int W, const float* mean3, const float* std3,
+                      zh_stream_t stream);
+/* per-pixel lattice coordinates (x/ss, y/ss, Y/sl, U/sc, V/sc), bilateral_solver.py:42-50 -> int32 [H*W,5] (parity probe). */
+int zh_bgrid_coords(const unsigned char* rgb, int H, int W, double sigma_spatial, double sigma_luma, double sigma_chroma,
+                    int* coords, zh_stream_t stream);
+/* BilateralGrid + bistochastize + BilateralSolver.solve for one channel: bilateral_solver.py:58-149 with the
+ * constants of bilateral_solver_output (:162-175: confidence 0.999, lam 256, A_diag_min 1e-5, cg_tol 1e-5, maxiter 25)
+ * passed by the caller.  rgb u8 [H,W,3]; target u8 [H,W] or f64 [H,W] (exactly one non-NULL); out_soft f64 [H,W];
+ * stats int32 [2] = {nvertices, cg iterations} (device, may be NULL); n_out/m_out f64 [H*W] debug copies of the
+ * bistochastisation vectors (may be NULL). */
+size_t zh_bilateral_workspace_size(int H, int W, double sigma_spatial, double sigma_luma, double sigma_chroma);
+int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8, const double* target_f64, int H, int W,
+                       double sigma_spatial, double sigma_luma, double sigma_chroma, double confidence, double lam,
+                       double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
+                       double* n_out, double* m_out, void* workspace, size_t workspace_bytes, zh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -176,15 +176,67 @@ def gen_selfmask():
     np.savez_compressed(os.path.join(GOLD, "selfmask.npz"), **d)
 
 
+def gen_bilateral():
+    """Reference bilateral solver (utils/bilateral_solver.py) on small synthetic images + the gray-ramp known answer."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for m in [k for k in sys.modules if k.startswith("networks") or k.startswith("utils")]:
+        del sys.modules[m]
+    import scipy.sparse.linalg as spla
+    import utils.bilateral_solver as rb
+    from PIL import Image
+    its = []
+
+    def cg_shim(A, b, x0=None, M=None, maxiter=None, tol=1e-5):
+        n_it = [0]
+        x, info = spla.cg(A, b, x0=x0, M=M, maxiter=maxiter, rtol=tol, atol=0.0, callback=lambda xk: n_it.__setitem__(0, n_it[0] + 1))
+        its.append(n_it[0])
+        return x, info
+    rb.cg = cg_shim
+    d = {}
+    ramp = np.repeat(np.arange(0, 256, 16, dtype=np.uint8)[None, :, None], 3, axis=2)       # gray 0,16,...,240
+    g = rb.BilateralGrid(np.repeat(ramp, 4, axis=0), sigma_spatial=16, sigma_luma=16, sigma_chroma=8)
+    yuv = rb.rgb2yuv(ramp)
+    d["ramp_luma_bins"] = (yuv[0, :, 0] / 16).astype(int)
+    d["ramp_chroma_bins"] = (yuv[0, :, 1:] / 8).astype(int)
+    for tag, (h, w, seed) in {"a": (96, 128, 3), "b": (120, 90, 5), "c": (64, 64, 9)}.items():
+        rgb = detgen.selfmask_like_rgb(h, w, seed=seed)
+        yy, xx = np.mgrid[:h, :w]
+        target = (((yy - h * 0.5) ** 2 + (xx - w * 0.45) ** 2) < (0.3 * min(h, w)) ** 2).astype(np.uint8)
+        if tag == "c":
+            target[:8, :8] = 1                                                             # a second component
+        grid = rb.BilateralGrid(rgb, sigma_spatial=16, sigma_luma=16, sigma_chroma=8)
+        Dn, Dm = rb.bistochastize(grid)
+        soft, binary = rb.bilateral_solver_output(Image.fromarray(rgb), target)
+        d[f"{tag}_hw"] = np.array([h, w, seed])
+        d[f"{tag}_target"] = target
+        d[f"{tag}_nvertices"] = grid.nvertices
+        d[f"{tag}_nnz"] = np.array([b.nnz for b in grid.blurs])
+        d[f"{tag}_n"], d[f"{tag}_m"] = Dn.diagonal(), Dm.diagonal()
+        d[f"{tag}_soft"], d[f"{tag}_binary"] = soft, binary
+        d[f"{tag}_cg_iters"] = its[-1]
+        print("bilateral", tag, "V", grid.nvertices, "nnz", d[f"{tag}_nnz"], "cg iters", its[-1], "fg", (soft > 0.5).mean())
+    # de-normalise step (utils/utils.py:261-273) on values engineered to land on integer boundaries
+    from utils.utils import convert_tensor_to_pil_image
+    x = torch.from_numpy(detgen.det_normal("denorm", (3, 40, 56)))
+    x[0, 0, :16] = torch.from_numpy(((np.arange(16) * 16 / 255.0 - 0.485) / 0.229).astype(np.float32))
+    d["denorm_u8"] = np.array(convert_tensor_to_pil_image(x))
+    np.savez_compressed(os.path.join(GOLD, "bilateral.npz"), **d)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if "--bilateral-only" in sys.argv:
+        gen_bilateral()
+        sys.exit(0)
     if "--selfmask-only" in sys.argv:
         gen_selfmask()
         sys.exit(0)
     gen_ops()
     gen_selfmask()
+    gen_bilateral()
     gen_e2e("tiny", detgen.TINY, b=2, H=80, W=112, n_cat=7, size=(80, 112), full=True)
     gen_e2e("vitb16_336", detgen.VIT_B16, b=1, H=336, W=336, n_cat=81, size=(336, 336), full=False)
     gen_e2e("vitb32_224", detgen.VIT_B32, b=1, H=224, W=224, n_cat=81, size=(224, 224), full=False)

@@ -1,0 +1,79 @@
+"""-m gpu: float64 bilateral-solver kernels against the reference's golden outputs and the NumPy/SciPy oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_yuv_binning_all_colours_bit_exact(dev):
+    """Integer output: lattice coordinates of ALL 2^24 RGB colours equal np.tensordot's (bilateral_solver.py:21-22,46-49),
+    incl. the bin-edge cases (gray 16 -> Y = 15.999999999999998 -> bin 0)."""
+    from zutis_amd import ops
+    from oracle import bilateral_ref as B
+    r, g, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    rgb = np.stack([r, g, b], -1).reshape(4096, 4096, 3)
+    got = ops.bgrid_coords(torch.from_numpy(rgb).to(dev)).cpu().numpy()
+    ref = B.grid_coords(rgb)
+    assert np.array_equal(got, ref)
+
+
+def test_denormalize_bit_exact(dev, golden_dir):
+    from zutis_amd import ops, detgen
+    g = np.load(f"{golden_dir}/bilateral.npz")
+    x = detgen.det_normal("denorm", (3, 40, 56))
+    x[0, 0, :16] = ((np.arange(16) * 16 / 255.0 - 0.485) / 0.229).astype(np.float32)
+    got = ops.denormalize_u8(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.array_equal(got, g["denorm_u8"])                      # the reference's convert_tensor_to_pil_image output
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_solver_vs_reference_golden(dev, golden_dir, tag):
+    from zutis_amd import ops, detgen
+    g = np.load(f"{golden_dir}/bilateral.npz")
+    h, w, seed = (int(v) for v in g[f"{tag}_hw"])
+    rgb = detgen.selfmask_like_rgb(h, w, seed=seed)
+    soft, stats, n, m = ops.bilateral_solve(torch.from_numpy(rgb).to(dev), torch.from_numpy(g[f"{tag}_target"]).to(dev), debug=True)
+    V, its = (int(v) for v in stats.cpu().numpy())
+    assert V == int(g[f"{tag}_nvertices"])                          # integer: exact
+    assert its == int(g[f"{tag}_cg_iters"])
+    assert np.abs(n.cpu().numpy()[:V] - g[f"{tag}_n"]).max() < 1e-13      # bistochastisation (sqrt/div are IEEE)
+    assert np.abs(m.cpu().numpy()[:V] - g[f"{tag}_m"]).max() < 1e-11
+    err = np.abs(soft.cpu().numpy() - g[f"{tag}_soft"]).max()
+    assert err < 1e-9, err                                          # output_solver float64, tol 1e-9
+    assert np.array_equal(soft.cpu().numpy() > 0.5, g[f"{tag}_soft"] > 0.5)
+
+
+def test_dropin_bilateral_solver_output(dev, golden_dir):
+    from zutis_amd import detgen
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    from PIL import Image
+    from utils.bilateral_solver import bilateral_solver_output
+    g = np.load(f"{golden_dir}/bilateral.npz")
+    h, w, seed = (int(v) for v in g["c_hw"])
+    soft, binary = bilateral_solver_output(Image.fromarray(detgen.selfmask_like_rgb(h, w, seed=seed)), g["c_target"])
+    assert soft.dtype == np.float64 and binary.dtype == np.bool_
+    assert np.abs(soft - g["c_soft"]).max() < 1e-9
+    assert np.array_equal(binary, g["c_binary"])
+
+
+def test_solver_vs_oracle_selfmask_size(dev):
+    """Full SelfMask-style size (512x683, V ~ 10^4-10^5): round trip against the oracle + float target path."""
+    from zutis_amd import ops, detgen
+    from oracle import bilateral_ref as B
+    h, w = 512, 683
+    rgb = detgen.selfmask_like_rgb(h, w, seed=3)
+    yy, xx = np.mgrid[:h, :w]
+    target = (((yy - 250) ** 2 + (xx - 300) ** 2) < 150 ** 2).astype(np.uint8)
+    ref_soft, _ = B.bilateral_solver_output(rgb, target)
+    soft, stats = ops.bilateral_solve(torch.from_numpy(rgb).to(dev), torch.from_numpy(target).to(dev))
+    grid = B.Grid(rgb)
+    assert int(stats[0]) == grid.nvertices
+    assert np.abs(soft.cpu().numpy() - ref_soft).max() < 1e-9
+    soft64, _ = ops.bilateral_solve(torch.from_numpy(rgb).to(dev), torch.from_numpy(target.astype(np.float64)).to(dev))
+    assert np.abs(soft64.cpu().numpy() - ref_soft).max() < 1e-9

@@ -112,3 +112,30 @@ def test_selfmask_oracle_matches_reference(golden_dir):
     assert np.abs(o["objectness"].numpy() - g["small_objectness"]).max() < 2e-6
     assert np.abs(o["mask_pred"].numpy() - g["small_mask_pred"]).max() < 5e-5
     assert np.array_equal(np.stack(dts).astype(bool), np.unpackbits(g["small_dts"], axis=-1)[..., :W].astype(bool))
+
+
+def test_bilateral_oracle_matches_reference(golden_dir):
+    """Grid size, nnz of every blur matrix, bistochastisation vectors (bit-exact), CG iteration count, soft output and
+    post-processed component against utils/bilateral_solver.py run in the authoring container."""
+    from oracle import bilateral_ref as B
+    g = np.load(f"{golden_dir}/bilateral.npz")
+    ramp = np.repeat(np.arange(0, 256, 16, dtype=np.uint8)[None, :, None], 3, axis=2)
+    c = B.grid_coords(ramp)
+    assert c[:, 2].tolist() == [0, 0, 1, 3, 3, 5, 6, 7, 7, 9, 10, 10, 12, 12, 14, 15]      # SURVEY.md §8c known answer
+    assert np.array_equal(c[:, 2], g["ramp_luma_bins"]) and np.array_equal(c[:, 3:], g["ramp_chroma_bins"])
+    for tag in "abc":
+        h, w, seed = (int(v) for v in g[f"{tag}_hw"])
+        rgb = detgen.selfmask_like_rgb(h, w, seed=seed)
+        grid = B.Grid(rgb)
+        assert grid.nvertices == int(g[f"{tag}_nvertices"])
+        assert [(grid.nbr[:, d, :] >= 0).sum() for d in range(5)] == g[f"{tag}_nnz"].tolist()
+        t = g[f"{tag}_target"].reshape(-1).astype(np.double)
+        xhat, its, n, m = B.solve(grid, t, np.ones(t.size) * 0.999)
+        assert np.array_equal(n, g[f"{tag}_n"]) and np.array_equal(m, g[f"{tag}_m"])
+        assert its == int(g[f"{tag}_cg_iters"])
+        soft = xhat.reshape(h, w)
+        assert np.abs(soft - g[f"{tag}_soft"]).max() < 1e-12
+        assert np.array_equal(B.postprocess(soft), g[f"{tag}_binary"])
+    x = detgen.det_normal("denorm", (3, 40, 56))
+    x[0, 0, :16] = ((np.arange(16) * 16 / 255.0 - 0.485) / 0.229).astype(np.float32)
+    assert np.array_equal(B.denormalize_to_u8(x), g["denorm_u8"])

@@ -23,7 +23,7 @@ def declared_symbols(header: str = HEADER):
     return sorted(set(re.findall(r"\b(zh_[a-z0-9_]+)\s*\(", txt)))
 
 
-_vp, _l, _i, _f, _sz = C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_size_t
+_vp, _l, _i, _f, _sz, _d = C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_size_t, C.c_double
 _SIGS = {
     "zh_version": (C.c_int, []),
     "zh_arch": (C.c_char_p, []),
@@ -47,6 +47,10 @@ _SIGS = {
     "zh_instance_mask_stats": (_i, [_vp, _l, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "zh_masked_mean_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "zh_instance_classify": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "zh_denormalize_u8": (_i, [_vp, _vp, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "zh_bgrid_coords": (_i, [_vp, _i, _i, _d, _d, _d, _vp, _vp]),
+    "zh_bilateral_workspace_size": (_sz, [_i, _i, _d, _d, _d]),
+    "zh_bilateral_solve": (_i, [_vp, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "zh_mask_iou_workspace_size": (_sz, [_i, _l]),
     "zh_mask_iou_counts": (_i, [_vp, _i, _l, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -1,0 +1,443 @@
+// Fast bilateral solver (Barron & Poole) for SelfMask mask refinement — utils/bilateral_solver.py:40-195 — in
+// float64 on gfx950, plus the de-normalise-to-uint8 step in front of it (utils/utils.py:261-273).
+// Compiled with -ffp-contract=off: bin edges are hit exactly (gray 16 -> Y = 15.999999999999998 -> bin 0) and the
+// grid quantities (bistochastisation) are bit-identical to NumPy/SciPy.
+//
+// MI355X design.  The reference builds the grid with a float hash + np.unique (a sort of N keys) + five
+// searchsorted passes + six CSR matrices.  Here the 5-D lattice is small and dense-indexable
+// (Nx*Ny*Nl*Nu*Nv cells, 22.5 M at 512x683 => a 2.8 MB bitmap that lives in L2), and the dense cell order IS the
+// hash order (hash = x + 255 y + 255^2 l + ... sorts by (v,u,l,y,x)).  So:
+//   vertex id of a cell   = exclusive popcount-prefix of the occupancy bitmap   (== np.unique's sorted rank)
+//   neighbour of a vertex = bit test at cell +/- stride_d + the same prefix      (== searchsorted + equality test)
+// No sort, no hash table, no CSR: splat is an integer-indexed atomic add (order-independent for binary targets:
+// every addend is 0 or the same constant), blur is a 10-entry gather summed in SciPy's CSR column order.
+// The PCG loop keeps every scalar (rho, alpha, ||r||, the convergence flag) on the device: 3 launches per
+// iteration, deterministic two-level reductions, no host round trip until the result is sliced.
+#include "common.h"
+
+typedef unsigned long long u64;
+
+struct BgDims { int Nx, Ny, Nl, Nu, Nv; long cells; };
+
+__device__ __forceinline__ double blur_gather(const double* __restrict__ x, const int* __restrict__ nb, double xv) {
+  double out = 10.0 * xv;                                     // 2 * dim * x   (bilateral_solver.py:97)
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    const int lo = nb[2 * d], hi = nb[2 * d + 1];
+    double t = lo >= 0 ? x[lo] : 0.0;
+    if (hi >= 0) t = t + x[hi];
+    out = out + t;
+  }
+  return out;
+}
+__device__ __forceinline__ double blur_gather_scaled(const double* __restrict__ x, const double* __restrict__ s,
+                                                     const int* __restrict__ nb, double xv) {  // blur(s .* x)
+  double out = 10.0 * xv;
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    const int lo = nb[2 * d], hi = nb[2 * d + 1];
+    double t = lo >= 0 ? s[lo] * x[lo] : 0.0;
+    if (hi >= 0) t = t + s[hi] * x[hi];
+    out = out + t;
+  }
+  return out;
+}
+
+// ---- de-normalise: fp32 x*std + mean, *255, clip, TRUNCATE (utils/utils.py:269-272).  x [3,H,W] -> rgb u8 [H,W,3]
+__global__ __launch_bounds__(256) void denorm_kernel(const float* x, unsigned char* rgb, long HW, float m0, float m1, float m2,
+                                                     float s0, float s1, float s2) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = __fadd_rn(__fmul_rn(x[c * HW + i], sd[c]), mean[c]);
+    v = fminf(fmaxf(__fmul_rn(v, 255.0f), 0.0f), 255.0f);
+    rgb[i * 3 + c] = (unsigned char)v;
+  }
+}
+
+extern "C" int zh_denormalize_u8(const float* x, unsigned char* rgb, int H, int W, const float* mean3, const float* std3,
+                                 hipStream_t stream) {
+  ZH_CHECK_ARG(x && rgb && H > 0 && W > 0 && mean3 && std3, "zh_denormalize_u8: bad arguments");   // mean3/std3 are HOST pointers
+  const long HW = (long)H * W;
+  hipLaunchKernelGGL(denorm_kernel, dim3(zh_cdiv(HW, 256)), dim3(256), 0, stream, x, rgb, HW, mean3[0], mean3[1], mean3[2],
+                     std3[0], std3[1], std3[2]);
+  ZH_CHECK_LAUNCH("zh_denormalize_u8");
+  return ZH_OK;
+}
+
+// ---- K1: 5-D coordinates (bilateral_solver.py:42-50) -> dense cell id, occupancy bitmap
+__device__ __forceinline__ void yuv_bins(unsigned char R, unsigned char G, unsigned char B, double sl, double sc, int& l, int& u, int& v) {
+  const double r = R, g = G, b = B;
+  // np.tensordot -> OpenBLAS dgemm: a k-ordered FMA chain on every FMA-capable x86 (probed exhaustively over all 2^24
+  // colours: plain mul/add order mis-bins 207 of them, the chain none).  Explicit fma(): the file is built with
+  // -ffp-contract=off so nothing else is contracted.
+  const double Y = fma(b, 0.114, fma(g, 0.587, r * 0.299));
+  const double U = fma(b, 0.5, fma(g, -0.331264, r * -0.168736)) + 128.0;
+  const double V = fma(b, -0.081312, fma(g, -0.418688, r * 0.5)) + 128.0;
+  l = (int)(Y / sl); u = (int)(U / sc); v = (int)(V / sc);
+}
+
+__global__ __launch_bounds__(256) void bg_cells_kernel(const unsigned char* rgb, int H, int W, double ss, double sl, double sc,
+                                                       BgDims dm, int* cell, u64* bitmap, int* coords_out) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long)H * W) return;
+  const int y = (int)(p / W), x = (int)(p - (long)y * W);
+  int l, u, v;
+  yuv_bins(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2], sl, sc, l, u, v);
+  const int cx = (int)((double)x / ss), cy = (int)((double)y / ss);
+  if (coords_out) { int* c = coords_out + 5 * p; c[0] = cx; c[1] = cy; c[2] = l; c[3] = u; c[4] = v; }
+  if (cell) {
+    l = min(l, dm.Nl - 1); u = min(u, dm.Nu - 1); v = min(v, dm.Nv - 1);
+    const long id = ((((long)v * dm.Nu + u) * dm.Nl + l) * dm.Ny + cy) * dm.Nx + cx;
+    cell[p] = (int)id;
+    atomicOr(&bitmap[id >> 6], 1ull << (id & 63));
+  }
+}
+
+// ---- K2: exclusive prefix of per-word popcounts (3 passes; words <= ~1M)
+#define SCAN_PER_BLOCK 1024
+__global__ __launch_bounds__(256) void bg_scan_block_sums(const u64* bitmap, long nwords, unsigned* blocksum) {
+  const long base = (long)blockIdx.x * SCAN_PER_BLOCK;
+  unsigned s = 0;
+  for (int i = threadIdx.x; i < SCAN_PER_BLOCK; i += 256)
+    if (base + i < nwords) s += __popcll(bitmap[base + i]);
+  __shared__ unsigned red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void bg_scan_top(unsigned* blocksum, int nb, int* nvertices) {   // one thread: nb is a few hundred
+  unsigned acc = 0;
+  for (int i = 0; i < nb; ++i) { const unsigned t = blocksum[i]; blocksum[i] = acc; acc += t; }
+  *nvertices = (int)acc;
+}
+__global__ __launch_bounds__(256) void bg_scan_write(const u64* bitmap, long nwords, const unsigned* blocksum, unsigned* wprefix) {
+  // each thread owns 4 consecutive words; block-level exclusive scan of the 256 thread sums
+  const long base = (long)blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 4;
+  unsigned c[4], s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { c[i] = base + i < nwords ? __popcll(bitmap[base + i]) : 0; s += c[i]; }
+  __shared__ unsigned sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned run = blocksum[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { if (base + i < nwords) wprefix[base + i] = run; run += c[i]; }
+}
+
+// ---- K3: pixel -> vertex, splat of ones / confidence / target*confidence (S.dot, bilateral_solver.py:87-88)
+__global__ __launch_bounds__(256) void bg_assign_kernel(const int* cell, const u64* bitmap, const unsigned* wprefix, long N,
+                                                        const unsigned char* t_u8, const double* t_f64, double conf,
+                                                        int* pix2v, double* cnt, double* wsplat, double* bsplat) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= N) return;
+  const int id = cell[p];
+  const u64 w = bitmap[id >> 6];
+  const int v = (int)(wprefix[id >> 6] + __popcll(w & ((1ull << (id & 63)) - 1ull)));
+  pix2v[p] = v;
+  const double t = t_u8 ? (double)t_u8[p] : t_f64[p];
+  atomicAdd(&cnt[v], 1.0);
+  atomicAdd(&wsplat[v], conf);
+  atomicAdd(&bsplat[v], t * conf);
+}
+
+// ---- K4/K5: vertex -> cell, neighbour table (get_valid_idx, bilateral_solver.py:29-37,69-81)
+__global__ __launch_bounds__(256) void bg_vertices_kernel(const u64* bitmap, const unsigned* wprefix, long nwords, int* vcell) {
+  const long w = (long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  u64 bits = bitmap[w];
+  unsigned v = wprefix[w];
+  while (bits) {
+    const int b = __ffsll((long long)bits) - 1;
+    vcell[v++] = (int)(w * 64 + b);
+    bits &= bits - 1;
+  }
+}
+__global__ __launch_bounds__(256) void bg_neighbors_kernel(const int* vcell, const u64* bitmap, const unsigned* wprefix, const int* nv,
+                                                           BgDims dm, int* nbr) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= *nv) return;
+  const long id = vcell[v];
+  long r = id;
+  int c[5];
+  const int dims[5] = {dm.Nx, dm.Ny, dm.Nl, dm.Nu, dm.Nv};
+  long stride[5];
+  long st = 1;
+#pragma unroll
+  for (int d = 0; d < 5; ++d) { c[d] = (int)(r % dims[d]); r /= dims[d]; stride[d] = st; st *= dims[d]; }
+#pragma unroll
+  for (int d = 0; d < 5; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int cc = c[d] + (s ? 1 : -1);
+      int out = -1;
+      if (cc >= 0 && cc < dims[d]) {
+        const long j = id + (s ? stride[d] : -stride[d]);
+        const u64 w = bitmap[j >> 6];
+        if ((w >> (j & 63)) & 1ull) out = (int)(wprefix[j >> 6] + __popcll(w & ((1ull << (j & 63)) - 1ull)));
+      }
+      nbr[v * 10 + 2 * d + s] = out;
+    }
+}
+
+// ---- bistochastisation (bilateral_solver.py:107-118)
+__global__ __launch_bounds__(256) void bg_bisto_step(const double* n_in, const double* m0, const int* nbr, const int* nv, double* n_out) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= *nv) return;
+  const double nvv = n_in[v];
+  n_out[v] = sqrt(nvv * m0[v] / blur_gather(n_in, nbr + v * 10, nvv));
+}
+__global__ __launch_bounds__(256) void bg_bisto_final(const double* n, const int* nbr, const int* nv, double* m) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= *nv) return;
+  m[v] = n[v] * blur_gather(n, nbr + v * 10, n[v]);
+}
+
+// ---- PCG (scipy.sparse.linalg.cg semantics, Jacobi preconditioner; bilateral_solver.py:133-147)
+struct CgPtrs {
+  const double *n, *m, *wsplat, *b; const int* nbr; const int* nv;
+  double *minv, *x, *r, *z, *p, *q;
+  double *part_rz, *part_rr, *part_pq;   // per-block partial sums [nblocks]; three arrays => no cross-block WAR
+  double* sc;                            // scalars: [0],[1] rho ping-pong, [2] atol, [3] converged flag, [4] iterations
+  double lam, a_diag_min, rtol; int nblocks;
+};
+
+__device__ __forceinline__ double matvec_row(const CgPtrs& c, const double* y, int v) {
+  // A y = lam * (m*y - n * blur(n .* y)) + wsplat*y
+  const double ny = c.n[v] * y[v];
+  const double bl = blur_gather_scaled(y, c.n, c.nbr + v * 10, ny);
+  return c.lam * (c.m[v] * y[v] - c.n[v] * bl) + c.wsplat[v] * y[v];
+}
+__device__ __forceinline__ double block_sum(double s, double* red) {   // deterministic: fixed tree, fixed order
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double sum_partials(const double* part, int nb, double* red) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+  return block_sum(s, red);
+}
+
+__global__ __launch_bounds__(256) void bg_fill_kernel(double* x, double val, const int* nv) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v < *nv) x[v] = val;
+}
+__global__ __launch_bounds__(256) void cg_y0_kernel(CgPtrs c) {          // flat initialisation y0 = splat(xw) / splat(w)
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v < *c.nv) c.x[v] = c.b[v] / c.wsplat[v];
+}
+__global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c) {
+  __shared__ double red[4];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  double rz = 0.0, rr = 0.0, bb = 0.0;
+  if (v < *c.nv) {
+    const double diag = c.lam * (c.m[v] - c.n[v] * 10.0 * c.n[v]) + c.wsplat[v];
+    const double mi = 1.0 / fmax(diag, c.a_diag_min);
+    c.minv[v] = mi;
+    const double r = c.b[v] - matvec_row(c, c.x, v);
+    c.r[v] = r;
+    const double z = mi * r;
+    c.z[v] = z;
+    rz = r * z; rr = r * r; bb = c.b[v] * c.b[v];
+  }
+  const double s1 = block_sum(rz, red), s2 = block_sum(rr, red), s3 = block_sum(bb, red);
+  if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = s1; c.part_rr[blockIdx.x] = s2; c.part_pq[blockIdx.x] = s3; }
+}
+__global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c) {        // one block: atol = rtol * ||b||
+  __shared__ double red[4];
+  const double bb = sum_partials(c.part_pq, c.nblocks, red);
+  if (threadIdx.x == 0) { c.sc[2] = c.rtol * sqrt(bb); c.sc[3] = 0.0; c.sc[4] = 0.0; }
+}
+__global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c, int it) {
+  __shared__ double red[4];
+  // every block re-derives the convergence decision from the same partials (deterministic) -> no intra-kernel flag race;
+  // once converged the partials are frozen, so the decision repeats for all later iterations
+  const double rho = sum_partials(c.part_rz, c.nblocks, red);
+  const double rr = sum_partials(c.part_rr, c.nblocks, red);
+  if (sqrt(rr) < c.sc[2]) {                                               // ||r|| < atol at the top of iteration `it`
+    if (blockIdx.x == 0 && threadIdx.x == 0 && c.sc[3] == 0.0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
+    return;
+  }
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v < *c.nv) c.p[v] = it == 0 ? c.z[v] : c.z[v] + (rho / c.sc[(it - 1) & 1]) * c.p[v];
+  if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;
+}
+__global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c) {
+  __shared__ double red[4];
+  if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  double pq = 0.0;
+  if (v < *c.nv) { const double q = matvec_row(c, c.p, v); c.q[v] = q; pq = c.p[v] * q; }
+  const double s = block_sum(pq, red);
+  if (threadIdx.x == 0) c.part_pq[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c, int it) {
+  __shared__ double red[4];
+  if (c.sc[3] != 0.0) return;
+  const double pq = sum_partials(c.part_pq, c.nblocks, red);
+  const double alpha = c.sc[it & 1] / pq;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  double rz = 0.0, rr = 0.0;
+  if (v < *c.nv) {
+    c.x[v] += alpha * c.p[v];
+    const double r = c.r[v] - alpha * c.q[v];
+    c.r[v] = r;
+    const double z = c.minv[v] * r;
+    c.z[v] = z;
+    rz = r * z; rr = r * r;
+  }
+  const double s1 = block_sum(rz, red), s2 = block_sum(rr, red);
+  if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = s1; c.part_rr[blockIdx.x] = s2; }
+}
+__global__ void cg_finish_kernel(CgPtrs c, int maxiter, int* stats) {
+  if (c.sc[3] == 0.0) c.sc[4] = (double)maxiter;
+  if (stats) { stats[0] = *c.nv; stats[1] = (int)c.sc[4]; }
+}
+
+__global__ __launch_bounds__(256) void bg_slice_kernel(const double* y, const int* pix2v, long N, double* out) {   // S^T y
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p < N) out[p] = y[pix2v[p]];
+}
+
+// ---- host orchestration -----------------------------------------------------------------------------------------
+static BgDims bg_dims(int H, int W, double ss, double sl, double sc) {
+  BgDims d;
+  d.Nx = (int)((double)(W - 1) / ss) + 1; d.Ny = (int)((double)(H - 1) / ss) + 1;
+  d.Nl = (int)(255.0 / sl) + 1; d.Nu = (int)(255.5 / sc) + 1; d.Nv = d.Nu;
+  d.cells = (long)d.Nx * d.Ny * d.Nl * d.Nu * d.Nv;
+  return d;
+}
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct BgLayout {
+  size_t bitmap, wprefix, blocksum, cell, pix2v, vcell, nbr, dbl, part, sc, nv, total;
+  long nwords; int nscan; long Vmax; int nblocks;
+};
+static BgLayout bg_layout(int H, int W, const BgDims& d) {
+  BgLayout L;
+  const long N = (long)H * W;
+  L.nwords = (d.cells + 63) / 64;
+  L.nscan = zh_cdiv(L.nwords, SCAN_PER_BLOCK);
+  L.Vmax = N < d.cells ? N : d.cells;
+  L.nblocks = zh_cdiv(L.Vmax, 256);
+  size_t o = 0;
+  L.bitmap = o; o += al((size_t)L.nwords * 8);
+  L.wprefix = o; o += al((size_t)L.nwords * 4);
+  L.blocksum = o; o += al((size_t)L.nscan * 4);
+  L.cell = o; o += al((size_t)N * 4);
+  L.pix2v = o; o += al((size_t)N * 4);
+  L.vcell = o; o += al((size_t)L.Vmax * 4);
+  L.nbr = o; o += al((size_t)L.Vmax * 40);
+  L.dbl = o; o += al((size_t)L.Vmax * 8) * 13;      // cnt, wsplat, bsplat, nA, nB, m, minv, x, r, z, p, q, spare
+  L.part = o; o += al((size_t)L.nblocks * 8 * 3);
+  L.sc = o; o += 256;
+  L.nv = o; o += 256;
+  L.total = o;
+  return L;
+}
+
+extern "C" size_t zh_bilateral_workspace_size(int H, int W, double sigma_spatial, double sigma_luma, double sigma_chroma) {
+  if (H <= 0 || W <= 0 || sigma_spatial <= 0 || sigma_luma <= 0 || sigma_chroma <= 0) return 0;
+  const BgDims d = bg_dims(H, W, sigma_spatial, sigma_luma, sigma_chroma);
+  return bg_layout(H, W, d).total;
+}
+
+// debug / parity entry: per-pixel integer coordinates (x, y, luma, u, v) exactly as bilateral_solver.py:42-50
+extern "C" int zh_bgrid_coords(const unsigned char* rgb, int H, int W, double sigma_spatial, double sigma_luma, double sigma_chroma,
+                               int* coords, hipStream_t stream) {
+  ZH_CHECK_ARG(rgb && coords && H > 0 && W > 0, "zh_bgrid_coords: bad arguments");
+  BgDims d = bg_dims(H, W, sigma_spatial, sigma_luma, sigma_chroma);
+  hipLaunchKernelGGL(bg_cells_kernel, dim3(zh_cdiv((long)H * W, 256)), dim3(256), 0, stream, rgb, H, W, sigma_spatial, sigma_luma,
+                     sigma_chroma, d, (int*)nullptr, (u64*)nullptr, coords);
+  ZH_CHECK_LAUNCH("zh_bgrid_coords");
+  return ZH_OK;
+}
+
+// Whole solver for one image and one channel.  target: u8 [H,W] (target_u8) or f64 [H,W] (target_f64), exactly one non-NULL.
+// out_soft f64 [H,W].  stats (device, may be NULL): int32 [2] = {nvertices, cg iterations}.  Optional debug outputs
+// (device, may be NULL): n_out / m_out f64 [>= nvertices].
+extern "C" int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8, const double* target_f64, int H, int W,
+                                  double sigma_spatial, double sigma_luma, double sigma_chroma, double confidence, double lam,
+                                  double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
+                                  double* n_out, double* m_out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  ZH_CHECK_ARG(rgb && out_soft && H > 0 && W > 0, "zh_bilateral_solve: bad arguments");
+  ZH_CHECK_ARG((target_u8 != nullptr) != (target_f64 != nullptr), "zh_bilateral_solve: pass exactly one of target_u8 / target_f64");
+  ZH_CHECK_ARG(sigma_spatial > 0 && sigma_luma > 0 && sigma_chroma > 0 && cg_maxiter >= 0, "zh_bilateral_solve: bad parameters");
+  const BgDims d = bg_dims(H, W, sigma_spatial, sigma_luma, sigma_chroma);
+  ZH_CHECK_ARG(d.cells < (1L << 31), "zh_bilateral_solve: lattice too large (%ld cells)", d.cells);
+  const BgLayout L = bg_layout(H, W, d);
+  if (!workspace || workspace_bytes < L.total) {
+    zh_set_error("zh_bilateral_solve: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+    return ZH_ERR_WORKSPACE;
+  }
+  char* ws = (char*)workspace;
+  const long N = (long)H * W;
+  u64* bitmap = (u64*)(ws + L.bitmap);
+  unsigned* wprefix = (unsigned*)(ws + L.wprefix);
+  unsigned* blocksum = (unsigned*)(ws + L.blocksum);
+  int* cell = (int*)(ws + L.cell);
+  int* pix2v = (int*)(ws + L.pix2v);
+  int* vcell = (int*)(ws + L.vcell);
+  int* nbr = (int*)(ws + L.nbr);
+  const size_t dstride = al((size_t)L.Vmax * 8);
+  double* D[13];
+  for (int i = 0; i < 13; ++i) D[i] = (double*)(ws + L.dbl + dstride * i);
+  double *cnt = D[0], *wsplat = D[1], *bsplat = D[2], *nA = D[3], *nB = D[4], *m = D[5];
+  double* part = (double*)(ws + L.part);
+  double* sc = (double*)(ws + L.sc);
+  int* nv = (int*)(ws + L.nv);
+
+  (void)hipMemsetAsync(bitmap, 0, (size_t)L.nwords * 8, stream);
+  (void)hipMemsetAsync(ws + L.dbl, 0, dstride * 3, stream);                    // cnt, wsplat, bsplat
+  (void)hipMemsetAsync(sc, 0, 256, stream);
+  const dim3 blk(256), gN(zh_cdiv(N, 256)), gV(L.nblocks);
+  hipLaunchKernelGGL(bg_cells_kernel, gN, blk, 0, stream, rgb, H, W, sigma_spatial, sigma_luma, sigma_chroma, d, cell, bitmap, (int*)nullptr);
+  hipLaunchKernelGGL(bg_scan_block_sums, dim3(L.nscan), blk, 0, stream, bitmap, L.nwords, blocksum);
+  hipLaunchKernelGGL(bg_scan_top, dim3(1), dim3(1), 0, stream, blocksum, L.nscan, nv);
+  hipLaunchKernelGGL(bg_scan_write, dim3(L.nscan), blk, 0, stream, bitmap, L.nwords, blocksum, wprefix);
+  hipLaunchKernelGGL(bg_assign_kernel, gN, blk, 0, stream, cell, bitmap, wprefix, N, target_u8, target_f64, confidence, pix2v, cnt, wsplat, bsplat);
+  hipLaunchKernelGGL(bg_vertices_kernel, dim3(zh_cdiv(L.nwords, 256)), blk, 0, stream, bitmap, wprefix, L.nwords, vcell);
+  hipLaunchKernelGGL(bg_neighbors_kernel, gV, blk, 0, stream, vcell, bitmap, wprefix, nv, d, nbr);
+  // bistochastise: n = 1; 10x n = sqrt(n*m0/blur(n)); m = n*blur(n)
+  hipLaunchKernelGGL(bg_fill_kernel, gV, blk, 0, stream, nA, 1.0, nv);
+  double *ncur = nA, *nnext = nB;
+  for (int i = 0; i < 10; ++i) {
+    hipLaunchKernelGGL(bg_bisto_step, gV, blk, 0, stream, ncur, cnt, nbr, nv, nnext);
+    double* t = ncur; ncur = nnext; nnext = t;
+  }
+  hipLaunchKernelGGL(bg_bisto_final, gV, blk, 0, stream, ncur, nbr, nv, m);
+  if (n_out) (void)hipMemcpyAsync(n_out, ncur, (size_t)L.Vmax * 8, hipMemcpyDeviceToDevice, stream);   // room for H*W doubles
+  if (m_out) (void)hipMemcpyAsync(m_out, m, (size_t)L.Vmax * 8, hipMemcpyDeviceToDevice, stream);
+  // PCG
+  CgPtrs c;
+  c.n = ncur; c.m = m; c.wsplat = wsplat; c.b = bsplat; c.nbr = nbr; c.nv = nv;
+  c.minv = D[6]; c.x = D[7]; c.r = D[8]; c.z = D[9]; c.p = D[10]; c.q = D[11];
+  c.part_rz = part; c.part_rr = part + (size_t)L.nblocks; c.part_pq = part + 2 * (size_t)L.nblocks; c.sc = sc;
+  c.lam = lam; c.a_diag_min = a_diag_min; c.rtol = cg_tol; c.nblocks = L.nblocks;
+  hipLaunchKernelGGL(cg_y0_kernel, gV, blk, 0, stream, c);
+  hipLaunchKernelGGL(cg_init_kernel, gV, blk, 0, stream, c);
+  hipLaunchKernelGGL(cg_atol_kernel, dim3(1), blk, 0, stream, c);
+  for (int it = 0; it < cg_maxiter; ++it) {
+    hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it);
+    hipLaunchKernelGGL(cg_matvec_kernel, gV, blk, 0, stream, c);
+    hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it);
+  }
+  hipLaunchKernelGGL(bg_slice_kernel, gN, blk, 0, stream, c.x, pix2v, N, out_soft);
+  hipLaunchKernelGGL(cg_finish_kernel, dim3(1), dim3(1), 0, stream, c, cg_maxiter, stats);
+  ZH_CHECK_LAUNCH("zh_bilateral_solve");
+  return ZH_OK;
+}

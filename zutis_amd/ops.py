@@ -198,3 +198,48 @@ def mask_iou_counts(masks_u8, n, pixels, inter, uni):
     need = L.zh_mask_iou_workspace_size(n, pixels)
     ws = torch.empty(need, dtype=torch.uint8, device=masks_u8.device)
     _lib.check(L.zh_mask_iou_counts(_p(masks_u8), n, pixels, _p(inter), _p(uni), _p(ws), need, _stream()), "zh_mask_iou_counts")
+
+
+# ---------------------------------------------------------------------------------------- bilateral solver (float64)
+def denormalize_u8(x, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """utils/utils.py:261-273 on device: x f32 [3,H,W] -> rgb u8 [H,W,3]."""
+    import ctypes as C
+    L = _lib.load()
+    _chk(x, f32, "denormalize x")
+    _, H, W = x.shape
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
+    m = (C.c_float * 3)(*[float(np.float32(v)) for v in mean])
+    s = (C.c_float * 3)(*[float(np.float32(v)) for v in std])
+    _lib.check(L.zh_denormalize_u8(_p(x), _p(out), H, W, m, s, _stream()), "zh_denormalize_u8")
+    return out
+
+
+def bgrid_coords(rgb_u8, sigma_spatial=16, sigma_luma=16, sigma_chroma=8):
+    L = _lib.load()
+    H, W, _ = rgb_u8.shape
+    out = torch.empty((H * W, 5), dtype=torch.int32, device=rgb_u8.device)
+    _lib.check(L.zh_bgrid_coords(_p(rgb_u8), H, W, float(sigma_spatial), float(sigma_luma), float(sigma_chroma), _p(out), _stream()),
+               "zh_bgrid_coords")
+    return out
+
+
+def bilateral_solve(rgb_u8, target, sigma_spatial=16, sigma_luma=16, sigma_chroma=8, confidence=0.999, lam=256.0,
+                    a_diag_min=1e-5, cg_tol=1e-5, cg_maxiter=25, debug=False):
+    """rgb u8 [H,W,3] + target u8|f64 [H,W] (device) -> soft f64 [H,W] (device), stats int32 [2] (device)
+    [, n, m f64 [H*W] when debug]."""
+    L = _lib.load()
+    H, W, _ = rgb_u8.shape
+    _chk(rgb_u8, torch.uint8, "rgb")
+    assert target.shape == (H, W) and target.is_contiguous() and target.dtype in (torch.uint8, torch.float64)
+    need = L.zh_bilateral_workspace_size(H, W, float(sigma_spatial), float(sigma_luma), float(sigma_chroma))
+    ws = torch.empty(need, dtype=torch.uint8, device=rgb_u8.device)
+    out = torch.empty((H, W), dtype=torch.float64, device=rgb_u8.device)
+    stats = torch.zeros((2,), dtype=torch.int32, device=rgb_u8.device)
+    n = torch.zeros((H * W,), dtype=torch.float64, device=rgb_u8.device) if debug else None
+    m = torch.zeros((H * W,), dtype=torch.float64, device=rgb_u8.device) if debug else None
+    t8 = target if target.dtype == torch.uint8 else None
+    t64 = target if target.dtype == torch.float64 else None
+    _lib.check(L.zh_bilateral_solve(_p(rgb_u8), _p(t8), _p(t64), H, W, float(sigma_spatial), float(sigma_luma), float(sigma_chroma),
+                                    float(confidence), float(lam), float(a_diag_min), float(cg_tol), int(cg_maxiter), _p(out),
+                                    _p(stats), _p(n), _p(m), _p(ws), need, _stream()), "zh_bilateral_solve")
+    return (out, stats, n, m) if debug else (out, stats)
