@@ -197,3 +197,66 @@ def test_selfmask_dropin_module(dev, golden_dir):
     assert isinstance(out["dts"], list) and out["dts"][0].dtype == torch.uint8 and out["dts"][0].device.type == "cpu"
     ref = np.unpackbits(g["small_dts"], axis=-1)[..., :W].astype(bool)
     assert (torch.stack(out["dts"]).numpy().astype(bool) != ref).mean() < 5e-3
+
+
+@pytest.mark.parametrize("width,layers,patch,grid,embed,B", [(128, 2, 14, 3, 64, 3), (1024, 2, 14, 24, 768, 2)])
+def test_clip_encode_image_vs_oracle(dev, width, layers, patch, grid, embed, B):
+    """CLIP encode_image (utils/extract_image_embeddings.py:72-73): CLS -> ln_post -> @proj -> L2, fixed pos-embed.
+    Second case = ViT-L/14@336 geometry (D=1024, K=588 padded to 640, T=577) with 2 layers."""
+    from zutis_amd import detgen
+    from zutis_amd.engine import ClipImageEncoder
+    from oracle import zutis_ref as O
+    cfg = detgen.ZutisConfig(width=width, layers=layers, patch=patch, grid=grid, embed_dim=embed)
+    sd = {k: v for k, v in detgen.zutis_state_dict(cfg).items() if k.startswith("encoder.")}
+    x = torch.from_numpy(detgen.images(B, patch * grid, patch * grid, seed=5))
+    with torch.no_grad():
+        ref = O.clip_encode_image(O.to_torch_params(sd), x, patch).numpy()
+    enc = ClipImageEncoder({k.replace("encoder.", "visual."): torch.from_numpy(v).to(dev) for k, v in sd.items()}, patch)
+    got = enc.encode_image(x.to(dev)).cpu().numpy()
+    assert got.shape == (B, embed)
+    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
+    assert np.abs(got - ref).max() < 1e-3
+    with pytest.raises(Exception):
+        enc.encode_image(torch.zeros((1, 3, patch * (grid + 1), patch * grid), device=dev))   # CLIP needs its native grid
+
+
+def test_running_score_dropin(dev, golden_dir):
+    import os, sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    from utils.running_score import RunningScore
+    g = np.load(f"{golden_dir}/ops.npz")
+    rs = RunningScore(7, device=dev)
+    rs.update(g["rs_gt"], g["rs_pred"])                               # numpy in, as trainer.py:347
+    assert np.array_equal(rs.confusion_matrix, g["rs_hist"])
+    sc, _ = rs.get_scores()
+    assert np.allclose([sc["Pixel Acc"], sc["Mean Acc"], sc["FreqW Acc"], sc["Mean IoU"]], g["rs_scores"], rtol=0, atol=1e-12)
+    rs.reset()
+    rs.update(torch.from_numpy(g["rs_gt"]).to(dev), torch.from_numpy(g["rs_pred"]).to(dev))   # device tensors
+    assert np.array_equal(rs.confusion_matrix, g["rs_hist"])
+
+
+def test_c4_geometry_518px_920_classes(dev):
+    """BASELINE config 4 geometry: ViT-B/16 @518 px (conv floor => 32x32 grid, T=1025, M=4096), 920 classes, b=1,
+    against the CPU oracle; plus size-independent properties (unit-norm tokens, sigmoid range, argmax idempotence)."""
+    from zutis_amd import detgen
+    from oracle import zutis_ref as O
+    cfg = detgen.VIT_B16
+    eng = _engine(cfg, dev)
+    x = torch.from_numpy(detgen.images(1, 518, 518, seed=2))
+    text = torch.from_numpy(detgen.text_embeddings(920, cfg.embed_dim))
+    out = eng.forward(x.to(dev))
+    assert out["mask_proposals"].shape == (1, 6, 100, 64, 64) and out["patch_tokens"].shape == (1, 64, 64, 512)
+    pt = out["patch_tokens"]
+    assert (pt.norm(dim=-1) - 1).abs().max().item() < 1e-5
+    assert 0 <= out["mask_proposals"].min().item() and out["mask_proposals"].max().item() <= 1
+    lo = eng.semantic_logits_lowres(pt, text.to(dev))
+    labels = eng.predict_semantic(pt, text.to(dev), (518, 518))
+    assert labels.shape == (1, 518, 518) and int(labels.max()) < 920
+    full = eng.predict_semantic(pt, text.to(dev), (518, 518), return_logits=True)
+    assert torch.equal(full.argmax(dim=1), labels)                    # fused upsample+argmax == argmax of the materialised logits
+    with torch.no_grad():
+        ref = O.zutis_forward(O.to_torch_params(detgen.zutis_state_dict(cfg)), x, cfg.patch, cfg.dec_heads)
+        ref_lo = O.semantic_logits_lowres(ref["patch_tokens"], text).numpy()
+    assert np.abs(lo.cpu().numpy() - ref_lo).max() < LOGIT_TOL

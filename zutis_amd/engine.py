@@ -94,6 +94,41 @@ class _EngineBase:
         w["dec.norm.w"], w["dec.norm.b"] = c32(P["decoder.norm.weight"]), c32(P["decoder.norm.bias"])
         w["query_embed"] = c32(P["query_embed"])
 
+    def _pack_clip_visual(self, w, P, prefix: str, D: int, layers: int, patch: int):
+        """CLIP VisionTransformer parameters (clip_arch.py:335-354) -> conv (K padded to 64), enc.{i}.*, ln_pre/ln_post."""
+        h, c32 = self._h, self._c32
+        kc = 3 * patch * patch
+        self.Kc = _rup(kc, 64)
+        wc = torch.zeros((D, self.Kc), dtype=f16, device=self._device())
+        wc[:, :kc] = P[prefix + "conv1.weight"].detach().reshape(D, kc).to(f16)
+        w["conv"] = wc
+        for name in ("class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias", "ln_post.weight", "ln_post.bias"):
+            w["encoder." + name] = c32(P[prefix + name])
+        for i in range(layers):
+            p, q = f"{prefix}transformer.resblocks.{i}.", f"enc.{i}."
+            w[q + "qkv_w"], w[q + "qkv_b"] = h(P[p + "attn.in_proj_weight"]), c32(P[p + "attn.in_proj_bias"])
+            w[q + "out_w"], w[q + "out_b"] = h(P[p + "attn.out_proj.weight"]), c32(P[p + "attn.out_proj.bias"])
+            w[q + "fc_w"], w[q + "fc_b"] = h(P[p + "mlp.c_fc.weight"]), c32(P[p + "mlp.c_fc.bias"])
+            w[q + "proj_w"], w[q + "proj_b"] = h(P[p + "mlp.c_proj.weight"]), c32(P[p + "mlp.c_proj.bias"])
+            for ln, ln2 in (("ln_1", "ln1"), ("ln_2", "ln2")):
+                w[q + ln2 + ".w"], w[q + ln2 + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
+        w["projT"] = h(P[prefix + "proj"].detach().t())                                # [E, D]
+
+    def _clip_trunk(self, x: torch.Tensor, pos: torch.Tensor, h: int, w: int):
+        """conv1-as-GEMM, cls concat + pos + ln_pre, all resblocks (clip_arch.py:378-401).  Returns X f32 [B*T, D]."""
+        W_, D, p = self._w, self.D, self.patch
+        B = x.shape[0]
+        T, R = 1 + h * w, B * (1 + h * w)
+        col = self._buf("col", (B * h * w, self.Kc), f16)
+        ops.im2col(x, col, p, self.Kc)                                                   # :378 conv1 as GEMM
+        pe32 = self._buf("patch_emb", (B * h * w, D), f32)
+        ops.gemm(col, W_["conv"], pe32)
+        X = self._buf("X", (R, D), f32)
+        ops.assemble_tokens_ln(pe32, W_["encoder.class_embedding"], pos, W_["encoder.ln_pre.weight"],
+                               W_["encoder.ln_pre.bias"], 1e-5, X, B, T, D)                # :384-397
+        self._vit_blocks(X, B, T, D, self.heads, self.layers, 1e-5, ops.ACT_QUICKGELU)     # :318-321
+        return X
+
     def _vit_blocks(self, X, B, T, D, heads, n_layers, eps, act):
         """Pre-LN transformer blocks on the fp32 residual stream X [B*T, D] (in place).
         clip_arch.py:318-321 (QuickGELU, eps 1e-5) and selfmask/vision_transformer.py:160-170 (erf GELU, eps 1e-6)."""
@@ -193,27 +228,11 @@ class ZutisEngine(_EngineBase):
         P, D, w = self.params, self.D, {}
         dev = self._device()
         h, c32 = self._h, self._c32
-        kc = 3 * self.patch * self.patch
-        self.Kc = _rup(kc, 64)
-        wc = torch.zeros((D, self.Kc), dtype=f16, device=dev)
-        wc[:, :kc] = P["encoder.conv1.weight"].detach().reshape(D, kc).to(f16)
-        w["conv"] = wc
-        for name in ("encoder.class_embedding", "encoder.positional_embedding", "encoder.ln_pre.weight", "encoder.ln_pre.bias",
-                     "encoder.ln_post.weight", "encoder.ln_post.bias"):
-            w[name] = c32(P[name])
-        for i in range(self.layers):
-            p, q = f"encoder.transformer.resblocks.{i}.", f"enc.{i}."
-            w[q + "qkv_w"], w[q + "qkv_b"] = h(P[p + "attn.in_proj_weight"]), c32(P[p + "attn.in_proj_bias"])
-            w[q + "out_w"], w[q + "out_b"] = h(P[p + "attn.out_proj.weight"]), c32(P[p + "attn.out_proj.bias"])
-            w[q + "fc_w"], w[q + "fc_b"] = h(P[p + "mlp.c_fc.weight"]), c32(P[p + "mlp.c_fc.bias"])
-            w[q + "proj_w"], w[q + "proj_b"] = h(P[p + "mlp.c_proj.weight"]), c32(P[p + "mlp.c_proj.bias"])
-            for ln, ln2 in (("ln_1", "ln1"), ("ln_2", "ln2")):
-                w[q + ln2 + ".w"], w[q + ln2 + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
+        self._pack_clip_visual(w, P, "encoder.", D, self.layers, self.patch)
         for ffn in ("ffn1", "ffn2"):
             for j in range(3):
                 w[f"{ffn}.{j}.w"], w[f"{ffn}.{j}.b"] = h(P[f"{ffn}.layers.{j}.weight"]), c32(P[f"{ffn}.layers.{j}.bias"])
         self._pack_decoder(w, P, D, self.dec_layers)
-        w["projT"] = h(P["encoder.proj"].detach().t())                                 # [E, D]
         self._w, self._packed_key = w, key
         self._geo.clear()
 
@@ -243,16 +262,8 @@ class ZutisEngine(_EngineBase):
         W_, D, p = self._w, self.D, self.patch
         B, _, H, Wd = x.shape
         h, w = (H - p) // p + 1, (Wd - p) // p + 1
-        T, R = 1 + h * w, B * (1 + h * w)
-        geo = self._geometry(h, w)
-        col = self._buf("col", (B * h * w, self.Kc), f16)
-        ops.im2col(x, col, p, self.Kc)                                                   # :378 conv1 as GEMM
-        pe32 = self._buf("patch_emb", (B * h * w, D), f32)
-        ops.gemm(col, W_["conv"], pe32)
-        X = self._buf("X", (R, D), f32)
-        ops.assemble_tokens_ln(pe32, W_["encoder.class_embedding"], geo["pos"], W_["encoder.ln_pre.weight"],
-                               W_["encoder.ln_pre.bias"], 1e-5, X, B, T, D)                # :384-397
-        self._vit_blocks(X, B, T, D, self.heads, self.layers, 1e-5, ops.ACT_QUICKGELU)     # :318-321
+        T = 1 + h * w
+        X = self._clip_trunk(x, self._geometry(h, w)["pos"], h, w)
         tok = self._buf("tok", (B, h * w, D), f32)
         ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B * h * w, D, out_f32=tok,
                       in_group_rows=h * w, in_group_stride=T, in_offset=1)                 # :403-404
@@ -361,6 +372,50 @@ class ZutisEngine(_EngineBase):
         uni = torch.empty((n, n), dtype=torch.int32, device=masks_u8.device)
         ops.mask_iou_counts(masks_u8.contiguous(), n, px, inter, uni)
         return inter.cpu().numpy() / (uni.cpu().numpy() + 1e-7)
+
+
+class ClipImageEncoder(_EngineBase):
+    """CLIP `encode_image` for the index-dataset pipeline (utils/extract_image_embeddings.py:72-73; third-party `clip`,
+    restated from the original forward kept in clip_arch.py:413-431,531-532): fixed positional embedding, CLS token ->
+    ln_post -> @proj, then L2 normalisation.  `params` uses the CLIP visual state_dict keys under `prefix`."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int, prefix: str = "visual."):
+        self.params, self.patch, self.prefix = params, patch, prefix
+        self.D = params[prefix + "class_embedding"].shape[0]
+        self.heads = self.D // 64
+        self.layers = 1 + max(int(k[len(prefix):].split(".")[2]) for k in params if k.startswith(prefix + "transformer.resblocks."))
+        self.E = params[prefix + "proj"].shape[1]
+        self.grid = int(math.isqrt(params[prefix + "positional_embedding"].shape[0] - 1))
+        self._init_base()
+
+    def _pack(self):
+        key = self._version_key()
+        if key == self._packed_key:
+            return
+        w = {}
+        self._pack_clip_visual(w, self.params, self.prefix, self.D, self.layers, self.patch)
+        self._w, self._packed_key = w, key
+
+    def encode_image(self, x: torch.Tensor) -> torch.Tensor:
+        """x f32 [B,3,R,R] at the model's native resolution -> unit-norm embeddings f32 [B,E]."""
+        self._pack()
+        if not (x.is_cuda and x.dtype == f32 and x.dim() == 4 and x.shape[1] == 3):
+            raise ZutisHipError("encode_image: expected float32 CUDA tensor [B,3,H,W]")
+        p, g = self.patch, self.grid
+        B, _, H, Wd = x.shape
+        h, w = (H - p) // p + 1, (Wd - p) // p + 1
+        if (h, w) != (g, g):
+            raise ZutisHipError(f"encode_image: input {H}x{Wd} gives a {h}x{w} grid; CLIP's fixed pos-embed needs {g}x{g}")
+        W_, D = self._w, self.D
+        X = self._clip_trunk(x.contiguous(), W_["encoder.positional_embedding"], h, w)
+        cls16 = self._buf("cls16", (B, D), f16)
+        ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B, D, out_f16=cls16,
+                      in_group_rows=1, in_group_stride=1 + h * w, in_offset=0)              # ln_post(x[:, 0, :])
+        e32 = self._buf("emb32", (B, self.E), f32)
+        ops.gemm(cls16, W_["projT"], e32)                                                   # @ proj
+        out = torch.empty((B, self.E), dtype=f32, device=x.device)
+        ops.l2norm_rows(e32, B, self.E, out_f32=out)                                        # / norm(dim=-1)
+        return out
 
 
 class SelfMaskEngine(_EngineBase):
