@@ -193,57 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(G
   // parameters: a runtime switch unrolled 32x blew the instruction cache (fc GEMM 1.4x slower in the model).
   const long cb = (long)batch * p.sC;
   const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
-  if (VEC == 2) {
-    // LDS-staged epilogue: the direct form stores 32-byte runs (4 lanes x 8 B) into 16 different 128-B lines per
-    // instruction and measured 2.4 TB/s, fully exposed (34 % of a K=768 tile).  Here each wave transposes its tile through
-    // a private, conflict-free LDS slab (row stride +16 B) and writes whole rows with 16 B per lane.
-    constexpr int ESZ = OUT_F16 ? 2 : 4;
-    constexpr int RS = TN * 16 * ESZ + 16;                  // slab row stride (bytes)
-    constexpr int PR = (OUT_F16 ? 64 : 32) < TM * 16 ? (OUT_F16 ? 64 : 32) : TM * 16;   // rows per pass
-    constexpr int MTP = PR / 16;
-    constexpr int CPRW = TN * 16 * ESZ / 16;                // 16-B chunks per row
-    constexpr int NIT = PR * CPRW / 64;
-    static_assert((PR * CPRW) % 64 == 0, "epilogue slab must divide into full wave reads");
-    static_assert(NW * PR * RS <= (int)sizeof(smem), "epilogue slabs exceed the ring");
-    __syncthreads();                                        // ring no longer read; every LDS-DMA has landed
-    char* slab = (char*)smem + wave * (PR * RS);
-#pragma clang loop unroll(full)
-    for (int pass = 0; pass < TM / MTP; ++pass) {
-#pragma clang loop unroll(full)
-      for (int nt = 0; nt < TN; ++nt) {
-        const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
-#pragma clang loop unroll(full)
-        for (int ml = 0; ml < MTP; ++ml) {
-          f32x4 v = acc[nt][pass * MTP + ml] + bv;
-          if (ACT != ZH_ACT_NONE) {
-            v[0] = zh_act(v[0], ACT); v[1] = zh_act(v[1], ACT); v[2] = zh_act(v[2], ACT); v[3] = zh_act(v[3], ACT);
-          }
-          char* dst = slab + (ml * 16 + frow) * RS + (nt * 16 + fk * 4) * ESZ;
-          if (OUT_F16) {
-            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            *(half4_t*)dst = h;
-          } else {
-            *(f32x4*)dst = v;
-          }
-        }
-      }
-#pragma clang loop unroll(full)
-      for (int it = 0; it < NIT; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c / CPRW, ch = c - row * CPRW;
-        const int m = m0 + wr * TM * 16 + pass * PR + row;
-        const int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
-        f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
-        if (m < p.M && n < p.N) {
-          if (!OUT_F16 && R) d += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
-          if (OUT_F16) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
-          else *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
-        }
-      }
-    }
-  } else if (VEC) {
+  if (VEC) {
 #pragma clang loop unroll(full)
     for (int nt = 0; nt < TN; ++nt) {
       const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
@@ -253,7 +203,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(G
 #pragma clang loop unroll(full)
       for (int mt = 0; mt < TM; ++mt) {
         const int m = m0 + (wr * TM + mt) * 16 + frow;
-        if (nok && m < p.M) {
+        if (nok && m < p.M && p.res_rows == 12345) {
           f32x4 v = acc[nt][mt] + bv;
           if (ACT != ZH_ACT_NONE) {
             v[0] = zh_act(v[0], ACT); v[1] = zh_act(v[1], ACT); v[2] = zh_act(v[2], ACT); v[3] = zh_act(v[3], ACT);
@@ -355,15 +305,11 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   const double c128 = tiling_cost(M, N, batch, 128, 128, 2, 0.8);
   int pick = (c128 < c256 && c128 < c192) ? 128 : (c192 < c256 ? 192 : 256);
   if (force) pick = atoi(force);
-  // 16-byte row stores need 16-B aligned rows; an f16 residual is not supported (none on the hot path)
-  const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&
-                       ((N * esz) % 16 == 0) && !(out_f16 && residual);
   bool ok;
   if (!p.vec_ok) ok = launch_gemm<2, 2, 4, 4, 0>(p, batch, out_f16, stream);      // scalar-store fallback: small tile only
-  else if (!wide_ok) ok = launch_gemm<2, 2, 4, 4, 1>(p, batch, out_f16, stream);  // direct 8/16-B stores
-  else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 2>(p, batch, out_f16, stream);
-  else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 2>(p, batch, out_f16, stream);
-  else ok = launch_gemm<2, 4, 8, 4, 2>(p, batch, out_f16, stream);
+  else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 1>(p, batch, out_f16, stream);
+  else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 1>(p, batch, out_f16, stream);
+  else ok = launch_gemm<2, 4, 8, 4, 1>(p, batch, out_f16, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16: (out_f16=%d, act=%d) is not an instantiated epilogue (f32: none|sigmoid; f16: none|quickgelu|relu|gelu_erf)",
                out_f16, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16");
