@@ -125,7 +125,9 @@ def test_dropin_module_matches_reference_golden(dev, golden_dir):
         from zutis_amd import rle
         for j, p in enumerate(preds):
             assert p["image_id"] == g[f"inst_{key}_img"][j] and p["category_id"] == g[f"inst_{key}_cat"][j]
-            assert abs(p["score"] - g[f"inst_{key}_score"][j]) < 2e-3
+            # score = mean(p inside p>0.5) * class prob: one low-res pixel crossing 0.5 (fp16-MFMA noise ~3e-4) moves it by
+            # ~1/mask_size; the kernel itself is checked to 1e-6 on identical inputs in test_instance_kernels_vs_oracle_exact_inputs
+            assert abs(p["score"] - g[f"inst_{key}_score"][j]) < 2e-2
             m = rle.decode(p["segmentation"]).astype(bool)
             assert (m != ref_masks[j]).mean() < 1e-2          # masks come from fp16-MFMA proposals thresholded at 0.5
             assert np.abs(np.array(p["bbox"]) - g[f"inst_{key}_bbox"][j]).max() <= 1.0

@@ -71,6 +71,25 @@ def test_gemm_inplace_residual_and_batched(dev):
     assert torch.allclose(out.cpu(), torch.einsum("mk,bnk->bmn", A[0].float(), W2.float()), atol=1e-3, rtol=1e-4)
 
 
+def test_gemm_race_screen_bitwise_repeatable(dev):
+    """The K loop is an LDS-DMA ring retired by counted vmcnt + raw barriers: a mis-counted wait shows up as RARE wrong
+    tiles.  Screen every tile shape (256x256, 256x192, 128x128, 128x64) over many launches: results must be bitwise
+    identical run to run and match the fp32 reference."""
+    from zutis_amd import ops
+    for (M, N, K) in [(2048, 2304, 768), (1500, 768, 3072), (700, 640, 192), (300, 200, 64), (3200, 768, 128)]:
+        A, W = _randn((M, K), 100 + M).to(f16).to(dev), _randn((N, K), 200 + N).to(f16).to(dev)
+        ref = (A.float() @ W.float().t())
+        first = None
+        for it in range(40):
+            out = torch.empty((M, N), dtype=f32, device=dev)
+            ops.gemm(A, W, out)
+            if first is None:
+                first = out.clone()
+                assert torch.allclose(first, ref, atol=2e-3 * math.sqrt(K / 64), rtol=1e-3)
+            else:
+                assert torch.equal(out, first), f"non-repeatable GEMM result at launch {it} for {(M, N, K)}"
+
+
 def test_gemm_rejects_bad_k(dev):
     from zutis_amd import ops, _lib
     A, W = torch.zeros((8, 40), dtype=f16, device=dev), torch.zeros((8, 40), dtype=f16, device=dev)

@@ -58,10 +58,12 @@ __device__ __forceinline__ float wave_max(float v) {
 #define ZH_ACT_GELU_ERF 4    // nn.GELU, networks/selfmask/vision_transformer.py:79
 
 __device__ __forceinline__ float zh_act(float x, int act) {
+  // v_exp_f32 / v_rcp_f32 (1 ulp) instead of IEEE expf + division: the epilogue of the 14144x3072 c_fc GEMM spends
+  // 43 M activations per call; results differ from the libm form by < 2e-7 relative (tests: 2e-4 abs on O(1) values).
   switch (act) {
-    case ZH_ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));
+    case ZH_ACT_QUICKGELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     case ZH_ACT_RELU: return fmaxf(x, 0.0f);
-    case ZH_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+    case ZH_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
     case ZH_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     default: return x;
   }
