@@ -126,22 +126,23 @@ __global__ __launch_bounds__(256, 2) void attn_f16_kernel(AttnArgs p) {
     }
     // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
     float mx = -INFINITY;
-    const bool tail = kbase + KT > p.Tk;
+    if (kbase + KT > p.Tk) {                    // last tile only: keys beyond Tk score -inf
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + 32 * u + 16 * (r >> 3) + 8 * hh + (r & 7);
+          if (key >= p.Tk) s[u][r] = -INFINITY;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[u][r] * p.scale_log2;
-        if (tail) {
-          const int key = kbase + 32 * u + 16 * (r >> 3) + 8 * hh + (r & 7);
-          v = key < p.Tk ? v : -INFINITY;
-        }
-        s[u][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    // running max kept in log2 units (scale_log2 > 0 commutes with max): p = 2^(s*c - m) is ONE fma + v_exp_f32
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
     half8_t pf[2][2];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16_kernel(AttnArgs p) {
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(s[u][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
         psum += e;
         pf[u][r >> 3][r & 7] = (half_t)e;
       }
