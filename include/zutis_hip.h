@@ -117,6 +117,11 @@ int zh_upsample_argmax(const float* logits_lo, long long* labels, int B, int n, 
 int zh_upsample_bilinear_nchw(const float* x, float* out, unsigned char* mask_u8, float threshold, long planes,
                               int h, int w, int H, int W, float scale_h, float scale_w, zh_stream_t stream);
 
+/* F.interpolate(mask[None,None], size=(H,W), mode="nearest") on a u8 mask: datasets/index_dataset.py:215
+ * (restore the original resolution of a pseudo-mask).  scale_* = float32(in)/float32(out). */
+int zh_resize_nearest_u8(const unsigned char* x, unsigned char* out, int h, int w, int H, int W, float scale_h, float scale_w,
+                         zh_stream_t stream);
+
 /* RunningScore._fast_hist: utils/running_score.py:11-16.  hist_accum int64 [n*n] += bincount(n*gt+pred), 0<=gt<n. */
 int zh_confusion_hist(const long long* label_true, const long long* label_pred, long long* hist_accum, long total,
                       int n_class, zh_stream_t stream);

@@ -77,3 +77,33 @@ def test_solver_vs_oracle_selfmask_size(dev):
     assert np.abs(soft.cpu().numpy() - ref_soft).max() < 1e-9
     soft64, _ = ops.bilateral_solve(torch.from_numpy(rgb).to(dev), torch.from_numpy(target.astype(np.float64)).to(dev))
     assert np.abs(soft64.cpu().numpy() - ref_soft).max() < 1e-9
+
+
+def test_resize_nearest_bit_exact(dev):
+    from zutis_amd import ops, detgen
+    import torch.nn.functional as F
+    m = (detgen.det_normal("nearest", (61, 83)) > 0).astype(np.uint8)
+    for (H, W) in [(427, 640), (61, 83), (30, 200), (512, 683)]:
+        got = ops.resize_nearest_u8(torch.from_numpy(m).to(dev), H, W).cpu().numpy()
+        ref = F.interpolate(torch.from_numpy(m)[None, None], size=(H, W), mode="nearest")[0, 0].numpy()
+        assert np.array_equal(got, ref)
+
+
+def test_pseudo_mask_driver_end_to_end(dev, tmp_path):
+    """SelfMask -> device bilateral solver -> nearest resize -> RLE JSON, against the oracle chain on the same inputs."""
+    from zutis_amd import detgen, pseudo_masks, rle
+    from zutis_amd.engine import SelfMaskEngine
+    from oracle import selfmask_ref as S, bilateral_ref as B, zutis_ref as O
+    import json
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()})
+    x = torch.from_numpy(detgen.images(1, 72, 100, seed=11))[0]
+    p = str(tmp_path / "m" / "a.json")
+    pseudo_masks.generate_pseudo_masks(eng, [x.to(dev)], [(144, 200)], [p])
+    got = rle.decode(json.load(open(p))).astype(bool)
+    assert got.shape == (144, 200)
+    with torch.no_grad():
+        dts, _, _ = S.selfmask_inference(O.to_torch_params(detgen.selfmask_state_dict()), x[None])
+    soft, _ = B.bilateral_solver_output(B.denormalize_to_u8(x.numpy()), dts[0])
+    ref = (soft > 0.5)
+    ref = ref[(np.arange(144) * np.float32(72 / 144)).astype(int)][:, (np.arange(200) * np.float32(100 / 200)).astype(int)]
+    assert (got != ref).mean() < 1e-2          # the SelfMask mask itself comes from fp16-MFMA logits

@@ -275,3 +275,23 @@ extern "C" int zh_upsample_bilinear_nchw(const float* x, float* out, unsigned ch
   ZH_CHECK_LAUNCH("zh_upsample_bilinear_nchw");
   return ZH_OK;
 }
+
+// ---- nearest-neighbour resize of a u8 mask (F.interpolate(mode="nearest"), datasets/index_dataset.py:215):
+//      src = min(floor(dst * scale), in - 1), scale = float(in) / float(out) (ATen nearest_neighbor_compute_source_index)
+__global__ __launch_bounds__(256) void resize_nearest_u8_kernel(const unsigned char* x, unsigned char* out, int h, int w, int H, int W,
+                                                                float scale_h, float scale_w) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)H * W) return;
+  const int oy = (int)(idx / W), ox = (int)(idx - (long)oy * W);
+  const int sy = min((int)floorf(__fmul_rn((float)oy, scale_h)), h - 1);
+  const int sx = min((int)floorf(__fmul_rn((float)ox, scale_w)), w - 1);
+  out[idx] = x[(long)sy * w + sx];
+}
+
+extern "C" int zh_resize_nearest_u8(const unsigned char* x, unsigned char* out, int h, int w, int H, int W, float scale_h, float scale_w,
+                                    hipStream_t stream) {
+  ZH_CHECK_ARG(x && out && h > 0 && w > 0 && H > 0 && W > 0, "zh_resize_nearest_u8: bad arguments");
+  hipLaunchKernelGGL(resize_nearest_u8_kernel, dim3(zh_cdiv((long)H * W, 256)), dim3(256), 0, stream, x, out, h, w, H, W, scale_h, scale_w);
+  ZH_CHECK_LAUNCH("zh_resize_nearest_u8");
+  return ZH_OK;
+}

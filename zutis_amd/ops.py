@@ -243,3 +243,13 @@ def bilateral_solve(rgb_u8, target, sigma_spatial=16, sigma_luma=16, sigma_chrom
                                     float(confidence), float(lam), float(a_diag_min), float(cg_tol), int(cg_maxiter), _p(out),
                                     _p(stats), _p(n), _p(m), _p(ws), need, _stream()), "zh_bilateral_solve")
     return (out, stats, n, m) if debug else (out, stats)
+
+
+def resize_nearest_u8(x_u8, H, W):
+    """F.interpolate(x[None,None], size=(H,W), mode="nearest")[0,0] for a u8 [h,w] mask on the GPU."""
+    L = _lib.load()
+    _chk(x_u8, torch.uint8, "resize_nearest x")
+    h, w = x_u8.shape
+    out = torch.empty((H, W), dtype=torch.uint8, device=x_u8.device)
+    _lib.check(L.zh_resize_nearest_u8(_p(x_u8), _p(out), h, w, H, W, lin_scale(h, H), lin_scale(w, W), _stream()), "zh_resize_nearest_u8")
+    return out
