@@ -32,21 +32,19 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 #define KT 64
 #define VS 96
 
-template <int DH, int NWAVE>
-__global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
-  constexpr int NT = 64 * NWAVE;
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_f16_kernel(AttnArgs p) {
   constexpr int KS = DH + 8;          // K row stride (halves)
   constexpr int NKS = DH / 16;        // k-steps of QK^T
   constexpr int NDT = DH / 32;        // 32-row d tiles of O^T
   constexpr int CPR = DH / 8;         // 16-byte chunks per K/V row
-  constexpr int NLD = (KT * CPR) / NT;
-  static_assert((KT * CPR) % NT == 0, "tile chunks must divide over the block");
-  __shared__ __attribute__((aligned(16))) half_t sKb[2][KT * KS];   // double-buffered: one barrier per key tile
-  __shared__ __attribute__((aligned(16))) half_t sVb[2][KT * VS];
+  constexpr int NLD = (KT * CPR) / 256;
+  __shared__ __attribute__((aligned(16))) half_t sK[KT * KS];
+  __shared__ __attribute__((aligned(16))) half_t sV[KT * VS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.y, img = blockIdx.z;
-  const int q0 = blockIdx.x * (32 * NWAVE) + wave * 32;
+  const int q0 = blockIdx.x * 128 + wave * 32;
   const int ql = lane & 31, hh = lane >> 5;
   const long hoff = (long)head * DH;
 
@@ -76,7 +74,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   auto load_tile = [&](int kbase) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int c = tid + i * NT;
+      const int c = tid + i * 256;
       const int row = c / CPR, cc = c - row * CPR;
       const int key = kbase + row;
       if (key < p.Tk) {
@@ -88,13 +86,13 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
       }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int c = tid + i * NT;
+      const int c = tid + i * 256;
       const int row = c / CPR, cc = c - row * CPR;
-      *(half8_t*)(sKb[buf] + row * KS + cc * 8) = kreg[i];
-      *(half8_t*)(sVb[buf] + row * VS + cc * 8) = vreg[i];
+      *(half8_t*)(sK + row * KS + cc * 8) = kreg[i];
+      *(half8_t*)(sV + row * VS + cc * 8) = vreg[i];
     }
   };
 
@@ -106,13 +104,11 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
 
   const int ntiles = (p.Tk + KT - 1) / KT;
   load_tile(0);
-  store_tile(0);
+  store_tile();
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int kbase = t * KT;
-    const half_t* sK = sKb[t & 1];
-    const half_t* sV = sVb[t & 1];
     if (t + 1 < ntiles) load_tile(kbase + KT);
 
     // ---- S^T = K Q^T  (two 32-key slot tiles)
@@ -183,8 +179,8 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
         }
       }
 
-    // buffer (t+1)&1 was last read in iteration t-1; every wave passed the barrier that ended t-1 => free to overwrite
-    if (t + 1 < ntiles) store_tile((t + 1) & 1);
+    __syncthreads();
+    if (t + 1 < ntiles) store_tile();
     __syncthreads();
   }
 
@@ -224,11 +220,9 @@ extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const voi
   p.O = (half_t*)O; p.ldo = ldo; p.sO = strideO;
   p.Tq = Tq; p.Tk = Tk; p.H = heads;
   p.scale_log2 = scale * 1.4426950408889634f;
-  // 128-query (4-wave) blocks: each K/V tile is shared four ways.  A 64-query (2-wave) variant was measured slower on
-  // every shape of the model (encoder 301 vs 423 TF, cross-attention 230 vs 397 TF) and was dropped.
   dim3 grid(zh_cdiv(Tq, 128), heads, batch);
-  if (head_dim == 64) hipLaunchKernelGGL((attn_f16_kernel<64, 4>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((attn_f16_kernel<96, 4>), grid, dim3(256), 0, stream, p);
+  if (head_dim == 64) hipLaunchKernelGGL(attn_f16_kernel<64>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(attn_f16_kernel<96>, grid, dim3(256), 0, stream, p);
   ZH_CHECK_LAUNCH("zh_attention_f16");
   return ZH_OK;
 }
