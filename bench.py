@@ -131,8 +131,14 @@ def main():
         stats = {k: (len(v), sum(w for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
         nl, fl, tt = stats["gemm_f16"]
         ach = fl / tt / 1e12
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")     # separate rocprofv3 --pmc passes of this command
+        if os.path.exists(pmc) and B == 32 and S == 336:
+            traffic = json.load(open(pmc))["gemm_f16_kernel_all_variants"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction)"
         roof = {"bound": "mfma", "kernel": "gemm_f16_kernel", "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src, "flops_per_launch": round(fl / nl),
                 "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
                 "gemm_share_of_step": round(tt / (elapsed / args.steps), 3)}
         if "attention_f16" in stats:
