@@ -163,6 +163,10 @@ int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8,
                        double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
                        double* n_out, double* m_out, void* workspace, size_t workspace_bytes, zh_stream_t stream);
 
+/* HOST helper (no GPU): COCO RLE string of one u8 [H,W] mask = pycocotools.mask.encode(np.asfortranarray(m))["counts"]
+ * (zutis.py:290,448; datasets/index_dataset.py:219).  Returns the length, -1 if cap is too small. */
+long zh_rle_encode_host(const unsigned char* mask, int H, int W, char* out, long cap);
+
 #ifdef __cplusplus
 }
 #endif

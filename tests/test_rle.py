@@ -31,3 +31,13 @@ def test_mask_to_box():
     m = np.zeros((10, 12), bool)
     m[2:5, 3:9] = True
     assert rle.mask_to_box(m) == [3.0, 2.0, 8.0, 4.0]
+
+
+def test_c_helper_matches_python_restatement():
+    for seed, shape in enumerate([(7, 5), (80, 112), (1, 1), (33, 64), (336, 336)]):
+        m = detgen.det_normal("rlec", shape, seed=seed) > 0.8
+        assert rle.encode(m)["counts"] == rle.encode_py(m)["counts"]
+    for m in (np.zeros((4, 6), bool), np.ones((4, 6), bool)):
+        assert rle.encode(m)["counts"] == rle.encode_py(m)["counts"]
+    big = np.zeros((300, 300), bool); big[5:290, 7] = True; big[0:3, 200] = True
+    assert rle.encode(big)["counts"] == rle.encode_py(big)["counts"]

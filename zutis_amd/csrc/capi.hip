@@ -14,3 +14,38 @@ void zh_set_error(const char* fmt, ...) {
 extern "C" const char* zh_last_error(void) { return g_err; }
 extern "C" int zh_version(void) { return 100; }
 extern "C" const char* zh_arch(void) { return "gfx950"; }
+
+// ---- host-side COCO RLE (pycocotools maskApi.c rleEncode + rleToString restated): the reference encodes every kept
+//      instance mask with pycocotools.mask.encode(np.asfortranarray(m)) (networks/zutis.py:290,448).  HOST pointers.
+//      mask u8 [H,W] row-major; runs are taken in column-major order starting with the zeros run.  Returns the string
+//      length, or -1 if `cap` is too small.
+extern "C" long zh_rle_encode_host(const unsigned char* mask, int H, int W, char* out, long cap) {
+  long n = 0;
+  long cnts_prev2 = 0, cnts_prev1 = 0;     // counts[i-2], counts[i-1]
+  long idx = 0;
+  auto emit = [&](long c) -> bool {
+    long x = c;
+    if (idx > 2) x -= cnts_prev2;
+    bool more = true;
+    while (more) {
+      long ch = x & 0x1f;
+      x >>= 5;
+      more = (ch & 0x10) ? x != -1 : x != 0;
+      if (more) ch |= 0x20;
+      if (n >= cap) return false;
+      out[n++] = (char)(ch + 48);
+    }
+    cnts_prev2 = cnts_prev1; cnts_prev1 = c; ++idx;
+    return true;
+  };
+  unsigned char cur = 0;
+  long run = 0;
+  for (int x = 0; x < W; ++x)
+    for (int y = 0; y < H; ++y) {
+      const unsigned char v = mask[(long)y * W + x] != 0;
+      if (v != cur) { if (!emit(run)) return -1; run = 0; cur = v; }
+      ++run;
+    }
+  if (!emit(run)) return -1;
+  return n;
+}
