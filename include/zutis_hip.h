@@ -163,6 +163,11 @@ int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8,
                        double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
                        double* n_out, double* m_out, void* workspace, size_t workspace_bytes, zh_stream_t stream);
 
+/* Retrieval (datasets/index_dataset.py:163-167): per row of scores [rows, N] (row stride ld) the k largest entries, score
+ * descending, ties by ascending index — replaces torch.argsort(descending=True)[:n_images] per category.
+ * idx_out int64 [rows,k]; val_out f32 [rows,k] or NULL.  k <= 1024. */
+int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, long long* idx_out, float* val_out, zh_stream_t stream);
+
 /* HOST helper (no GPU): COCO RLE string of one u8 [H,W] mask = pycocotools.mask.encode(np.asfortranarray(m))["counts"]
  * (zutis.py:290,448; datasets/index_dataset.py:219).  Returns the length, -1 if cap is too small. */
 long zh_rle_encode_host(const unsigned char* mask, int H, int W, char* out, long cap);

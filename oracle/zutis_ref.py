@@ -304,3 +304,11 @@ def scores_from_hist(hist: np.ndarray):
         freq = hist.sum(axis=1) / hist.sum()
         fwavacc = (freq[freq > 0] * iu[freq > 0]).sum()
     return {"Pixel Acc": acc, "Mean Acc": acc_cls, "FreqW Acc": fwavacc, "Mean IoU": mean_iu}, dict(enumerate(iu))
+
+
+def retrieve_topk(text: np.ndarray, image: np.ndarray, k: int):
+    """datasets/index_dataset.py:163-167: similarities = text @ image.T; per category argsort(descending)[:k].
+    Tie order is unspecified in the reference (torch.argsort is not stable); the restatement fixes it to ascending index."""
+    sim = text.astype(np.float32) @ image.astype(np.float32).T
+    idx = np.stack([np.lexsort((np.arange(sim.shape[1]), -row))[:k] for row in sim])
+    return idx, np.take_along_axis(sim, idx, axis=1)

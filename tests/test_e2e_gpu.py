@@ -262,3 +262,18 @@ def test_c4_geometry_518px_920_classes(dev):
         ref = O.zutis_forward(O.to_torch_params(detgen.zutis_state_dict(cfg)), x, cfg.patch, cfg.dec_heads)
         ref_lo = O.semantic_logits_lowres(ref["patch_tokens"], text).numpy()
     assert np.abs(lo.cpu().numpy() - ref_lo).max() < LOGIT_TOL
+
+
+def test_forward_graphed_matches_eager(dev):
+    """hipGraph replay (batch-1 latency path) returns exactly what the eager launch sequence returns, across replays and
+    for a second input shape."""
+    from zutis_amd import detgen
+    cfg = detgen.TINY
+    eng = _engine(cfg, dev)
+    for (H, W) in [(80, 112), (64, 96)]:
+        for seed in (0, 1, 2):
+            x = torch.from_numpy(detgen.images(1, H, W, seed=seed)).to(dev)
+            a = eng.forward(x)
+            a = {k: v.clone() for k, v in a.items()}
+            b = eng.forward_graphed(x)
+            assert torch.equal(a["mask_proposals"], b["mask_proposals"]) and torch.equal(a["patch_tokens"], b["patch_tokens"])

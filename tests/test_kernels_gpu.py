@@ -260,3 +260,42 @@ def test_confusion_hist(dev, golden_dir):
     ops.confusion_hist(torch.from_numpy(gt).to(dev), torch.from_numpy(pr).to(dev), hist, 920)
     m = (gt >= 0) & (gt < 920)
     assert np.array_equal(hist.cpu().numpy(), np.bincount(920 * gt[m] + pr[m], minlength=920 * 920))
+
+
+def test_topk_rows_exact(dev):
+    """Integer output: the k largest per row, score descending / index ascending, incl. heavy ties, negatives, k == N."""
+    from zutis_amd import ops
+    rng = np.random.default_rng(0)
+    for (R, N, k) in [(5, 1000, 500), (3, 70000, 500), (4, 513, 513), (2, 2000, 1), (3, 5000, 1000)]:
+        x = rng.standard_normal((R, N)).astype(np.float32)
+        x[0, : N // 2] = 0.25                                   # massive exact ties
+        x[-1] = -np.abs(x[-1])                                  # all negative
+        x[1 % R, 7] = np.inf
+        idx, val = ops.topk_rows(torch.from_numpy(x).to(dev), k, with_values=True)
+        ref = np.stack([np.lexsort((np.arange(N), -row))[:k] for row in x])
+        assert np.array_equal(idx.cpu().numpy(), ref)
+        assert np.array_equal(val.cpu().numpy(), np.take_along_axis(x, ref, 1))
+    # padded leading dimension: only the first N columns count
+    x = rng.standard_normal((2, 104)).astype(np.float32); x[:, 100:] = 1e9
+    idx = ops.topk_rows(torch.from_numpy(x).to(dev), 10, N=100)
+    assert np.array_equal(idx.cpu().numpy(), np.stack([np.lexsort((np.arange(100), -r[:100]))[:10] for r in x]))
+
+
+def test_retrieval_vs_oracle(dev):
+    """text @ image.T + top-k (datasets/index_dataset.py:163-167), chunked path included."""
+    from zutis_amd import retrieval, detgen
+    from oracle import zutis_ref as O
+    C, N, E, k = 9, 3001, 128, 50
+    t = detgen.text_embeddings(C, E)
+    im = detgen.det_normal("imgemb", (N, E)); im /= np.linalg.norm(im, axis=1, keepdims=True)
+    ref_idx, ref_val = O.retrieve_topk(t.astype(np.float16), im.astype(np.float16), k)     # same fp16-rounded operands
+    for chunk in (1 << 20, 1024):
+        idx, val = retrieval.retrieve_topk(torch.from_numpy(t).to(dev), torch.from_numpy(im).to(dev), k, chunk=chunk)
+        assert np.abs(val.cpu().numpy() - ref_val).max() < 1e-5
+        # identical operands, fp32 accumulation in a different order: allow swaps only between near-equal scores
+        got = idx.cpu().numpy()
+        for c in range(C):
+            diff = got[c] != ref_idx[c]
+            if diff.any():
+                assert np.abs(val.cpu().numpy()[c][diff] - ref_val[c][diff]).max() < 1e-5
+            assert len(set(got[c].tolist()) ^ set(ref_idx[c].tolist())) <= 2

@@ -22,6 +22,8 @@ def timeit(fn, n=10):
 te = timeit(lambda: eng.encode(x))
 tf = timeit(lambda: eng.forward(x))
 tp = timeit(lambda: eng.predict_semantic(out["patch_tokens"], text, (336, 336)))
+tg = timeit(lambda: eng.forward_graphed(x)) if B <= 8 else float("nan")
+print(f"B={B} graphed forward {tg:.2f} ms")
 print(f"B={B} encode {te:.2f} ms  forward {tf:.2f} ms  predict {tp:.2f} ms  -> {B / (tf + tp) * 1e3:.1f} img/s")
 flops = B * 124.4e9
 print(f"forward ~{flops / tf / 1e9:.1f} TFLOP/s")

@@ -190,6 +190,7 @@ class ZUTIS(nn.Module):
         self.clip_arch: str = clip_arch
         self.encoder_type: str = encoder_type
         self._engine: Optional[ZutisEngine] = None
+        self.use_hip_graph: bool = False       # opt-in: forward() of batches <= 4 replays a hipGraph captured per input shape
 
     # ------------------------------------------------------------------ plumbing
     def _get_engine(self) -> ZutisEngine:
@@ -220,7 +221,10 @@ class ZUTIS(nn.Module):
             raise NotImplementedError(
                 "ZUTIS on MI355X is inference-only (the training loop is out of scope): wrap the call in "
                 "torch.no_grad() or call .requires_grad_(False) as trainer.evaluate / coco20k_eval.py do")
-        return self._get_engine().forward(x.float())
+        eng = self._get_engine()
+        if self.use_hip_graph and x.shape[0] <= 4:       # host-bound regime: replay a captured hipGraph per input shape
+            return eng.forward_graphed(x.float().contiguous())
+        return eng.forward(x.float())
 
     # ------------------------------------------------------------------ predict
     @torch.no_grad()

@@ -253,3 +253,15 @@ def resize_nearest_u8(x_u8, H, W):
     out = torch.empty((H, W), dtype=torch.uint8, device=x_u8.device)
     _lib.check(L.zh_resize_nearest_u8(_p(x_u8), _p(out), h, w, H, W, lin_scale(h, H), lin_scale(w, W), _stream()), "zh_resize_nearest_u8")
     return out
+
+
+def topk_rows(scores, k, N=None, with_values=False):
+    """scores f32 [R, ld] on the GPU -> int64 [R,k] indices of the k largest of the first N columns (score desc, index asc)."""
+    L = _lib.load()
+    _chk(scores, f32, "topk scores")
+    R, ld = scores.shape
+    N = ld if N is None else N
+    idx = torch.empty((R, k), dtype=torch.int64, device=scores.device)
+    val = torch.empty((R, k), dtype=f32, device=scores.device) if with_values else None
+    _lib.check(L.zh_topk_rows(_p(scores), ld, R, N, k, _p(idx), _p(val), _stream()), "zh_topk_rows")
+    return (idx, val) if with_values else idx

@@ -101,5 +101,6 @@ def decode(rle: Dict) -> np.ndarray:
 
 def mask_to_box(mask: np.ndarray) -> List[float]:
     """torchvision.ops.masks_to_boxes for one mask: [xmin, ymin, xmax, ymax] of the non-zero pixels (float32 values)."""
-    ys, xs = np.nonzero(mask)
-    return [float(np.float32(xs.min())), float(np.float32(ys.min())), float(np.float32(xs.max())), float(np.float32(ys.max()))]
+    rows = np.flatnonzero(mask.any(axis=1))
+    cols = np.flatnonzero(mask.any(axis=0))
+    return [float(cols[0]), float(rows[0]), float(cols[-1]), float(rows[-1])]
