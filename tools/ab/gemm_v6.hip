@@ -354,8 +354,8 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   const double c192 = tiling_cost(M, N, batch, 256, 192, 1, 0.95);
   const double c128 = tiling_cost(M, N, batch, 128, 128, 2, 0.8);
   int pick = (c128 < c256 && c128 < c192) ? 128 : (c192 < c256 ? 192 : 256);
-  // small problems (decoder: M = B*Q rows): fewer than one 128x128 tile per CU -> halve the tile so every CU gets work
-  if (pick == 128 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch < 256) pick = 64;
+  // (a 128x64 tile for the decoder's M = B*Q GEMMs measured no better than 128x128: they are slice-latency bound;
+  //  it stays reachable through ZH_GEMM_TILE=64 for experiments)
   if (force) pick = atoi(force);
   // 16-byte row stores need 16-B aligned rows; an f16 residual is not supported (none on the hot path)
   const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&

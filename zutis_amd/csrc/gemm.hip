@@ -43,21 +43,25 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_barrier() {
-  static_assert(N == 0 || N == 4 || N == 8, "unsupported vmcnt");
-  if (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  static_assert(N == 0 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 10, "unsupported vmcnt");
+  if (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  else if (N == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
   else if (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+  else if (N == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // WM x WN waves; each wave owns TM x TN subtiles of 16x16.  Block tile = (WM*TM*16) x (WN*TN*16).
 template <int WM, int WN, int TM, int TN, int OUT_F16, int ACT, int VEC>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM * TN) >= 96 ? 2 : 1)) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int ROWS = BM + BN;             // LDS rows per stage (A rows then W rows), 64 B each
   constexpr int PIECES = ROWS / 16;         // 1-KiB DMA pieces per stage
-  constexpr int NP = 4;                     // DMA issues per wave per stage (duplicates pad uneven splits)
-  static_assert((PIECES + NW - 1) / NW <= NP, "tile needs more than 4 pieces per wave");
+  constexpr int NP = (PIECES + NW - 1) / NW;  // DMA issues per wave per stage (duplicates pad uneven splits)
+  static_assert(NP >= 3 && NP <= 5, "unsupported pieces-per-wave count");
   constexpr int STAGE_HALVES = ROWS * BK;
   __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE_HALVES];
 
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(G
   // LDS fragment read or one LDS-DMA issue of the NEXT slices; the wave's stream stays MFMA-paced instead of
   // front-loading 16 memory instructions behind the barrier.
   auto steady = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
-    wait_vmcnt_barrier<4>();
+    wait_vmcnt_barrier<NP>();
     issue_stage((kt + STAGES - 1) % STAGES);
     load_frags(kt + 1, na, nw);
     mfma_all(fa, fw);
@@ -168,15 +172,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16_kernel(G
   };
   auto tail = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
     if (kt + 1 < nk) {
-      if (kt + 2 < nk) wait_vmcnt_barrier<4>();     // stages issued after kt+1 so far: kt+2 only
+      if (kt + 2 < nk) wait_vmcnt_barrier<NP>();    // stages issued after kt+1 so far: kt+2 only
       else wait_vmcnt_barrier<0>();
       if (kt + STAGES - 1 < nk) issue_stage((kt + STAGES - 1) % STAGES);
       load_frags(kt + 1, na, nw);
     }
     mfma_all(fa, fw);
   };
-  if (nk >= 3) wait_vmcnt_barrier<8>();       // stage 0 landed; stages 1 and 2 may still be in flight
-  else if (nk == 2) wait_vmcnt_barrier<4>();
+  if (nk >= 3) wait_vmcnt_barrier<2 * NP>();  // stage 0 landed; stages 1 and 2 may still be in flight
+  else if (nk == 2) wait_vmcnt_barrier<NP>();
   else wait_vmcnt_barrier<0>();
   load_frags(0, fa0, fw0);
   int kt = 0;
@@ -366,6 +370,7 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   else if (pick == 64) ok = launch_gemm<2, 2, 4, 2, 2>(p, batch, out_f16, stream);   // 128 x 64
   else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 2>(p, batch, out_f16, stream);
   else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 2>(p, batch, out_f16, stream);
+  else if (pick == 1192) ok = launch_gemm<2, 2, 4, 6, 2>(p, batch, out_f16, stream);   // 128 x 192, 4 waves, 2 blocks/CU: experiment only (ZH_GEMM_TILE), measured 10-20 % slower than 256 x 192 on the N=768 GEMMs
   else ok = launch_gemm<2, 4, 8, 4, 2>(p, batch, out_f16, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16: (out_f16=%d, act=%d) is not an instantiated epilogue (f32: none|sigmoid; f16: none|quickgelu|relu|gelu_erf)",
                out_f16, act);
