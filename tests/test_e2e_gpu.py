@@ -277,3 +277,25 @@ def test_forward_graphed_matches_eager(dev):
             a = {k: v.clone() for k, v in a.items()}
             b = eng.forward_graphed(x)
             assert torch.equal(a["mask_proposals"], b["mask_proposals"]) and torch.equal(a["patch_tokens"], b["patch_tokens"])
+
+
+def test_batch_invariance_full_size(dev):
+    """Size-independent property at the BASELINE geometry (ViT-B/16 @336): images are independent, so image i's outputs
+    are BITWISE the same whether it is evaluated alone or inside a batch (every reduction runs over K / keys / one image
+    in a fixed order) — this is what makes rank-sharded evaluation reproduce the single-GPU result exactly."""
+    from zutis_amd import detgen
+    cfg = detgen.VIT_B16
+    eng = _engine(cfg, dev)
+    x = torch.from_numpy(detgen.images(3, 336, 336, seed=4)).to(dev)
+    text = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim)).to(dev)
+    full = eng.forward(x)
+    full = {k: v.clone() for k, v in full.items()}
+    lab_full = eng.predict_semantic(full["patch_tokens"], text, (336, 336)).clone()
+    for i in (0, 2):
+        one = eng.forward(x[i:i + 1].contiguous())
+        assert torch.equal(one["mask_proposals"][0], full["mask_proposals"][i])
+        assert torch.equal(one["patch_tokens"][0], full["patch_tokens"][i])
+        assert torch.equal(eng.predict_semantic(one["patch_tokens"], text, (336, 336))[0], lab_full[i])
+    pt = full["patch_tokens"]
+    assert (pt.norm(dim=-1) - 1).abs().max().item() < 1e-5
+    assert 0 <= full["mask_proposals"].min().item() and full["mask_proposals"].max().item() <= 1

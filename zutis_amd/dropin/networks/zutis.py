@@ -213,7 +213,8 @@ class ZUTIS(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward_transformer_encoder(self, x: torch.Tensor):
-        return self._get_engine().encode(x.float())
+        tok, h, w = self._get_engine().encode(x.float())
+        return tok.clone(), h, w            # the engine's buffer is reused by the next call: hand out a copy
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         """x: b x 3 x h x w  ->  {"mask_proposals": b x L x Q x 2h' x 2w' (sigmoid), "patch_tokens": b x 2h' x 2w' x dim}"""

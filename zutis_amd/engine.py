@@ -52,6 +52,13 @@ class _EngineBase:
             raise ZutisHipError("engine parameters must live on a GPU (no CPU fallback)")
         return dev
 
+    _GEO_CAP = 64     # per-(h,w) tables (pos-embed, sine PE, graphs): native-resolution eval sees many shapes; keep the newest
+
+    def _geo_put(self, key, value):
+        if len(self._geo) >= self._GEO_CAP:
+            self._geo.pop(next(iter(self._geo)))
+        self._geo[key] = value
+
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
         k = (name, tuple(shape), dtype)
         b = self._bufs.get(k)
@@ -249,7 +256,7 @@ class ZutisEngine(_EngineBase):
             pe = torch.empty((4 * h * w, D), dtype=f32, device=dev)
             ops.sine_pe(pe, 2 * h, 2 * w, D)
             g = {"pos": pos, "pe": pe}
-            self._geo[(h, w)] = g
+            self._geo_put((h, w), g)
         return g
 
     # ------------------------------------------------------------------ encoder
@@ -327,7 +334,7 @@ class ZutisEngine(_EngineBase):
             with torch.cuda.graph(graph):
                 out = self.forward(static_x)
             g = {"x": static_x, "graph": graph, "out": out}
-            self._geo[key] = g
+            self._geo_put(key, g)
         g["x"].copy_(x)
         g["graph"].replay()
         return {k: v.clone() for k, v in g["out"].items()}
@@ -502,7 +509,7 @@ class SelfMaskEngine(_EngineBase):
                 ops.posembed_bicubic(self._w["pos"], pos, self.grid, h, w, self.D, np.float32(self.grid) / np.float32(h),
                                      np.float32(self.grid) / np.float32(w), True)
             g = {"pos": pos}
-            self._geo[(h, w)] = g
+            self._geo_put((h, w), g)
         return g["pos"]
 
     def forward(self, x: torch.Tensor, inference: bool = False):
