@@ -168,6 +168,16 @@ int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8,
  * idx_out int64 [rows,k]; val_out f32 [rows,k] or NULL.  k <= 1024. */
 int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, long long* idx_out, float* val_out, zh_stream_t stream);
 
+/* Device-side run extraction for COCO RLE + boxes + areas of selected masks (masks u8 [n,H,W] row-major; sel int32
+ * [n_sel] mask indices): positions int32 [n_sel, max_runs] = column-major pixel indices where the value changes;
+ * nruns int32 [n_sel,2] = {#transitions, value of pixel 0}; box_area int32 [n_sel,5] = {xmin,ymin,xmax,ymax,area}.
+ * Replaces the mask D2H in front of pycocotools.mask.encode / masks_to_boxes, zutis.py:288-294,446-452. */
+int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, int W, int max_runs,
+                 int* positions, int* nruns, int* box_area, zh_stream_t stream);
+
+/* HOST helper: RLE string from run lengths (pycocotools rleToString). */
+long zh_rle_counts_to_string_host(const long long* counts, long n, char* out, long cap);
+
 /* HOST helper (no GPU): COCO RLE string of one u8 [H,W] mask = pycocotools.mask.encode(np.asfortranarray(m))["counts"]
  * (zutis.py:290,448; datasets/index_dataset.py:219).  Returns the length, -1 if cap is too small. */
 long zh_rle_encode_host(const unsigned char* mask, int H, int W, char* out, long cap);

@@ -299,3 +299,24 @@ def test_retrieval_vs_oracle(dev):
             if diff.any():
                 assert np.abs(val.cpu().numpy()[c][diff] - ref_val[c][diff]).max() < 1e-5
             assert len(set(got[c].tolist()) ^ set(ref_idx[c].tolist())) <= 2
+
+
+def test_mask_runs_device_rle_matches_host_encoder(dev):
+    """Device run extraction + box + area == host RLE encoder / numpy box for random, empty, full and striped masks."""
+    from zutis_amd import ops, rle
+    from zutis_amd.engine import ZutisEngine
+    rng = np.random.default_rng(1)
+    H, W = 77, 145
+    masks = (rng.random((7, H, W)) > 0.6).astype(np.uint8)
+    masks[1] = 0; masks[2] = 1; masks[3] = 0; masks[3][10:30, 64:66] = 1; masks[4] = 0; masks[4][0, 0] = 1; masks[5][:, ::2] = 1
+    dm = torch.from_numpy(masks).to(dev)
+    sel = np.array([6, 0, 1, 2, 3, 4, 5], np.int32)
+    rles, boxes, areas = ZutisEngine.encode_masks(None, dm, sel, max_runs=20000)
+    for j, q in enumerate(sel):
+        m = masks[q]
+        assert areas[j] == int(m.sum())
+        assert rles[j] == rle.encode(m)
+        if m.any():
+            assert boxes[j] == rle.mask_to_box(m)
+    rles2, _, _ = ZutisEngine.encode_masks(None, dm, np.array([0], np.int32), max_runs=16)     # overflow -> host fallback
+    assert rles2[0] == rle.encode(masks[0])

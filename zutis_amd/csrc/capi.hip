@@ -49,3 +49,22 @@ extern "C" long zh_rle_encode_host(const unsigned char* mask, int H, int W, char
   if (!emit(run)) return -1;
   return n;
 }
+
+// HOST: RLE string from run lengths (pycocotools rleToString): counts int64 [n] -> chars; returns length or -1.
+extern "C" long zh_rle_counts_to_string_host(const long long* counts, long n, char* out, long cap) {
+  long len = 0;
+  for (long i = 0; i < n; ++i) {
+    long x = (long)counts[i];
+    if (i > 2) x -= (long)counts[i - 2];
+    bool more = true;
+    while (more) {
+      long ch = x & 0x1f;
+      x >>= 5;
+      more = (ch & 0x10) ? x != -1 : x != 0;
+      if (more) ch |= 0x20;
+      if (len >= cap) return -1;
+      out[len++] = (char)(ch + 48);
+    }
+  }
+  return len;
+}

@@ -197,3 +197,86 @@ extern "C" int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels
   ZH_CHECK_LAUNCH("zh_mask_iou_counts");
   return ZH_OK;
 }
+
+// ---- run-length transitions + box + area of selected masks ON THE DEVICE (replaces the B x Q x H x W mask D2H in front of
+//      pycocotools.mask.encode / masks_to_boxes, networks/zutis.py:288-294,446-452).  COCO RLE runs are column-major:
+//      a block owns one mask, walks it in 64-column panels staged through LDS (coalesced row reads), counts the value
+//      changes per column, prefix-sums them, and writes the column-major pixel positions where the value changes.
+//      counts = diff([0, positions..., H*W]) with a leading 0-run inserted when pixel 0 is set (host, tiny).
+#define RUNS_PANEL 64
+__global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* masks, const int* sel, int H, int W, int max_runs,
+                                                        int* positions, int* nruns, int* box_area) {
+  extern __shared__ unsigned char sm[];                    // [H][RUNS_PANEL] panel, then int colcnt[RUNS_PANEL + 1]
+  __shared__ int s_base, s_first, s_minx, s_maxx, s_miny, s_maxy, s_area;
+  const unsigned char* m = masks + (long)sel[blockIdx.x] * H * W;
+  int* pos = positions + (long)blockIdx.x * max_runs;
+  int* colcnt = (int*)(sm + (((long)H * RUNS_PANEL + 15) & ~15L));
+  if (threadIdx.x == 0) { s_base = 0; s_first = m[0] != 0; s_minx = W; s_maxx = -1; s_miny = H; s_maxy = -1; s_area = 0; }
+  __syncthreads();
+  for (int x0 = 0; x0 < W; x0 += RUNS_PANEL) {
+    const int pw = min(RUNS_PANEL, W - x0);
+    for (int i = threadIdx.x; i < H * RUNS_PANEL; i += 256) {
+      const int y = i / RUNS_PANEL, c = i - y * RUNS_PANEL;
+      sm[i] = c < pw ? (m[(long)y * W + x0 + c] != 0) : 0;
+    }
+    __syncthreads();
+    // pass 1: transitions per column (a column's first pixel is compared with the previous column's last pixel)
+    if (threadIdx.x < RUNS_PANEL) {
+      const int c = threadIdx.x;
+      int cnt = 0;
+      if (c < pw) {
+        unsigned char prev = c > 0 ? sm[(H - 1) * RUNS_PANEL + c - 1] : (x0 > 0 ? (m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0]);
+        int area = 0, ymin = H, ymax = -1;
+        for (int y = 0; y < H; ++y) {
+          const unsigned char v = sm[y * RUNS_PANEL + c];
+          cnt += v != prev;
+          prev = v;
+          if (v) { ++area; ymin = min(ymin, y); ymax = y; }
+        }
+        if (area) {
+          atomicAdd(&s_area, area); atomicMin(&s_minx, x0 + c); atomicMax(&s_maxx, x0 + c);
+          atomicMin(&s_miny, ymin); atomicMax(&s_maxy, ymax);
+        }
+      }
+      colcnt[c] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                               // exclusive scan of <= 64 counts
+      int acc = s_base;
+      for (int c = 0; c < RUNS_PANEL; ++c) { const int t = colcnt[c]; colcnt[c] = acc; acc += t; }
+      s_base = acc;
+    }
+    __syncthreads();
+    // pass 2: write positions
+    if (threadIdx.x < pw) {
+      const int c = threadIdx.x;
+      unsigned char prev = c > 0 ? sm[(H - 1) * RUNS_PANEL + c - 1] : (x0 > 0 ? (m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0]);
+      int o = colcnt[c];
+      for (int y = 0; y < H; ++y) {
+        const unsigned char v = sm[y * RUNS_PANEL + c];
+        if (v != prev) { if (o < max_runs) pos[o] = (x0 + c) * H + y; ++o; }
+        prev = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    nruns[blockIdx.x * 2] = s_base;                        // number of transitions (may exceed max_runs => host fallback)
+    nruns[blockIdx.x * 2 + 1] = s_first;                   // value of pixel 0
+    int* b = box_area + blockIdx.x * 5;
+    b[0] = s_minx; b[1] = s_miny; b[2] = s_maxx; b[3] = s_maxy; b[4] = s_area;
+  }
+}
+
+extern "C" int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, int W, int max_runs,
+                            int* positions, int* nruns, int* box_area, hipStream_t stream) {
+  ZH_CHECK_ARG(masks && sel && positions && nruns && box_area && n_sel > 0 && H > 0 && W > 0 && max_runs > 0, "zh_mask_runs: bad arguments");
+  const size_t lds = (((size_t)H * RUNS_PANEL + 15) & ~(size_t)15) + (RUNS_PANEL + 1) * sizeof(int);
+  ZH_CHECK_ARG(lds <= 160 * 1024 - 64, "zh_mask_runs: H=%d too tall for the LDS panel", H);
+  ZH_CHECK_ARG((long)H * W < (1L << 31), "zh_mask_runs: mask too large");
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)mask_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(mask_runs_kernel, dim3(n_sel), dim3(256), lds, stream, masks, sel, H, W, max_runs, positions, nruns, box_area);
+  ZH_CHECK_LAUNCH("zh_mask_runs");
+  return ZH_OK;
+}

@@ -258,33 +258,42 @@ class ZUTIS(nn.Module):
         size = None if size is None else (int(size[0]), int(size[1]))
         masks_dev, scores, category_ids = eng.instance_candidates(
             mask_proposals, dict_outputs["patch_tokens"], self.text_embeddings, threshold, temperature, size)
-        binary_masks: np.ndarray = masks_dev.cpu().numpy().astype(bool)
+        B, Q, Hm, Wm = masks_dev.shape
         confidence_scores: np.ndarray = scores.cpu().numpy()
         category_ids: np.ndarray = category_ids.cpu().numpy()
         if image_ids is None:
-            image_ids = [0 for _ in range(len(binary_masks))]
+            image_ids = [0 for _ in range(B)]
 
-        predictions: List[dict] = list()
-        for bi, (m_img, s_img, c_img, image_id) in enumerate(zip(binary_masks, confidence_scores, category_ids, image_ids)):
+        # The reference pulls all B x Q x H x W boolean masks to the host, then loops (zutis.py:423-469).  Here the masks
+        # stay on the GPU: IoU counts + areas come from the popcount kernel, the greedy NMS (control flow only) runs on
+        # the host over Q x Q numbers, and only the KEPT masks' run boundaries and boxes are copied back.
+        kept = []                                       # (batch index, category, query, score)
+        for bi in range(B):
+            s_img, c_img = confidence_scores[bi], category_ids[bi]
             if nms_type is None:
-                keep = [(int(c), q, s) for q, (s, c) in enumerate(zip(s_img, c_img)) if c != 0 and m_img[q].any()]
+                kept += [(bi, int(c), q, float(s)) for q, (s, c) in enumerate(zip(s_img, c_img)) if c != 0]
             else:
-                iou = eng.mask_iou_matrix(masks_dev[bi]) if nms_type is not None else None
-                keep = self.non_maximum_suppression_indices(m_img, s_img, c_img, nms_type=nms_type, iou=iou)
-            for c, q, s in keep:
-                m = m_img[q]
-                label_id = new_label_id_to_old_label_id[c] if new_label_id_to_old_label_id is not None else c
-                prediction = {
-                    "category_id": label_id,
-                    "segmentation": (_coco_encode(np.asfortranarray(m)) if _coco_encode is not None else _rle.encode(m)),
-                    "score": float(s),
-                    "image_id": image_id,
-                    "image_size": m_img[0].shape[-2:],
-                    "bbox": _rle.mask_to_box(m),
-                }
-                if label_id_to_category is not None:
-                    prediction["pred_class"] = label_id_to_category[label_id]
-                predictions.append(prediction)
+                iou, areas = eng.mask_iou_matrix(masks_dev[bi], return_areas=True)
+                kept += [(bi, c, q, s) for c, q, s in
+                         self.non_maximum_suppression_indices(areas > 0, s_img, c_img, nms_type=nms_type, iou=iou)]
+        sel = np.array([bi * Q + q for bi, _, q, _ in kept], dtype=np.int32)
+        rles, boxes, areas = eng.encode_masks(masks_dev.view(B * Q, Hm, Wm), sel)
+        predictions: List[dict] = list()
+        for (bi, c, q, s), r, box, area in zip(kept, rles, boxes, areas):
+            if area == 0:                               # `if m.sum() == 0: continue` (zutis.py:281,439)
+                continue
+            label_id = new_label_id_to_old_label_id[c] if new_label_id_to_old_label_id is not None else c
+            prediction = {
+                "category_id": label_id,
+                "segmentation": r,                      # same dict as pycocotools.mask.encode(np.asfortranarray(m))
+                "score": float(s),
+                "image_id": image_ids[bi],
+                "image_size": (Hm, Wm),
+                "bbox": box,
+            }
+            if label_id_to_category is not None:
+                prediction["pred_class"] = label_id_to_category[label_id]
+            predictions.append(prediction)
         return predictions
 
     @staticmethod
@@ -323,6 +332,6 @@ class ZUTIS(nn.Module):
                         ns.append(s)
                 cand, cs = nc, np.array(ns)
             for m, s in selected:
-                if binary_masks[m].any():
+                if np.any(binary_masks[m]):             # binary_masks: [Q,H,W] masks or a [Q] "mask is non-empty" vector
                     out.append((c, int(m), s.item() if hasattr(s, "item") else float(s)))
         return out

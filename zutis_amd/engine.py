@@ -395,15 +395,40 @@ class ZutisEngine(_EngineBase):
             masks = binary
         return masks, score, cat
 
-    def mask_iou_matrix(self, masks_u8: torch.Tensor) -> np.ndarray:
+    def mask_iou_matrix(self, masks_u8: torch.Tensor, return_areas: bool = False):
         """Pairwise IoU of one image's [Q,H,W] u8 masks: exact popcounts on device, float64 divide on the host
-        (= utils/iou.py:30-32 on boolean masks)."""
+        (= utils/iou.py:30-32 on boolean masks).  The diagonal of the intersection counts is each mask's area."""
         n = masks_u8.shape[0]
         px = masks_u8[0].numel()
         inter = torch.empty((n, n), dtype=torch.int32, device=masks_u8.device)
         uni = torch.empty((n, n), dtype=torch.int32, device=masks_u8.device)
         ops.mask_iou_counts(masks_u8.contiguous(), n, px, inter, uni)
-        return inter.cpu().numpy() / (uni.cpu().numpy() + 1e-7)
+        ih = inter.cpu().numpy()
+        iou = ih / (uni.cpu().numpy() + 1e-7)
+        return (iou, np.diag(ih).copy()) if return_areas else iou
+
+    def encode_masks(self, masks_u8: torch.Tensor, sel: np.ndarray, max_runs: int = 8192):
+        """COCO RLE dicts, xyxy boxes and areas of the masks `sel` (flat indices into [n,H,W]) without moving the masks
+        to the host: zh_mask_runs extracts the column-major run boundaries on the device; only those cross PCIe."""
+        from . import rle
+        n, H, W = masks_u8.shape
+        if len(sel) == 0:
+            return [], [], []
+        sel_dev = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32)).to(masks_u8.device)
+        pos, nr, ba = ops.mask_runs(masks_u8.contiguous(), sel_dev, max_runs)
+        nr_h, ba_h = nr.cpu().numpy(), ba.cpu().numpy()
+        keep = int(min(max_runs, max(1, nr_h[:, 0].max())))
+        pos_h = pos[:, :keep].cpu().numpy()
+        rles, boxes, areas = [], [], []
+        for j, q in enumerate(sel):
+            cnt, first = int(nr_h[j, 0]), int(nr_h[j, 1])
+            if cnt > max_runs:                                   # pathological mask: fall back to the host encoder
+                rles.append(rle.encode(masks_u8[int(q)].cpu().numpy()))
+            else:
+                rles.append(rle.rle_from_transitions(pos_h[j, :cnt], first, H, W))
+            boxes.append([float(v) for v in ba_h[j, :4]])
+            areas.append(int(ba_h[j, 4]))
+        return rles, boxes, areas
 
 
 class ClipImageEncoder(_EngineBase):

@@ -265,3 +265,17 @@ def topk_rows(scores, k, N=None, with_values=False):
     val = torch.empty((R, k), dtype=f32, device=scores.device) if with_values else None
     _lib.check(L.zh_topk_rows(_p(scores), ld, R, N, k, _p(idx), _p(val), _stream()), "zh_topk_rows")
     return (idx, val) if with_values else idx
+
+
+def mask_runs(masks_u8, sel, max_runs=8192):
+    """masks u8 [n,H,W] (device), sel int32 [m] (device) -> (positions int32 [m,max_runs], nruns int32 [m,2], box_area int32 [m,5])."""
+    L = _lib.load()
+    _chk(masks_u8, torch.uint8, "mask_runs masks")
+    _chk(sel, torch.int32, "mask_runs sel")
+    n, H, W = masks_u8.shape
+    m = sel.numel()
+    pos = torch.empty((m, max_runs), dtype=torch.int32, device=masks_u8.device)
+    nr = torch.empty((m, 2), dtype=torch.int32, device=masks_u8.device)
+    ba = torch.empty((m, 5), dtype=torch.int32, device=masks_u8.device)
+    _lib.check(L.zh_mask_runs(_p(masks_u8), _p(sel), m, H, W, max_runs, _p(pos), _p(nr), _p(ba), _stream()), "zh_mask_runs")
+    return pos, nr, ba

@@ -104,3 +104,20 @@ def mask_to_box(mask: np.ndarray) -> List[float]:
     rows = np.flatnonzero(mask.any(axis=1))
     cols = np.flatnonzero(mask.any(axis=0))
     return [float(cols[0]), float(rows[0]), float(cols[-1]), float(rows[-1])]
+
+
+def rle_from_transitions(positions: np.ndarray, first_value: int, h: int, w: int) -> Dict:
+    """COCO RLE dict from the column-major transition positions produced by zh_mask_runs (device):
+    counts = diff([0, positions..., h*w]) with a leading empty zero-run when pixel 0 is set."""
+    import ctypes as C
+    from . import _lib
+    edges = np.concatenate(([0], positions.astype(np.int64), [h * w]))
+    counts = np.diff(edges)
+    if first_value:
+        counts = np.concatenate(([0], counts))
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    cap = 8 * counts.size + 16
+    buf = C.create_string_buffer(cap)
+    n = _lib.load().zh_rle_counts_to_string_host(counts.ctypes.data, counts.size, C.addressof(buf), cap)
+    assert n >= 0
+    return {"size": [int(h), int(w)], "counts": buf.raw[:n]}
