@@ -26,7 +26,7 @@
 #include "common.h"
 
 #define BK 32
-#define STAGES 4
+#define STAGES 5
 #define GROUP_M 8
 
 struct GemmArgs {
@@ -43,8 +43,11 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_barrier() {
-  static_assert(N == 0 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 10, "unsupported vmcnt");
-  if (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+  static_assert(N == 0 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 9 || N == 10 || N == 12 || N == 15, "unsupported vmcnt");
+  if (N == 15) asm volatile("s_waitcnt vmcnt(15)\n\ts_barrier" ::: "memory");
+  else if (N == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+  else if (N == 9) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+  else if (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
   else if (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
   else if (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
   else if (N == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   // LDS fragment read or one LDS-DMA issue of the NEXT slices; the wave's stream stays MFMA-paced instead of
   // front-loading 16 memory instructions behind the barrier.
   auto steady = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
-    wait_vmcnt_barrier<NP>();
+    wait_vmcnt_barrier<2 * NP>();
     issue_stage((kt + STAGES - 1) % STAGES);
     load_frags(kt + 1, na, nw);
     mfma_all(fa, fw);
@@ -172,19 +175,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   };
   auto tail = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
     if (kt + 1 < nk) {
-      if (kt + 2 < nk) wait_vmcnt_barrier<NP>();    // stages issued after kt+1 so far: kt+2 only
+      if (kt + 3 < nk) wait_vmcnt_barrier<2 * NP>();      // stages issued after kt+1 so far: kt+2, kt+3
+      else if (kt + 2 < nk) wait_vmcnt_barrier<NP>();
       else wait_vmcnt_barrier<0>();
       if (kt + STAGES - 1 < nk) issue_stage((kt + STAGES - 1) % STAGES);
       load_frags(kt + 1, na, nw);
     }
     mfma_all(fa, fw);
   };
-  if (nk >= 3) wait_vmcnt_barrier<2 * NP>();  // stage 0 landed; stages 1 and 2 may still be in flight
+  if (nk >= 4) wait_vmcnt_barrier<3 * NP>();  // stage 0 landed; stages 1..3 may still be in flight
+  else if (nk == 3) wait_vmcnt_barrier<2 * NP>();
   else if (nk == 2) wait_vmcnt_barrier<NP>();
   else wait_vmcnt_barrier<0>();
   load_frags(0, fa0, fw0);
   int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {
+  for (; kt + STAGES < nk; kt += 2) {
     steady(kt, fa0, fw0, fa1, fw1);
     steady(kt + 1, fa1, fw1, fa0, fw0);
   }

@@ -24,6 +24,7 @@
 //  * Block ids: XCD-aware bijective remap, then 8-row super-tiles so one XCD's concurrent tiles share panels in
 //    its 4 MiB L2 (measured L2 hit rate 82 %).
 #include "common.h"
+#include <type_traits>
 
 #define BK 32
 #define STAGES 4
@@ -132,65 +133,66 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const half_t* rdA = smem + (wr * TM * 16) * BK + foff;
   const half_t* rdW = smem + (BM + wc * TN * 16) * BK + foff;
 
-  // Register double-buffered fragments: while the MFMAs of slice kt run, the ds_read_b128 of slice kt+1 are in
-  // flight (the LDS latency at the head of every slice was exposed on all 8 waves at once behind the barrier).
-  // Slice kt+1 must therefore have landed one iteration earlier: counted waits are vmcnt(4) in the steady state.
-  half8_t fa0[TM], fw0[TN], fa1[TM], fw1[TN];
-  auto load_frags = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN]) {
-    const int so = (kt % STAGES) * STAGE_HALVES;
-#pragma unroll
-    for (int t = 0; t < TM; ++t) fa[t] = *(const half8_t*)(rdA + so + t * 16 * BK);
-#pragma unroll
-    for (int t = 0; t < TN; ++t) fw[t] = *(const half8_t*)(rdW + so + t * 16 * BK);
+  // Fragment schedule.  The A-side fragment fa[mt] is dead after its TN MFMAs, so the next slice's fa[mt] is read IN PLACE
+  // right behind them; only the W-side fragments (live across the whole slice) are double-buffered.  Every LDS read and
+  // LDS-DMA issue of the next slices sits in the shadow of MFMAs of the current one; the order is pinned with
+  // sched_barrier(0) (hipcc otherwise sinks all 12 reads to the end of the phase under register pressure, which exposed
+  // the LDS latency at the head of every slice: SQ_WAIT_ANY 30 %, MFMA pipe 51 % busy).
+  half8_t fa[TM], fw0[TN], fw1[TN];
+  auto rd_a = [&](int kt, int t) { return *(const half8_t*)(rdA + (kt % STAGES) * STAGE_HALVES + t * 16 * BK); };
+  auto rd_w = [&](int kt, int t) { return *(const half8_t*)(rdW + (kt % STAGES) * STAGE_HALVES + t * 16 * BK); };
+  auto issue_piece = [&](int slot, int i) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(smem + slot * STAGE_HALVES + lds_piece[i]), 16, 0, 0);
+    gp[i] += BK;
   };
-  auto mfma_all = [&](half8_t (&fa)[TM], half8_t (&fw)[TN]) {
+  // one slice: MFMAs of slice kt from (fa, fw); meanwhile fa <- slice kt+1 in place, nw <- W fragments of slice kt+1,
+  // and the DMA of slice kt+STAGES-1.  PREFETCH / ISSUE are compile-time so the steady phase is branch-free.
+  auto phase = [&](int kt, half8_t (&fw)[TN], half8_t (&nw)[TN], auto prefetch, auto issue) {
+    constexpr bool PREFETCH = decltype(prefetch)::value, ISSUE = decltype(issue)::value;
+    const int slot = (kt + STAGES - 1) % STAGES;
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt)
+    for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
-      for (int mt = 0; mt < TM; ++mt)
+      for (int nt = 0; nt < TN; ++nt)
         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
-  };
-  // steady-state phase (kt + 3 < nk): branch-free so the scheduler can interleave — every group of MFMAs shadows one
-  // LDS fragment read or one LDS-DMA issue of the NEXT slices; the wave's stream stays MFMA-paced instead of
-  // front-loading 16 memory instructions behind the barrier.
-  auto steady = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
-    wait_vmcnt_barrier<NP>();
-    issue_stage((kt + STAGES - 1) % STAGES);
-    load_frags(kt + 1, na, nw);
-    mfma_all(fa, fw);
-    constexpr int NMEM = TM + TN + NP, NMFMA = TM * TN;
-#pragma unroll
-    for (int i = 0; i < TM + TN; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (PREFETCH) {
+        fa[mt] = rd_a(kt + 1, mt);
+        if (mt < TN) nw[mt] = rd_w(kt + 1, mt);
+      }
+      if (ISSUE && mt >= TM - NP) issue_piece(slot, mt - (TM - NP));
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto tail = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
-    if (kt + 1 < nk) {
-      if (kt + 2 < nk) wait_vmcnt_barrier<NP>();    // stages issued after kt+1 so far: kt+2 only
-      else wait_vmcnt_barrier<0>();
-      if (kt + STAGES - 1 < nk) issue_stage((kt + STAGES - 1) % STAGES);
-      load_frags(kt + 1, na, nw);
-    }
-    mfma_all(fa, fw);
-  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  static_assert(TM >= NP && TM >= TN, "phase() spreads NP DMA issues and TN W-fragment reads over TM MFMA groups");
   if (nk >= 3) wait_vmcnt_barrier<2 * NP>();  // stage 0 landed; stages 1 and 2 may still be in flight
   else if (nk == 2) wait_vmcnt_barrier<NP>();
   else wait_vmcnt_barrier<0>();
-  load_frags(0, fa0, fw0);
+#pragma unroll
+  for (int t = 0; t < TM; ++t) fa[t] = rd_a(0, t);
+#pragma unroll
+  for (int t = 0; t < TN; ++t) fw0[t] = rd_w(0, t);
   int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {
-    steady(kt, fa0, fw0, fa1, fw1);
-    steady(kt + 1, fa1, fw1, fa0, fw0);
+  for (; kt + 4 < nk; kt += 2) {               // steady state: kt+1 landed behind vmcnt(NP); kt+3 issued in the phase
+    wait_vmcnt_barrier<NP>();
+    phase(kt, fw0, fw1, T_{}, T_{});
+    wait_vmcnt_barrier<NP>();
+    phase(kt + 1, fw1, fw0, T_{}, T_{});
   }
-  for (; kt < nk; kt += 2) {
-    tail(kt, fa0, fw0, fa1, fw1);
-    tail(kt + 1, fa1, fw1, fa0, fw0);
+  for (; kt < nk; kt += 2) {                   // drain (nk is even): no more DMA once kt+3 >= nk
+    auto one = [&](int k, half8_t (&fw)[TN], half8_t (&nw)[TN]) {
+      if (k + 1 < nk) {
+        if (k + 2 < nk) wait_vmcnt_barrier<NP>();
+        else wait_vmcnt_barrier<0>();
+        if (k + STAGES - 1 < nk) phase(k, fw, nw, T_{}, T_{});
+        else phase(k, fw, nw, T_{}, F_{});
+      } else {
+        phase(k, fw, nw, F_{}, F_{});
+      }
+    };
+    one(kt, fw0, fw1);
+    one(kt + 1, fw1, fw0);
   }
 
   // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4).  ACT / VEC are template
@@ -370,7 +372,6 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   else if (pick == 64) ok = launch_gemm<2, 2, 4, 2, 2>(p, batch, out_f16, stream);   // 128 x 64
   else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 2>(p, batch, out_f16, stream);
   else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 2>(p, batch, out_f16, stream);
-  else if (pick == 1192) ok = launch_gemm<2, 2, 4, 6, 2>(p, batch, out_f16, stream);   // 128 x 192, 4 waves, 2 blocks/CU: experiment only (ZH_GEMM_TILE), measured 10-20 % slower than 256 x 192 on the N=768 GEMMs
   else ok = launch_gemm<2, 4, 8, 4, 2>(p, batch, out_f16, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16: (out_f16=%d, act=%d) is not an instantiated epilogue (f32: none|sigmoid; f16: none|quickgelu|relu|gelu_erf)",
                out_f16, act);

@@ -123,9 +123,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;                    // even: K % 64 == 0
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue_stage(s);
+  issue_stage(0);
+  issue_stage(1);                              // nk >= 2 (K % 64 == 0)
 
   const int frow = lane & 15, fk = lane >> 4;
   const int foff = frow * BK + ((fk ^ ((-(frow >> 2)) & 3)) * 8);   // per-lane offset inside a 16-row subtile
@@ -150,25 +149,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       for (int mt = 0; mt < TM; ++mt)
         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
   };
-  // steady-state phase (kt + 3 < nk): branch-free so the scheduler can interleave — every group of MFMAs shadows one
-  // LDS fragment read or one LDS-DMA issue of the NEXT slices; the wave's stream stays MFMA-paced instead of
-  // front-loading 16 memory instructions behind the barrier.
-  auto steady = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
-    wait_vmcnt_barrier<NP>();
-    issue_stage((kt + STAGES - 1) % STAGES);
-    load_frags(kt + 1, na, nw);
-    mfma_all(fa, fw);
-    constexpr int NMEM = TM + TN + NP, NMFMA = TM * TN;
-#pragma unroll
-    for (int i = 0; i < TM + TN; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
+  // steady state, ONE barrier per TWO slices: at super-step (kt, kt+1) both stages have landed (vmcnt(0) of this wave's
+  // DMAs + barrier); stages kt+2, kt+3 are issued right behind the barrier into the two slots read in the previous
+  // super-step.  Slice kt+1's fragments are read under slice kt's MFMAs; slice kt+2's cannot be (not landed yet).
+  auto super_step = [&](int kt) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    issue_stage((kt + 2) % STAGES);
+    issue_stage((kt + 3) % STAGES);
+    load_frags(kt, fa0, fw0);
+    load_frags(kt + 1, fa1, fw1);
+    mfma_all(fa0, fw0);
+    mfma_all(fa1, fw1);
   };
   auto tail = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
     if (kt + 1 < nk) {
@@ -179,19 +170,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     }
     mfma_all(fa, fw);
   };
-  if (nk >= 3) wait_vmcnt_barrier<2 * NP>();  // stage 0 landed; stages 1 and 2 may still be in flight
-  else if (nk == 2) wait_vmcnt_barrier<NP>();
-  else wait_vmcnt_barrier<0>();
-  load_frags(0, fa0, fw0);
   int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {
-    steady(kt, fa0, fw0, fa1, fw1);
-    steady(kt + 1, fa1, fw1, fa0, fw0);
-  }
-  for (; kt < nk; kt += 2) {
-    tail(kt, fa0, fw0, fa1, fw1);
-    tail(kt + 1, fa1, fw1, fa0, fw0);
-  }
+  for (; kt + 2 < nk; kt += 2) super_step(kt);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // last two slices: nothing left to issue
+  load_frags(kt, fa0, fw0);
+  load_frags(kt + 1, fa1, fw1);
+  mfma_all(fa0, fw0);
+  mfma_all(fa1, fw1);
 
   // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4).  ACT / VEC are template
   // parameters: a runtime switch unrolled 32x blew the instruction cache (fc GEMM 1.4x slower in the model).
