@@ -104,6 +104,9 @@ int zh_sine_pe(float* out, int h, int w, int D, float temperature, zh_stream_t s
 /* memory + pos (transformer.py:281): out f16 = a f16 + add f32[r % add_rows]. */
 int zh_add_rowperiodic_f16(const void* a, const float* add, void* out, long rows, int D, int add_rows, zh_stream_t stream);
 
+/* x[i] = value (tgt = zeros_like(queries), zutis.py:164) — a kernel so that it can be part of a launch plan. */
+int zh_fill_f32(float* x, float value, long n, zh_stream_t stream);
+
 /* f32 -> f16 (optionally + add[r % add_rows]). */
 int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, zh_stream_t stream);
 
@@ -174,6 +177,14 @@ int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, long lon
  * Replaces the mask D2H in front of pycocotools.mask.encode / masks_to_boxes, zutis.py:288-294,446-452. */
 int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, int W, int max_runs,
                  int* positions, int* nruns, int* box_area, zh_stream_t stream);
+
+/* Native launch plans (zutis_amd/plan.py): replay n recorded calls of the entry points above (op id + 24 argument words
+ * each; dispatcher generated from this header) in one C loop; zh_plan_run2 alternates two plans on two streams. */
+int zh_plan_run(const void* cmds, int n, zh_stream_t stream);
+int zh_plan_run2(const void* cmds_a, int na, zh_stream_t stream_a, const void* cmds_b, int nb, zh_stream_t stream_b);
+/* Name of the entry point the library dispatches plan op `op` to (NULL if out of range): the host checks it against its
+ * own table so that a stale library cannot mis-dispatch. */
+const char* zh_plan_op_name(int op);
 
 /* HOST helper: RLE string from run lengths (pycocotools rleToString). */
 long zh_rle_counts_to_string_host(const long long* counts, long n, char* out, long cap);

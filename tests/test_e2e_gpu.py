@@ -299,3 +299,32 @@ def test_batch_invariance_full_size(dev):
     pt = full["patch_tokens"]
     assert (pt.norm(dim=-1) - 1).abs().max().item() < 1e-5
     assert 0 <= full["mask_proposals"].min().item() and full["mask_proposals"].max().item() <= 1
+
+
+def test_launch_plan_replay_matches_eager(dev):
+    """Native launch plan (zh_plan_run): bitwise the eager result, across replays with new inputs, and with two plans
+    interleaved on two streams (zh_plan_run2)."""
+    from zutis_amd import detgen, plan as zplan
+    cfg = detgen.TINY
+    text = torch.from_numpy(detgen.text_embeddings(7, cfg.embed_dim)).to(dev)
+    eng, ref_eng = _engine(cfg, dev), _engine(cfg, dev)
+    p = eng.build_plan((2, 3, 80, 112), text, (80, 112))
+    assert p["plan"].n > 20, p["plan"].n
+    for seed in (0, 1, 2):
+        x = torch.from_numpy(detgen.images(2, 80, 112, seed=seed)).to(dev)
+        out, labels = eng.run_plan(p, x)
+        ref = ref_eng.forward(x)
+        assert torch.equal(out["mask_proposals"], ref["mask_proposals"]) and torch.equal(out["patch_tokens"], ref["patch_tokens"])
+        assert torch.equal(labels, ref_eng.predict_semantic(ref["patch_tokens"], text, (80, 112)))
+    # two engines / two plans / two streams, interleaved from C
+    eng_b = _engine(cfg, dev)
+    pb = eng_b.build_plan((2, 3, 80, 112), text, (80, 112))
+    xa = torch.from_numpy(detgen.images(2, 80, 112, seed=5)).to(dev)
+    xb = torch.from_numpy(detgen.images(2, 80, 112, seed=6)).to(dev)
+    p["x"].copy_(xa); pb["x"].copy_(xb)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    zplan.run2(p["plan"], sa.cuda_stream, pb["plan"], sb.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(p["labels"], ref_eng.predict_semantic(ref_eng.forward(xa)["patch_tokens"], text, (80, 112)))
+    assert torch.equal(pb["labels"], ref_eng.predict_semantic(ref_eng.forward(xb)["patch_tokens"], text, (80, 112)))

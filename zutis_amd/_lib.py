@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(HERE, "libzutis_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h")
 
 _lib = None
+RECORDER = None   # zutis_amd.plan.Recorder while a launch plan is being recorded
 
 
 class ZutisHipError(RuntimeError):
@@ -40,6 +41,7 @@ _SIGS = {
     "zh_upsample2x_bilinear_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "zh_sine_pe": (_i, [_vp, _i, _i, _i, _f, _vp]),
     "zh_add_rowperiodic_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "zh_fill_f32": (_i, [_vp, _f, _l, _vp]),
     "zh_cast_f32_f16": (_i, [_vp, _vp, _i, _vp, _l, _i, _vp]),
     "zh_upsample_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "zh_upsample_bilinear_nchw": (_i, [_vp, _vp, _vp, _f, _l, _i, _i, _i, _i, _f, _f, _vp]),
@@ -56,16 +58,36 @@ _SIGS = {
     "zh_bgrid_coords": (_i, [_vp, _i, _i, _d, _d, _d, _vp, _vp]),
     "zh_bilateral_workspace_size": (_sz, [_i, _i, _d, _d, _d]),
     "zh_bilateral_solve": (_i, [_vp, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "zh_plan_op_name": (C.c_char_p, [_i]),
+    "zh_plan_run": (_i, [_vp, _i, _vp]),
+    "zh_plan_run2": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "zh_mask_iou_workspace_size": (_sz, [_i, _l]),
     "zh_mask_iou_counts": (_i, [_vp, _i, _l, _vp, _vp, _vp, _sz, _vp]),
 }
 
 
-def load():
+class _RecordingProxy:
+    """Stands in for the CDLL while a plan is recorded: plannable entry points are logged, everything else passes through."""
+
+    def __init__(self, lib, rec):
+        self._lib, self._rec = lib, rec
+
+    def __getattr__(self, name):
+        from . import plan
+        fn = getattr(self._lib, name)
+        if name in plan.op_table():
+            def _log(*args):
+                self._rec.calls.append((name, args))
+                return 0
+            return _log
+        return fn
+
+
+def load(raw: bool = False):
     """Load the shared library (building nothing: run `python -m zutis_amd.build` / __graft_entry__.build())."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _RecordingProxy(_lib, RECORDER) if (RECORDER is not None and not raw) else _lib
     if not os.path.exists(LIB_PATH):
         raise ZutisHipError(
             f"{LIB_PATH} is missing: the HIP extension is REQUIRED (no CPU fallback). "
@@ -79,7 +101,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
-    return lib
+    return load(raw)
 
 
 def register(name, restype, argtypes):

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzutis_hip.so")
 # float64 bilateral solver: no FMA contraction (bin edges and bistochastisation are bit-compared with NumPy/SciPy)
 EXTRA_FLAGS = {"bilateral.hip": ["-ffp-contract=off"]}
-SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip", "plan.hip"]
 
 
 def _hipcc() -> str:
@@ -31,7 +31,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "common.h")]
+    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -40,12 +40,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     objs = []
     os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+    from . import plan
+    plan.generate_dispatch(os.path.join(CSRC, "plan_gen.inc"))      # launch-plan dispatcher, generated from the header
     procs = []
     for src in sources():
         obj = os.path.join(HERE, "_obj", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
-                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, "common.h"))):
+        deps = [src, os.path.join(CSRC, "common.h")]
+        if os.path.basename(src) == "plan.hip":                     # includes the dispatcher generated from the header
+            deps.append(os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h"))
+        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):
             continue
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS.get(os.path.basename(src), []) + \
               ["-c", src, "-o", obj]

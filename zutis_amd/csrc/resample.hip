@@ -344,3 +344,15 @@ extern "C" int zh_resize_nearest_u8(const unsigned char* x, unsigned char* out, 
   ZH_CHECK_LAUNCH("zh_resize_nearest_u8");
   return ZH_OK;
 }
+
+// ---- fill an f32 buffer (tgt = zeros, networks/zutis.py:164) as a kernel so it can live inside a launch plan
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* x, float v, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+extern "C" int zh_fill_f32(float* x, float value, long n, hipStream_t stream) {
+  ZH_CHECK_ARG(x && n > 0, "zh_fill_f32: bad arguments");
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(zh_cdiv(n, 256)), dim3(256), 0, stream, x, value, n);
+  ZH_CHECK_LAUNCH("zh_fill_f32");
+  return ZH_OK;
+}

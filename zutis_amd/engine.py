@@ -42,6 +42,7 @@ class _EngineBase:
         self._w: Dict[str, torch.Tensor] = {}
         self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
         self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._buf_gen = 0             # bumped on every (re)allocation: launch plans check it
 
     def _version_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.params.values())
@@ -67,6 +68,7 @@ class _EngineBase:
                 del self._bufs[kk]
             b = torch.empty(shape, dtype=dtype, device=self._device())
             self._bufs[k] = b
+            self._buf_gen += 1
         return b
 
     @staticmethod
@@ -178,7 +180,7 @@ class _EngineBase:
         ff16 = self._buf("ff16", (R, W_["dec.0.l1_w"].shape[0]), f16)
         inter16 = self._buf("inter16", (B * (L if stack_all else 1) * Q, D), f16)
         out32 = self._buf("dec_out32", (R, D), f32)
-        tgt.zero_()
+        ops.fill_f32(tgt, 0.0)                                                              # tgt = zeros (zutis.py:164)
         ops.cast_f16(tgt, tgt16, R, D)
         ops.cast_f16(tgt, qin16, R, D, add=qpos, add_rows=Q)
         for l in range(L):
@@ -311,7 +313,8 @@ class ZutisEngine(_EngineBase):
         ts = self._buf("textspace", (B * M, self.E), f32)
         ops.gemm(TOK, W_["projT"], ts)                                                      # :319
         pt = torch.empty((B, h2, w2, self.E), dtype=f32, device=x.device)
-        ops.global_ln_l2(ts, B, M, self.E, out_f32=pt, eps=1e-5, l2_eps=1e-7)               # :320-322
+        ws = self._buf("gln_ws", (max(1, ops.global_ln_l2_workspace_size(B, M, self.E)),), torch.uint8)
+        ops.global_ln_l2(ts, B, M, self.E, out_f32=pt, eps=1e-5, l2_eps=1e-7, workspace=ws)  # :320-322
         return {"mask_proposals": masks, "patch_tokens": pt}
 
     # ------------------------------------------------------------------ hipGraph replay (latency path)
@@ -339,6 +342,37 @@ class ZutisEngine(_EngineBase):
         g["graph"].replay()
         return {k: v.clone() for k, v in g["out"].items()}
 
+    # ------------------------------------------------------------------ native launch plans
+    def build_plan(self, x_shape, text: Optional[torch.Tensor] = None, size: Optional[Tuple[int, int]] = None):
+        """Record forward() (and predict_semantic() when `text` is given) for one input shape into a native launch plan
+        (zutis_amd/plan.py).  Returns a dict with the static input `x`, the static outputs and the plan.  The engine must
+        not be used with other shapes between build and replay (its buffer cache backs the recorded pointers)."""
+        from . import plan as zplan
+        self._pack()
+        dev = self._device()
+        static_x = torch.zeros(tuple(x_shape), dtype=f32, device=dev)
+        text32 = None if text is None else text.detach().to(device=dev, dtype=f32).contiguous()
+        self.forward(static_x)                                     # eager warm-up: packs weights, fills caches
+        if text32 is not None:
+            self.predict_semantic(self.forward(static_x)["patch_tokens"], text32, size)
+        gen = self._buf_gen
+        with zplan.Recorder() as rec:
+            out = self.forward(static_x)
+            labels = None if text32 is None else self.predict_semantic(out["patch_tokens"], text32, size)
+        if self._buf_gen != gen:
+            raise ZutisHipError("build_plan: buffers were re-allocated while recording")
+        return {"x": static_x, "out": out, "labels": labels, "text": text32, "plan": rec.build(), "gen": gen}
+
+    def run_plan(self, p, x: Optional[torch.Tensor] = None):
+        """Replay a plan from build_plan() on the current stream.  Outputs are the plan's static tensors (overwritten by
+        the next replay: clone what must survive)."""
+        if self._buf_gen != p["gen"]:
+            raise ZutisHipError("run_plan: the engine's buffers changed since the plan was built")
+        if x is not None:
+            p["x"].copy_(x)
+        p["plan"].run(torch.cuda.current_stream().cuda_stream)
+        return p["out"], p["labels"]
+
     # ------------------------------------------------------------------ predict (semantic)
     def semantic_logits_lowres(self, patch_tokens: torch.Tensor, text: torch.Tensor) -> torch.Tensor:
         """einsum("nc,bchw->bnhw") zutis.py:361-365 -> f32 [B,n,h,w]."""
@@ -346,7 +380,9 @@ class ZutisEngine(_EngineBase):
         n = text.shape[0]
         pt16 = self._buf("pt16", (B * h * w, E), f16)
         ops.cast_f16(patch_tokens.contiguous(), pt16, B * h * w, E)
-        t16 = text.detach().to(device=patch_tokens.device, dtype=f16).contiguous()
+        t32 = text.detach().to(device=patch_tokens.device, dtype=f32).contiguous()
+        t16 = self._buf("text16", (n, E), f16)
+        ops.cast_f16(t32, t16, n, E)
         lo = torch.empty((B, n, h, w), dtype=f32, device=patch_tokens.device)
         ops.gemm(t16, pt16, lo, M=n, N=h * w, K=E, lda=E, ldw=E, ldc=h * w, batch=B, strideA=0, strideW=h * w * E,
                  strideC=n * h * w)

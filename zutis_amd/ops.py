@@ -37,6 +37,8 @@ def _p(t: Optional[torch.Tensor]):
         return None
     if not t.is_cuda:
         raise _lib.ZutisHipError("zutis_amd ops need GPU tensors (no CPU fallback)")
+    if _lib.RECORDER is not None:
+        _lib.RECORDER.keepalive.append(t)        # a launch plan owns every tensor whose address it recorded
     return t.data_ptr()
 
 
@@ -105,9 +107,13 @@ def l2norm_rows(x, rows, D, out_f32=None, out_f16=None, eps=0.0):
     _lib.check(L.zh_l2norm_rows(_p(x), _p(out_f32), _p(out_f16), float(eps), rows, D, _stream()), "zh_l2norm_rows")
 
 
+def global_ln_l2_workspace_size(B, M, Cc) -> int:
+    return int(_lib.load(raw=True).zh_global_ln_l2_workspace_size(B, M, Cc))
+
+
 def global_ln_l2(x, B, M, Cc, out_f32=None, out_f16=None, eps=1e-5, l2_eps=1e-7, workspace=None):
     L = _lib.load()
-    need = L.zh_global_ln_l2_workspace_size(B, M, Cc)
+    need = global_ln_l2_workspace_size(B, M, Cc)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
     _lib.check(L.zh_global_ln_l2(_p(x), _p(out_f32), _p(out_f16), float(eps), float(l2_eps), B, M, Cc, _p(workspace),
@@ -140,6 +146,12 @@ def sine_pe(out, h, w, D, temperature=10000.0):
 def add_rowperiodic_f16(a, add, out, rows, D, add_rows):
     L = _lib.load()
     _lib.check(L.zh_add_rowperiodic_f16(_p(a), _p(add), _p(out), rows, D, add_rows, _stream()), "zh_add_rowperiodic_f16")
+
+
+def fill_f32(x, value=0.0):
+    L = _lib.load()
+    _chk(x, f32, "fill x")
+    _lib.check(L.zh_fill_f32(_p(x), float(value), x.numel(), _stream()), "zh_fill_f32")
 
 
 def cast_f16(x, out, rows, D, add=None, add_rows=0):
