@@ -90,6 +90,25 @@ def test_gemm_race_screen_bitwise_repeatable(dev):
                 assert torch.equal(out, first), f"non-repeatable GEMM result at launch {it} for {(M, N, K)}"
 
 
+@pytest.mark.parametrize("tile", ["256", "192", "128", "64", "2128", "2064", "3064"])
+def test_gemm_every_tile_variant_every_ring_phase(dev, tile, monkeypatch):
+    """Each tile / ring-depth variant (ZH_GEMM_TILE developer override) over K = 64 .. 1024: every prologue / steady / tail
+    combination of the 4- and 8-deep LDS-DMA rings, ragged M and N, repeated launches bitwise identical."""
+    from zutis_amd import ops
+    monkeypatch.setenv("ZH_GEMM_TILE", tile)
+    M, N = 333, 328
+    for K in (64, 128, 192, 256, 320, 448, 512, 576, 640, 1024):
+        A, W = _randn((M, K), 300 + K, 0.5).to(f16).to(dev), _randn((N, K), 400 + K, 0.5).to(f16).to(dev)
+        ref = A.float() @ W.float().t()
+        outs = []
+        for _ in range(3):
+            out = torch.empty((M, N), dtype=f32, device=dev)
+            ops.gemm(A, W, out)
+            outs.append(out)
+        assert torch.allclose(outs[0], ref, atol=1e-3 * math.sqrt(K / 64), rtol=1e-3), (tile, K)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (tile, K)
+
+
 def test_gemm_rejects_bad_k(dev):
     from zutis_amd import ops, _lib
     A, W = torch.zeros((8, 40), dtype=f16, device=dev), torch.zeros((8, 40), dtype=f16, device=dev)

@@ -1,7 +1,7 @@
 """Eager vs native-plan replay (one stream, and two half-batch plans on two streams).  usage: plan_bench.py B [iters]"""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zutis_amd import detgen, plan as zplan
 from zutis_amd.engine import ZutisEngine
 

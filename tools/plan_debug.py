@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zutis_amd import detgen, plan as zplan
 from zutis_amd.engine import ZutisEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1

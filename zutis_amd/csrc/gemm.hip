@@ -26,7 +26,6 @@
 #include "common.h"
 
 #define BK 32
-#define STAGES 4
 #define GROUP_M 8
 
 struct GemmArgs {
@@ -43,25 +42,36 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_barrier() {
-  static_assert(N == 0 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 10, "unsupported vmcnt");
-  if (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
-  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-  else if (N == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-  else if (N == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// runtime count of whole stages (0 .. MAXC) that may stay in flight, NP DMA issues each
+template <int NP, int MAXC>
+__device__ __forceinline__ void wait_stages_barrier(int c) {
+  static_assert(MAXC <= 5, "extend the switch");
+  switch (c) {
+    case 0: wait_vmcnt_barrier<0>(); break;
+    case 1: wait_vmcnt_barrier<NP>(); break;
+    case 2: if (MAXC >= 2) { wait_vmcnt_barrier<(MAXC >= 2 ? 2 : 0) * NP>(); break; }
+    case 3: if (MAXC >= 3) { wait_vmcnt_barrier<(MAXC >= 3 ? 3 : 0) * NP>(); break; }
+    case 4: if (MAXC >= 4) { wait_vmcnt_barrier<(MAXC >= 4 ? 4 : 0) * NP>(); break; }
+    default: wait_vmcnt_barrier<MAXC * NP>(); break;
+  }
 }
 
 // WM x WN waves; each wave owns TM x TN subtiles of 16x16.  Block tile = (WM*TM*16) x (WN*TN*16).
-template <int WM, int WN, int TM, int TN, int OUT_F16, int ACT, int VEC>
+// STAGES = depth of the LDS ring: 4 for the big tiles; 8 for the small-tile variants used when a GEMM has fewer tiles than
+// the chip has CUs — those are bound by bytes in flight per CU (3 x 16 KiB per 128x128 block = 24 GB/s per CU at ~2 us of
+// loaded latency), so the ring, not the tile, is what has to grow.
+template <int WM, int WN, int TM, int TN, int STAGES, int OUT_F16, int ACT, int VEC>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM * TN) >= 96 ? 2 : 1)) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int ROWS = BM + BN;             // LDS rows per stage (A rows then W rows), 64 B each
   constexpr int PIECES = ROWS / 16;         // 1-KiB DMA pieces per stage
   constexpr int NP = (PIECES + NW - 1) / NW;  // DMA issues per wave per stage (duplicates pad uneven splits)
-  static_assert(NP >= 3 && NP <= 5, "unsupported pieces-per-wave count");
+  static_assert(NP >= 2 && NP <= 5 && STAGES >= 4 && STAGES <= 8, "unsupported pieces-per-wave count / ring depth");
+  constexpr int AHEAD = STAGES - 3;           // whole stages that may still be in flight at a steady-state barrier
   constexpr int STAGE_HALVES = ROWS * BK;
   __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE_HALVES];
 
@@ -154,37 +164,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   // LDS fragment read or one LDS-DMA issue of the NEXT slices; the wave's stream stays MFMA-paced instead of
   // front-loading 16 memory instructions behind the barrier.
   auto steady = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
-    wait_vmcnt_barrier<NP>();
+    wait_vmcnt_barrier<AHEAD * NP>();
     issue_stage((kt + STAGES - 1) % STAGES);
     load_frags(kt + 1, na, nw);
     mfma_all(fa, fw);
     constexpr int NMEM = TM + TN + NP, NMFMA = TM * TN;
+    if (NMFMA >= NMEM) {
 #pragma unroll
-    for (int i = 0; i < TM + TN; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
+      for (int i = 0; i < TM + TN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      for (int i = 0; i < NP; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
     }
   };
   auto tail = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
     if (kt + 1 < nk) {
-      if (kt + 2 < nk) wait_vmcnt_barrier<NP>();    // stages issued after kt+1 so far: kt+2 only
-      else wait_vmcnt_barrier<0>();
+      // slices issued so far: 0 .. min(nk-1, kt+STAGES-2); slice kt+1 must have landed, the later ones may fly
+      wait_stages_barrier<NP, AHEAD>(min(nk - 1, kt + STAGES - 2) - (kt + 1));
       if (kt + STAGES - 1 < nk) issue_stage((kt + STAGES - 1) % STAGES);
       load_frags(kt + 1, na, nw);
     }
     mfma_all(fa, fw);
   };
-  if (nk >= 3) wait_vmcnt_barrier<2 * NP>();  // stage 0 landed; stages 1 and 2 may still be in flight
-  else if (nk == 2) wait_vmcnt_barrier<NP>();
-  else wait_vmcnt_barrier<0>();
+  if (nk >= STAGES - 1) wait_vmcnt_barrier<(STAGES - 2) * NP>();   // stage 0 landed; the other STAGES-2 may still be in flight
+  else wait_vmcnt_barrier<0>();                                     // short K: not worth a counted wait
   load_frags(0, fa0, fw0);
   int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {
+  for (; kt + STAGES < nk; kt += 2) {
     steady(kt, fa0, fw0, fa1, fw1);
     steady(kt + 1, fa1, fw1, fa0, fw0);
   }
@@ -296,26 +307,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   }
 }
 
-template <int WM, int WN, int TM, int TN, int OUT_F16, int ACT, int VEC>
+template <int WM, int WN, int TM, int TN, int STAGES, int OUT_F16, int ACT, int VEC>
 static void launch_one(GemmArgs p, int batch, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   p.nbm = zh_cdiv(p.M, BM);
   p.nbn = zh_cdiv(p.N, BN);
   const unsigned nblk = (unsigned)((long)p.nbm * p.nbn * batch);
-  hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, OUT_F16, ACT, VEC>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
+  hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, STAGES, OUT_F16, ACT, VEC>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
 }
 
 // Instantiated (out type, activation) pairs = the ones the hot path uses; anything else is an argument error.
-template <int WM, int WN, int TM, int TN, int VEC>
+template <int WM, int WN, int TM, int TN, int STAGES, int VEC>
 static bool launch_gemm(const GemmArgs& p, int batch, int out_f16, hipStream_t stream) {
   const int key = out_f16 * 8 + p.act;
   switch (key) {
-    case 0 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, 0, ZH_ACT_NONE, VEC>(p, batch, stream); return true;
-    case 0 + ZH_ACT_SIGMOID: launch_one<WM, WN, TM, TN, 0, ZH_ACT_SIGMOID, VEC>(p, batch, stream); return true;
-    case 8 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, 1, ZH_ACT_NONE, VEC>(p, batch, stream); return true;
-    case 8 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, 1, ZH_ACT_QUICKGELU, VEC>(p, batch, stream); return true;
-    case 8 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, 1, ZH_ACT_RELU, VEC>(p, batch, stream); return true;
-    case 8 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, 1, ZH_ACT_GELU_ERF, VEC>(p, batch, stream); return true;
+    case 0 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 0, ZH_ACT_NONE, VEC>(p, batch, stream); return true;
+    case 0 + ZH_ACT_SIGMOID: launch_one<WM, WN, TM, TN, STAGES, 0, ZH_ACT_SIGMOID, VEC>(p, batch, stream); return true;
+    case 8 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_NONE, VEC>(p, batch, stream); return true;
+    case 8 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_QUICKGELU, VEC>(p, batch, stream); return true;
+    case 8 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_RELU, VEC>(p, batch, stream); return true;
+    case 8 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_GELU_ERF, VEC>(p, batch, stream); return true;
     default: return false;
   }
 }
@@ -360,18 +371,24 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   int pick = (c128 < c256 && c128 < c192) ? 128 : (c192 < c256 ? 192 : 256);
   // (a 128x64 tile for the decoder's M = B*Q GEMMs measured no better than 128x128: they are slice-latency bound;
   //  it stays reachable through ZH_GEMM_TILE=64 for experiments)
+  // few-tile GEMMs (batch-1 inference: M = 442 tokens -> 24 tiles of 128x128 on 256 CUs): 64x64 tiles on an 8-deep
+  // ring put 4x the CUs to work; measured 32 -> 16 us on the 442x768x3072 MLP projection (tools/gemm_small.py)
+  if ((long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch <= 96) pick = 3064;
   if (force) pick = atoi(force);
   // 16-byte row stores need 16-B aligned rows; an f16 residual is not supported (none on the hot path)
   const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&
                        ((N * esz) % 16 == 0) && !(out_f16 && residual);
   bool ok;
-  if (!p.vec_ok) ok = launch_gemm<2, 2, 4, 4, 0>(p, batch, out_f16, stream);      // scalar-store fallback: small tile only
-  else if (!wide_ok) ok = launch_gemm<2, 2, 4, 4, 1>(p, batch, out_f16, stream);  // direct 8/16-B stores
-  else if (pick == 64) ok = launch_gemm<2, 2, 4, 2, 2>(p, batch, out_f16, stream);   // 128 x 64
-  else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 2>(p, batch, out_f16, stream);
-  else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 2>(p, batch, out_f16, stream);
-  else if (pick == 1192) ok = launch_gemm<2, 2, 4, 6, 2>(p, batch, out_f16, stream);   // 128 x 192, 4 waves, 2 blocks/CU: experiment only (ZH_GEMM_TILE), measured 10-20 % slower than 256 x 192 on the N=768 GEMMs
-  else ok = launch_gemm<2, 4, 8, 4, 2>(p, batch, out_f16, stream);
+  if (!p.vec_ok) ok = launch_gemm<2, 2, 4, 4, 4, 0>(p, batch, out_f16, stream);      // scalar-store fallback: small tile only
+  else if (!wide_ok) ok = launch_gemm<2, 2, 4, 4, 4, 1>(p, batch, out_f16, stream);  // direct 8/16-B stores
+  else if (pick == 2128) ok = launch_gemm<2, 2, 4, 4, 8, 2>(p, batch, out_f16, stream);   // 128 x 128, 8-deep ring
+  else if (pick == 2064) ok = launch_gemm<2, 2, 4, 2, 8, 2>(p, batch, out_f16, stream);   // 128 x 64, 8-deep ring
+  else if (pick == 3064) ok = launch_gemm<2, 2, 2, 2, 8, 2>(p, batch, out_f16, stream);   // 64 x 64, 8-deep ring
+  else if (pick == 64) ok = launch_gemm<2, 2, 4, 2, 4, 2>(p, batch, out_f16, stream);   // 128 x 64
+  else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 4, 2>(p, batch, out_f16, stream);
+  else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 4, 2>(p, batch, out_f16, stream);
+  else if (pick == 1192) ok = launch_gemm<2, 2, 4, 6, 4, 2>(p, batch, out_f16, stream);   // 128 x 192, 4 waves, 2 blocks/CU: experiment only (ZH_GEMM_TILE), measured 10-20 % slower than 256 x 192 on the N=768 GEMMs
+  else ok = launch_gemm<2, 4, 8, 4, 4, 2>(p, batch, out_f16, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16: (out_f16=%d, act=%d) is not an instantiated epilogue (f32: none|sigmoid; f16: none|quickgelu|relu|gelu_erf)",
                out_f16, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16");
