@@ -12,6 +12,12 @@ bilinear-upsample/argmax to 336x336 labels).  Inputs are resident in HBM before 
 For N > 1 images are sharded by rank (weak scaling, 32 per GPU) and each step all-gathers the low-res class
 logits over RCCL/xGMI (north_star: "RCCL all-gather of logits for evaluation"), overlapped with the next step.
 
+Steps are independent batches (an evaluation loop), so `--inflight 2` (default) keeps two of them in flight: each step
+is recorded once into a native launch plan (zutis_amd/plan.py) and consecutive steps are replayed interleaved on two HIP
+streams by one C loop (zh_plan_run_multi), so one batch's kernel tails, launch gaps and HBM-bound epilogues overlap the
+other's MFMA phases.  Every step still does all of its work inside the timed region; `--inflight 1` is the plain
+one-stream eager loop.
+
 Prints ONE JSON line on rank 0 (contract in the task brief) incl. `roofline` (dominant kernel = the fp16 MFMA
 GEMM, measured with HIP events around every launch of an instrumented step) and `cpu_baseline` (the oracle = CPU
 port of the reference path, timed on the host cores on a bounded sample, rank 0, N=1 only).
@@ -42,6 +48,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE config[1]: batch 32)")
     ap.add_argument("--size", type=int, default=336)
     ap.add_argument("--classes", type=int, default=81)
+    ap.add_argument("--inflight", type=int, default=2, help="independent steps in flight (HIP streams); 1 = eager, one stream")
+    ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
@@ -56,11 +64,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # nccl == RCCL on ROCm
 
     from zutis_amd import detgen, ops
+    from zutis_amd import plan as zplan
     from zutis_amd import distributed as zd
     from zutis_amd.engine import ZutisEngine
 
@@ -73,7 +85,7 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     x = torch.randn((B, 3, S, S), generator=g).to(dev)
     hw2 = (2 * ((S - cfg.patch) // cfg.patch + 1)) ** 2
-    gathered = [torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) for _ in range(2)] if dist_on else None
     pending = [None]
 
     def step(i: int):
@@ -81,29 +93,74 @@ def main():
         lo = eng.semantic_logits_lowres(out["patch_tokens"], text)
         labels = torch.empty((B, S, S), dtype=torch.int64, device=dev)
         ops.upsample_argmax(lo, labels, B, n, lo.shape[2], lo.shape[3], S, S)
-        if world > 1:
+        if dist_on:
             if pending[0] is not None:
                 pending[0].wait()
             _, pending[0] = zd.all_gather_logits(lo.view(B, n, hw2), out=gathered[i & 1], async_op=True)
         return labels
 
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        if pending[0] is not None:
-            pending[0].wait()
+    # ---- lanes: one engine (its own activation buffers), launch plan, stream and gather buffer per step in flight
+    n_lanes = max(1, args.inflight)
+    lanes = []
+    if n_lanes > 1:
+        for li in range(n_lanes):
+            e = eng if li == 0 else ZutisEngine(P, cfg.patch, cfg.dec_heads)
+            e.forward(x)                                   # eager warm-up: packs weights, sizes the buffer cache
+            with zplan.Recorder() as rec:
+                out = e.forward(x)
+                lo = e.semantic_logits_lowres(out["patch_tokens"], text)
+                labels = torch.empty((B, S, S), dtype=torch.int64, device=dev)
+                ops.upsample_argmax(lo, labels, B, n, lo.shape[2], lo.shape[3], S, S)
+            lanes.append({"eng": e, "plan": rec.build(), "lo": lo, "labels": labels, "stream": torch.cuda.Stream(device=dev),
+                          "gathered": torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) if dist_on else None,
+                          "pending": None})
+        torch.cuda.synchronize()
+
+    def run_steps(first: int, count: int):
+        """`count` consecutive steps; with lanes, groups of `n_lanes` steps are enqueued interleaved, one stream each."""
+        if not lanes:
+            for i in range(first, first + count):
+                step(i)
+            return
+        done = 0
+        while done < count:
+            grp = lanes[:min(n_lanes, count - done)]
+            if dist_on:
+                for ln in grp:                              # the lane's previous gather must have read `lo` before it is rewritten
+                    if ln["pending"] is not None:
+                        with torch.cuda.stream(ln["stream"]):
+                            ln["pending"].wait()
+                        ln["pending"] = None
+            zplan.run_many([ln["plan"] for ln in grp], [ln["stream"].cuda_stream for ln in grp])
+            if dist_on:
+                for ln in grp:
+                    with torch.cuda.stream(ln["stream"]):
+                        _, ln["pending"] = zd.all_gather_logits(ln["lo"].view(B, n, hw2), out=ln["gathered"], async_op=True)
+            done += len(grp)
+
+    def drain():
+        if dist_on:
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
+            for ln in lanes:
+                if ln["pending"] is not None:
+                    ln["pending"].wait()
+                    ln["pending"] = None
+
+    run_steps(0, args.warmup)
+    drain()
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        labels = step(i)
-    if world > 1 and pending[0] is not None:
-        pending[0].wait()
+    run_steps(0, args.steps)
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -188,13 +245,15 @@ def main():
             "config": {"workload": f"C2: ViT-B/16 CLIP encoder + ZUTIS head, {B}x3x{S}x{S} per GPU, {n} classes, "
                                    f"predict(semantic,size=({S},{S}))", "global_batch": world * B, "image_size": S,
                        "n_classes": n, "parallelism": f"dp{world}", "accumulate": "f32", "residual_stream": "f32",
-                       "collective": "all_gather(low-res logits) per step, overlapped" if world > 1 else "none",
+                       "collective": "all_gather(low-res logits) per step, overlapped" if dist_on else "none",
+                       "steps_in_flight": n_lanes,
+                       "launch": ("native launch plans, interleaved on %d HIP streams" % n_lanes) if n_lanes > 1 else "eager, 1 stream",
                        "flops_per_image": FLOPS_PER_IMAGE_C2},
             "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1),
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

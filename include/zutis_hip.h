@@ -182,6 +182,8 @@ int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, i
  * each; dispatcher generated from this header) in one C loop; zh_plan_run2 alternates two plans on two streams. */
 int zh_plan_run(const void* cmds, int n, zh_stream_t stream);
 int zh_plan_run2(const void* cmds_a, int na, zh_stream_t stream_a, const void* cmds_b, int nb, zh_stream_t stream_b);
+/* `count` plans round-robin on `count` streams (launch i of every plan before launch i+1 of any). */
+int zh_plan_run_multi(const void* const* cmds, const int* n, const zh_stream_t* streams, int count);
 /* Name of the entry point the library dispatches plan op `op` to (NULL if out of range): the host checks it against its
  * own table so that a stale library cannot mis-dispatch. */
 const char* zh_plan_op_name(int op);

@@ -60,6 +60,7 @@ _SIGS = {
     "zh_bilateral_solve": (_i, [_vp, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "zh_plan_op_name": (C.c_char_p, [_i]),
     "zh_plan_run": (_i, [_vp, _i, _vp]),
+    "zh_plan_run_multi": (_i, [_vp, _vp, _vp, _i]),
     "zh_plan_run2": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "zh_mask_iou_workspace_size": (_sz, [_i, _l]),
     "zh_mask_iou_counts": (_i, [_vp, _i, _l, _vp, _vp, _vp, _sz, _vp]),

@@ -35,7 +35,17 @@ struct GemmArgs {
   const float* bias;
   const float* R; long ldr, sR; int res_rows;
   int M, N, K, act, nbm, nbn, vec_ok;
+#ifdef ZH_GEMM_PROBE
+  long long* probe;   // developer build (tools/gemm_probe.py): 4 timestamps per block
+#endif
 };
+#ifdef ZH_GEMM_PROBE
+static long long* g_probe = nullptr;
+extern "C" void zh_gemm_set_probe(long long* p) { g_probe = p; }
+#define ZH_PROBE(i) do { if (p.probe && tid == 0) { p.probe[(long)blockIdx.x * 8 + (i)] = wall_clock64(); p.probe[(long)blockIdx.x * 8 + 4 + (i)] = clock64(); } } while (0)
+#else
+#define ZH_PROBE(i)
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -77,6 +87,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
+  ZH_PROBE(0);
 
   // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous id range
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -164,9 +175,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   // LDS fragment read or one LDS-DMA issue of the NEXT slices; the wave's stream stays MFMA-paced instead of
   // front-loading 16 memory instructions behind the barrier.
   auto steady = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
+#ifndef ZH_X_NOBAR
     wait_vmcnt_barrier<AHEAD * NP>();
+#endif
+#ifndef ZH_X_NODMA
     issue_stage((kt + STAGES - 1) % STAGES);
+#endif
+#ifndef ZH_X_NOFRAG
     load_frags(kt + 1, na, nw);
+#endif
     mfma_all(fa, fw);
     constexpr int NMEM = TM + TN + NP, NMFMA = TM * TN;
     if (NMFMA >= NMEM) {
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   };
   if (nk >= STAGES - 1) wait_vmcnt_barrier<(STAGES - 2) * NP>();   // stage 0 landed; the other STAGES-2 may still be in flight
   else wait_vmcnt_barrier<0>();                                     // short K: not worth a counted wait
+  ZH_PROBE(1);
   load_frags(0, fa0, fw0);
   int kt = 0;
   for (; kt + STAGES < nk; kt += 2) {
@@ -204,6 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     tail(kt + 1, fa1, fw1, fa0, fw0);
   }
 
+  ZH_PROBE(2);
   // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4).  ACT / VEC are template
   // parameters: a runtime switch unrolled 32x blew the instruction cache (fc GEMM 1.4x slower in the model).
   const long cb = (long)batch * p.sC;
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
         if (m < p.M && n < p.N) {
           if (!OUT_F16 && R) d += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
-          if (OUT_F16) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
+if (OUT_F16) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
           else *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
         }
       }
@@ -305,6 +324,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       }
     }
   }
+#ifdef ZH_GEMM_PROBE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ZH_PROBE(3);
+#endif
 }
 
 template <int WM, int WN, int TM, int TN, int STAGES, int OUT_F16, int ACT, int VEC>
@@ -359,6 +382,9 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   p.C = C; p.ldc = ldc; p.sC = strideC;
   p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
   p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
+#ifdef ZH_GEMM_PROBE
+  p.probe = g_probe;
+#endif
   const int esz = out_f16 ? 2 : 4;
   p.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && (strideC % 4 == 0) && (((uintptr_t)C & (4 * esz - 1)) == 0) &&
              (!bias || ((uintptr_t)bias & 15) == 0) &&

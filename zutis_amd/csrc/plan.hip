@@ -47,3 +47,13 @@ extern "C" int zh_plan_run2(const void* cmds_a, int na, zh_stream_t stream_a, co
   }
   return ZH_OK;
 }
+
+extern "C" int zh_plan_run_multi(const void* const* cmds, const int* n, const zh_stream_t* streams, int count) {
+  ZH_CHECK_ARG(cmds && n && streams && count > 0, "zh_plan_run_multi: bad arguments");
+  int longest = 0;
+  for (int j = 0; j < count; ++j) longest = n[j] > longest ? n[j] : longest;
+  for (int i = 0; i < longest; ++i)
+    for (int j = 0; j < count; ++j)
+      if (i < n[j]) { const int rc = zh_dispatch(((const ZhCmd*)cmds[j])[i], streams[j]); if (rc != ZH_OK) return rc; }
+  return ZH_OK;
+}
