@@ -59,6 +59,22 @@ int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long 
                      const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                      int batch, int heads, int Tq, int Tk, int head_dim, float scale, zh_stream_t stream);
 
+/* The same under CLIP's causal mask (build_attention_mask, clip_arch.py:525-531: -inf above the diagonal), Tq = Tk = T:
+ * the text tower's resblocks (clip_arch.py:534-541). */
+int zh_attention_causal_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                            const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
+                            int batch, int heads, int T, int head_dim, float scale, zh_stream_t stream);
+
+/* Text tower glue.  x = token_embedding(text) + positional_embedding (clip_arch.py:535-537): tokens int64 [n,ctx],
+ * table f32 [vocab,D], pos f32 [ctx,D] -> out f32 [n*ctx, D]. */
+int zh_embed_tokens_f32(const long long* tokens, const float* table, const float* pos, float* out, long n, int ctx, int D,
+                        int vocab, zh_stream_t stream);
+/* x[arange(n), text.argmax(-1)] (clip_arch.py:545): x f32 [n*ctx, D] -> out f32 [n, D]; first maximum on ties. */
+int zh_eot_rows_f32(const long long* tokens, const float* x, float* out, long n, int ctx, int D, zh_stream_t stream);
+/* Prompt ensembling tail (utils/extract_text_embeddings.py:110-112): x f32 [groups,T,E] unit-norm rows ->
+ * out[g] = mean_t x[g,t] / ||mean_t x[g,t]||. */
+int zh_group_mean_l2norm(const float* x, float* out, int groups, int T, int E, zh_stream_t stream);
+
 /* Row LayerNorm (biased variance, eps inside sqrt): clip_arch.py:286-292, transformer.py:249-251, 140-150.
  * in_row(r) = (r / in_group_rows)*in_group_stride + in_offset + r % in_group_rows   (drops the cls token for ln_post,
  * clip_arch.py:403-404); out_row(r) uses the same form (stacks decoder layers as [B,L,Q,D], transformer.py:140-150).

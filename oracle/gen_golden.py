@@ -224,6 +224,49 @@ def gen_bilateral():
     np.savez_compressed(os.path.join(GOLD, "bilateral.npz"), **d)
 
 
+def gen_text():
+    """CLIP.encode_text (clip_arch.py:534-547) of the REAL reference class + the prompt-ensembling loop of
+    utils/extract_text_embeddings.py:98-115 (run through the reference function with a stub tokenizer)."""
+    install_stubs(detgen.TINY)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from networks.clip_arch import CLIP
+    d = {}
+    for tag, tc, n in (("tiny", detgen.TEXT_TINY, 9), ("b", detgen.TEXT_B, 6)):
+        m = CLIP(embed_dim=tc.embed_dim, image_resolution=32, vision_layers=1, vision_width=64, vision_patch_size=16,
+                 context_length=tc.context_length, vocab_size=tc.vocab_size, transformer_width=tc.width,
+                 transformer_heads=tc.heads, transformer_layers=tc.layers).float().eval()
+        sd = {k: torch.from_numpy(v) for k, v in detgen.clip_text_state_dict(tc).items()}
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.startswith("visual.") or k == "logit_scale" for k in missing), (missing, unexpected)
+        tok = torch.from_numpy(detgen.text_tokens(n, tc))
+        with torch.no_grad():
+            d[f"{tag}_encode_text"] = m.encode_text(tok).numpy()
+        if tag == "tiny":
+            # the reference's own ensembling loop, with clip.tokenize replaced by our deterministic token rows
+            import clip as clip_stub
+            import utils.extract_text_embeddings as ete
+            C, T = 3, 5
+            toks = torch.from_numpy(detgen.text_tokens(C * T, tc, seed=23)).view(C, T, -1)
+            table = {f"cat{c}": toks[c] for c in range(C)}
+            clip_stub.tokenize = lambda texts: _FakeCuda(table[texts[0].split("|")[1]])
+            ete.clip = clip_stub
+            ete.tqdm = lambda x: x
+            res = ete.extract_text_embeddings(m, [f"cat{c}" for c in range(C)], [f"t{t}|{{}}|" for t in range(T)])
+            d["tiny_prompt_ensemble"] = np.stack([res[f"cat{c}"].numpy() for c in range(C)])
+    np.savez_compressed(os.path.join(GOLD, "text.npz"), **d)
+    print("text.npz", {k: v.shape for k, v in d.items()})
+
+
+class _FakeCuda:
+    """`clip.tokenize(texts).cuda()` in the reference loop: hand the CPU tensor back."""
+    def __init__(self, t):
+        self.t = t
+
+    def cuda(self):
+        return self.t
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
     os.makedirs(GOLD, exist_ok=True)
@@ -231,12 +274,16 @@ if __name__ == "__main__":
     if "--bilateral-only" in sys.argv:
         gen_bilateral()
         sys.exit(0)
+    if "--text-only" in sys.argv:
+        gen_text()
+        sys.exit(0)
     if "--selfmask-only" in sys.argv:
         gen_selfmask()
         sys.exit(0)
     gen_ops()
     gen_selfmask()
     gen_bilateral()
+    gen_text()
     gen_e2e("tiny", detgen.TINY, b=2, H=80, W=112, n_cat=7, size=(80, 112), full=True)
     gen_e2e("vitb16_336", detgen.VIT_B16, b=1, H=336, W=336, n_cat=81, size=(336, 336), full=False)
     gen_e2e("vitb32_224", detgen.VIT_B32, b=1, H=224, W=224, n_cat=81, size=(224, 224), full=False)

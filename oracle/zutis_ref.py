@@ -42,7 +42,7 @@ def layer_norm(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float =
 
 
 def mha(q_in: Tensor, k_in: Tensor, v_in: Tensor, in_w: Tensor, in_b: Tensor,
-        out_w: Tensor, out_b: Tensor, n_heads: int) -> Tensor:
+        out_w: Tensor, out_b: Tensor, n_heads: int, attn_mask: Optional[Tensor] = None) -> Tensor:
     """nn.MultiheadAttention forward (packed in_proj rows = [Wq;Wk;Wv]), batch-first.
 
     Reference call sites: networks/clip_arch.py:314-316 (self-attention, need_weights=False)
@@ -56,6 +56,8 @@ def mha(q_in: Tensor, k_in: Tensor, v_in: Tensor, in_w: Tensor, in_b: Tensor,
     k = F.linear(k_in, in_w[D:2 * D], in_b[D:2 * D]).view(B, Tk, n_heads, dh).transpose(1, 2)
     v = F.linear(v_in, in_w[2 * D:], in_b[2 * D:]).view(B, Tk, n_heads, dh).transpose(1, 2)
     s = torch.matmul(q * (1.0 / math.sqrt(dh)), k.transpose(-1, -2))
+    if attn_mask is not None:                    # additive float mask [Tq,Tk] (clip_arch.py:525-531: -inf above the diagonal)
+        s = s + attn_mask
     p = torch.softmax(s, dim=-1)
     o = torch.matmul(p, v).transpose(1, 2).reshape(B, Tq, D)
     return F.linear(o, out_w, out_b)
@@ -118,6 +120,42 @@ def clip_encode_image(P: Dict[str, Tensor], x: Tensor, patch: int, prefix: str =
         t = t + F.linear(y, P[p + "mlp.c_proj.weight"], P[p + "mlp.c_proj.bias"])
     e = layer_norm(t[:, 0], P[prefix + "ln_post.weight"], P[prefix + "ln_post.bias"]) @ P[prefix + "proj"]
     return e / e.norm(dim=-1, keepdim=True)
+
+
+def clip_encode_text(P: Dict[str, Tensor], tokens: Tensor, prefix: str = "") -> Tensor:
+    """networks/clip_arch.py:534-547 CLIP.encode_text: token embedding + positional embedding, pre-LN resblocks (:318-321)
+    under the causal mask of build_attention_mask (:525-531), ln_final, the EOT row (argmax of the token ids) @
+    text_projection.  tokens int64 [n, ctx] -> f32 [n, embed] (NOT normalised).  heads = width // 64 (:606)."""
+    n, ctx = tokens.shape
+    D = P[prefix + "positional_embedding"].shape[1]
+    heads = D // 64
+    t = P[prefix + "token_embedding.weight"][tokens] + P[prefix + "positional_embedding"][None]
+    mask = torch.full((ctx, ctx), float("-inf")).triu_(1)
+    k0 = len((prefix + "transformer.resblocks.").split(".")) - 1
+    n_layers = 1 + max(int(k.split(".")[k0]) for k in P if k.startswith(prefix + "transformer.resblocks."))
+    for i in range(n_layers):
+        p = f"{prefix}transformer.resblocks.{i}."
+        y = layer_norm(t, P[p + "ln_1.weight"], P[p + "ln_1.bias"])
+        t = t + mha(y, y, y, P[p + "attn.in_proj_weight"], P[p + "attn.in_proj_bias"],
+                    P[p + "attn.out_proj.weight"], P[p + "attn.out_proj.bias"], heads, attn_mask=mask)
+        y = layer_norm(t, P[p + "ln_2.weight"], P[p + "ln_2.bias"])
+        y = F.linear(y, P[p + "mlp.c_fc.weight"], P[p + "mlp.c_fc.bias"])
+        y = y * torch.sigmoid(1.702 * y)
+        t = t + F.linear(y, P[p + "mlp.c_proj.weight"], P[p + "mlp.c_proj.bias"])
+    t = layer_norm(t, P[prefix + "ln_final.weight"], P[prefix + "ln_final.bias"])
+    return t[torch.arange(n), tokens.argmax(dim=-1)] @ P[prefix + "text_projection"]
+
+
+def prompt_ensemble(P: Dict[str, Tensor], tokens: Tensor, prefix: str = "") -> Tensor:
+    """utils/extract_text_embeddings.py:98-115: per category, encode the T prompts, L2-normalise each, average, L2-normalise.
+    tokens int64 [C, T, ctx] -> f32 [C, embed]."""
+    out = []
+    for c in range(tokens.shape[0]):
+        e = clip_encode_text(P, tokens[c], prefix)
+        e = e / e.norm(dim=-1, keepdim=True)
+        m = e.mean(dim=0)
+        out.append(m / m.norm())
+    return torch.stack(out)
 
 
 # --------------------------------------------------------------------------- head

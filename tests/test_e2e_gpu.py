@@ -1,4 +1,5 @@
 """-m gpu: the HIP engine end to end against (a) the reference's golden outputs and (b) the CPU oracle."""
+import math
 import numpy as np
 import pytest
 import torch
@@ -328,3 +329,54 @@ def test_launch_plan_replay_matches_eager(dev):
     torch.cuda.synchronize()
     assert torch.equal(p["labels"], ref_eng.predict_semantic(ref_eng.forward(xa)["patch_tokens"], text, (80, 112)))
     assert torch.equal(pb["labels"], ref_eng.predict_semantic(ref_eng.forward(xb)["patch_tokens"], text, (80, 112)))
+
+
+@pytest.mark.parametrize("tag,cfgname,n", [("tiny", "TEXT_TINY", 9), ("b", "TEXT_B", 6)])
+def test_text_tower_matches_reference_golden(dev, golden_dir, tag, cfgname, n):
+    """ClipTextEncoder.encode_text vs CLIP.encode_text of the real reference (clip_arch.py:534-547, golden) and the oracle;
+    prompt ensembling vs the reference's extract_text_embeddings loop.  fp32 logits tolerance 1e-3 applies to the unit-norm
+    embeddings; raw (un-normalised) embeddings are O(1..10) and are compared relatively."""
+    from zutis_amd import detgen
+    from zutis_amd.engine import ClipTextEncoder
+    from oracle import zutis_ref as O
+    g = np.load(f"{golden_dir}/text.npz")
+    tc = getattr(detgen, cfgname)
+    sd = detgen.clip_text_state_dict(tc)
+    eng = ClipTextEncoder({k: torch.from_numpy(v).to(dev) for k, v in sd.items()})
+    tok = torch.from_numpy(detgen.text_tokens(n, tc))
+    e = eng.encode_text(tok.to(dev)).cpu().numpy()
+    ref = g[f"{tag}_encode_text"]
+    un = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)
+    assert np.abs(un(e) - un(ref)).max() < 1e-3
+    assert np.abs(e - ref).max() < 2e-3 * np.abs(ref).max()
+    if tag == "tiny":
+        toks = torch.from_numpy(detgen.text_tokens(15, tc, seed=23)).view(3, 5, -1)
+        pe = eng.prompt_ensemble(toks.to(dev)).cpu().numpy()
+        assert np.abs(pe - g["tiny_prompt_ensemble"]).max() < 1e-3
+        assert np.abs(np.linalg.norm(pe, axis=1) - 1).max() < 1e-6
+        # chunked == unchunked, and the drop-in model object through a reference-shaped loop
+        eng2 = ClipTextEncoder({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, chunk=4)
+        assert torch.equal(eng2.encode_text(tok.to(dev)).cpu(), torch.from_numpy(e))
+        from zutis_amd.dropin.networks.clip_text import HipClipText, prompt_engineering_batched
+        m = HipClipText({k: torch.from_numpy(v) for k, v in sd.items()}, device=dev)
+        table = {f"t{t}|cat{c}|": toks[c, t] for c in range(3) for t in range(5)}
+        res = prompt_engineering_batched(m, lambda texts: torch.stack([table[s] for s in texts]), [f"cat{c}" for c in range(3)],
+                                         [f"t{t}|{{}}|" for t in range(5)])
+        assert np.abs(np.stack([res[f"cat{c}"].cpu().numpy() for c in range(3)]) - g["tiny_prompt_ensemble"]).max() < 1e-3
+        with pytest.raises(IndexError):
+            eng.encode_text(torch.full((1, tc.context_length), tc.vocab_size, dtype=torch.int64))
+
+
+def test_causal_attention_kernel(dev):
+    from zutis_amd import ops
+    for (B, H, dh, T) in [(2, 2, 64, 77), (1, 3, 64, 200), (2, 1, 96, 130)]:
+        D = H * dh
+        g = torch.Generator().manual_seed(T)
+        q, k, v = (torch.randn((B, T, D), generator=g).half() for _ in range(3))
+        qh, kh, vh = (t.float().view(B, T, H, dh).transpose(1, 2) for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2) / math.sqrt(dh) + torch.full((T, T), float("-inf")).triu_(1)
+        ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, D)
+        o = torch.empty((B, T, D), dtype=torch.float16, device=dev)
+        ops.attention(q.to(dev), k.to(dev), v.to(dev), o, batch=B, heads=H, Tq=T, Tk=T, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D,
+                      strideQ=T * D, strideK=T * D, strideV=T * D, strideO=T * D, causal=True)
+        assert (o.float().cpu() - ref).abs().max().item() < 4e-3

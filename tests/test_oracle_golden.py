@@ -139,3 +139,23 @@ def test_bilateral_oracle_matches_reference(golden_dir):
     x = detgen.det_normal("denorm", (3, 40, 56))
     x[0, 0, :16] = ((np.arange(16) * 16 / 255.0 - 0.485) / 0.229).astype(np.float32)
     assert np.array_equal(B.denormalize_to_u8(x), g["denorm_u8"])
+
+
+@pytest.mark.parametrize("tag,cfgname,n", [("tiny", "TEXT_TINY", 9), ("b", "TEXT_B", 6)])
+def test_text_oracle_matches_reference(golden_dir, tag, cfgname, n):
+    """oracle clip_encode_text vs CLIP.encode_text of the real reference class (clip_arch.py:534-547); the prompt
+    ensembling vs the reference's own extract_text_embeddings loop (utils/extract_text_embeddings.py:98-115)."""
+    g = np.load(f"{golden_dir}/text.npz")
+    tc = getattr(detgen, cfgname)
+    P = O.to_torch_params(detgen.clip_text_state_dict(tc))
+    tok = torch.from_numpy(detgen.text_tokens(n, tc))
+    assert (tok.max(dim=1).values == tc.vocab_size - 1).all() and (tok[:, 0] == tc.vocab_size - 2).all()
+    with torch.no_grad():
+        e = O.clip_encode_text(P, tok).numpy()
+    assert np.abs(e - g[f"{tag}_encode_text"]).max() < 1e-5      # 12 fp32 layers; values O(1)
+    if tag == "tiny":
+        toks = torch.from_numpy(detgen.text_tokens(15, tc, seed=23)).view(3, 5, -1)
+        with torch.no_grad():
+            pe = O.prompt_ensemble(P, toks).numpy()
+        assert np.abs(pe - g["tiny_prompt_ensemble"]).max() < 1e-6
+        assert np.abs(np.linalg.norm(pe, axis=1) - 1).max() < 1e-6

@@ -31,6 +31,10 @@ _SIGS = {
     "zh_last_error": (C.c_char_p, []),
     "zh_gemm_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "zh_attention_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _vp]),
+    "zh_attention_causal_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _f, _vp]),
+    "zh_embed_tokens_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "zh_eot_rows_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "zh_group_mean_l2norm": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "zh_layernorm_f32": (_i, [_vp, _l, _l, _l, _l, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "zh_assemble_tokens_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "zh_l2norm_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),

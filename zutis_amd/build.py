@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzutis_hip.so")
 # float64 bilateral solver: no FMA contraction (bin edges and bistochastisation are bit-compared with NumPy/SciPy)
 EXTRA_FLAGS = {"bilateral.hip": ["-ffp-contract=off"]}
-SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip", "plan.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip", "text.hip", "plan.hip"]
 
 
 def _hipcc() -> str:

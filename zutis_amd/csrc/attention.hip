@@ -24,6 +24,7 @@ struct AttnArgs {
   half_t* O; long ldo, sO;
   int Tq, Tk, H;
   float scale_log2;
+  int causal;       // keys > query masked (CLIP text tower, clip_arch.py:525-531)
 };
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -104,7 +105,12 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   const int tr_row = 8 * hh + ((lane & 15) >> 2);
   const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
-  const int ntiles = (p.Tk + KT - 1) / KT;
+  int ntiles = (p.Tk + KT - 1) / KT;
+  if (p.causal) {                                           // key tiles entirely above this block's last query are skipped
+    const int qlast = min(p.Tq, (int)(blockIdx.x + 1) * (32 * NWAVE)) - 1;
+    ntiles = min(ntiles, qlast / KT + 1);
+  }
+  const int qidx = q0 + ql;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -130,13 +136,13 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
     }
     // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
     float mx = -INFINITY;
-    if (kbase + KT > p.Tk) {                    // last tile only: keys beyond Tk score -inf
+    if (kbase + KT > p.Tk || (p.causal && kbase + KT - 1 > q0)) {   // ragged last tile / tiles crossing the diagonal
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kbase + 32 * u + 16 * (r >> 3) + 8 * hh + (r & 7);
-          if (key >= p.Tk) s[u][r] = -INFINITY;
+          if (key >= p.Tk || (p.causal && key > qidx)) s[u][r] = -INFINITY;
         }
     }
 #pragma unroll
@@ -204,10 +210,10 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   }
 }
 
-extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
-                                const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
-                                int batch, int heads, int Tq, int Tk, int head_dim, float scale,
-                                hipStream_t stream) {
+static int attention_launch(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                            const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
+                            int batch, int heads, int Tq, int Tk, int head_dim, float scale, int causal,
+                            hipStream_t stream) {
   ZH_CHECK_ARG(Q && K && V && O, "zh_attention_f16: null operand");
   ZH_CHECK_ARG(batch > 0 && heads > 0 && Tq > 0 && Tk > 0, "zh_attention_f16: bad shape");
   ZH_CHECK_ARG(head_dim == 64 || head_dim == 96, "zh_attention_f16: head_dim %d not in {64, 96}", head_dim);
@@ -224,6 +230,7 @@ extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const voi
   p.O = (half_t*)O; p.ldo = ldo; p.sO = strideO;
   p.Tq = Tq; p.Tk = Tk; p.H = heads;
   p.scale_log2 = scale * 1.4426950408889634f;
+  p.causal = causal;
   // 128-query (4-wave) blocks: each K/V tile is shared four ways.  A 64-query (2-wave) variant was measured slower on
   // every shape of the model (encoder 301 vs 423 TF, cross-attention 230 vs 397 TF) and was dropped.
   dim3 grid(zh_cdiv(Tq, 128), heads, batch);
@@ -231,4 +238,19 @@ extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const voi
   else hipLaunchKernelGGL((attn_f16_kernel<96, 4>), grid, dim3(256), 0, stream, p);
   ZH_CHECK_LAUNCH("zh_attention_f16");
   return ZH_OK;
+}
+
+extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                                const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
+                                int batch, int heads, int Tq, int Tk, int head_dim, float scale,
+                                hipStream_t stream) {
+  return attention_launch(Q, ldq, strideQ, K, ldk, strideK, V, ldv, strideV, O, ldo, strideO, batch, heads, Tq, Tk, head_dim,
+                          scale, 0, stream);
+}
+
+extern "C" int zh_attention_causal_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                                       const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
+                                       int batch, int heads, int T, int head_dim, float scale, hipStream_t stream) {
+  return attention_launch(Q, ldq, strideQ, K, ldk, strideK, V, ldv, strideV, O, ldo, strideO, batch, heads, T, T, head_dim,
+                          scale, 1, stream);
 }

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   constexpr int ROWS = BM + BN;             // LDS rows per stage (A rows then W rows), 64 B each
   constexpr int PIECES = ROWS / 16;         // 1-KiB DMA pieces per stage
   constexpr int NP = (PIECES + NW - 1) / NW;  // DMA issues per wave per stage (duplicates pad uneven splits)
-  static_assert(NP >= 2 && NP <= 5 && STAGES >= 4 && STAGES <= 8, "unsupported pieces-per-wave count / ring depth");
+  static_assert(NP >= 2 && NP <= 8 && STAGES >= 4 && STAGES <= 8, "unsupported pieces-per-wave count / ring depth");
   constexpr int AHEAD = STAGES - 3;           // whole stages that may still be in flight at a steady-state barrier
   constexpr int STAGE_HALVES = ROWS * BK;
   __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE_HALVES];
@@ -329,6 +329,7 @@ if (OUT_F16) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
   ZH_PROBE(3);
 #endif
 }
+
 
 template <int WM, int WN, int TM, int TN, int STAGES, int OUT_F16, int ACT, int VEC>
 static void launch_one(GemmArgs p, int batch, hipStream_t stream) {

@@ -193,6 +193,71 @@ def selfmask_state_dict(seed: int = 4321) -> "OrderedDict[str, np.ndarray]":
                        for k, (shp, std, mean) in selfmask_param_shapes().items())
 
 
+@dataclass(frozen=True)
+class ClipTextConfig:
+    """CLIP text tower hyper-parameters (networks/clip_arch.py:443-447,484-495; ViT-B/16 + ViT-B/32 checkpoints: ctx 77,
+    vocab 49408, width 512, 8 heads = width // 64, 12 layers, embed 512)."""
+    context_length: int = 77
+    vocab_size: int = 49408
+    width: int = 512
+    layers: int = 12
+    embed_dim: int = 512
+
+    @property
+    def heads(self) -> int:
+        return self.width // 64
+
+
+TEXT_B = ClipTextConfig()
+TEXT_TINY = ClipTextConfig(context_length=12, vocab_size=96, width=128, layers=2, embed_dim=64)
+
+
+def clip_text_param_shapes(cfg: ClipTextConfig):
+    """CLIP state_dict keys of the text tower (clip_arch.py:484-495); stds follow CLIP.initialize_parameters (:497-523)."""
+    D, L = cfg.width, cfg.layers
+    attn_std, proj_std, fc_std = D ** -0.5, (D ** -0.5) * ((2 * L) ** -0.5), (2 * D) ** -0.5
+    P = OrderedDict()
+    P["token_embedding.weight"] = ((cfg.vocab_size, D), 0.02, 0.0)
+    P["positional_embedding"] = ((cfg.context_length, D), 0.01, 0.0)
+    for i in range(L):
+        p = f"transformer.resblocks.{i}."
+        P[p + "attn.in_proj_weight"] = ((3 * D, D), attn_std, 0.0)
+        P[p + "attn.in_proj_bias"] = ((3 * D,), 0.02, 0.0)
+        P[p + "attn.out_proj.weight"] = ((D, D), proj_std, 0.0)
+        P[p + "attn.out_proj.bias"] = ((D,), 0.02, 0.0)
+        P[p + "ln_1.weight"] = ((D,), 0.1, 1.0)
+        P[p + "ln_1.bias"] = ((D,), 0.1, 0.0)
+        P[p + "mlp.c_fc.weight"] = ((4 * D, D), fc_std, 0.0)
+        P[p + "mlp.c_fc.bias"] = ((4 * D,), 0.02, 0.0)
+        P[p + "mlp.c_proj.weight"] = ((D, 4 * D), proj_std, 0.0)
+        P[p + "mlp.c_proj.bias"] = ((D,), 0.02, 0.0)
+        P[p + "ln_2.weight"] = ((D,), 0.1, 1.0)
+        P[p + "ln_2.bias"] = ((D,), 0.1, 0.0)
+    P["ln_final.weight"] = ((D,), 0.1, 1.0)
+    P["ln_final.bias"] = ((D,), 0.1, 0.0)
+    P["text_projection"] = ((D, cfg.embed_dim), D ** -0.5, 0.0)
+    return P
+
+
+def clip_text_state_dict(cfg: ClipTextConfig, seed: int = 2468):
+    return OrderedDict((k, det_normal("text." + k, shp, std, mean, seed)) for k, (shp, std, mean) in clip_text_param_shapes(cfg).items())
+
+
+def text_tokens(n: int, cfg: ClipTextConfig, seed: int = 11) -> np.ndarray:
+    """int64 [n, ctx] shaped like clip.tokenize output: SOT (= vocab-2), 1 .. ctx-2 body tokens, EOT (= vocab-1, the
+    unique maximum: encode_text locates it with argmax, clip_arch.py:545), zero padding."""
+    u = np.abs(det_normal("tokens", (n, cfg.context_length), 1.0, 0.0, seed))
+    body = 1 + (u * 1e6).astype(np.int64) % (cfg.vocab_size - 3)
+    lens = 1 + (np.abs(det_normal("token_lens", (n,), 1.0, 0.0, seed)) * 1e6).astype(np.int64) % (cfg.context_length - 2)
+    out = np.zeros((n, cfg.context_length), dtype=np.int64)
+    for i in range(n):
+        L = int(lens[i])
+        out[i, 0] = cfg.vocab_size - 2
+        out[i, 1:1 + L] = body[i, :L]
+        out[i, 1 + L] = cfg.vocab_size - 1
+    return out
+
+
 def text_embeddings(n_categories: int, dim: int, seed: int = 7) -> np.ndarray:
     """Unit-norm rows standing in for CLIP text embeddings (networks/zutis.py:36-37)."""
     t = det_normal("text_embeddings", (n_categories, dim), seed=seed).astype(np.float64)

@@ -113,6 +113,12 @@ class _EngineBase:
         w["conv"] = wc
         for name in ("class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias", "ln_post.weight", "ln_post.bias"):
             w["encoder." + name] = c32(P[prefix + name])
+        self._pack_resblocks(w, P, prefix, layers)
+        w["projT"] = h(P[prefix + "proj"].detach().t())                                # [E, D]
+
+    def _pack_resblocks(self, w, P, prefix: str, layers: int):
+        """{prefix}transformer.resblocks.{i}.* (ResidualAttentionBlock, clip_arch.py:300-321) -> enc.{i}.*"""
+        h, c32 = self._h, self._c32
         for i in range(layers):
             p, q = f"{prefix}transformer.resblocks.{i}.", f"enc.{i}."
             w[q + "qkv_w"], w[q + "qkv_b"] = h(P[p + "attn.in_proj_weight"]), c32(P[p + "attn.in_proj_bias"])
@@ -121,7 +127,6 @@ class _EngineBase:
             w[q + "proj_w"], w[q + "proj_b"] = h(P[p + "mlp.c_proj.weight"]), c32(P[p + "mlp.c_proj.bias"])
             for ln, ln2 in (("ln_1", "ln1"), ("ln_2", "ln2")):
                 w[q + ln2 + ".w"], w[q + ln2 + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
-        w["projT"] = h(P[prefix + "proj"].detach().t())                                # [E, D]
 
     def _clip_trunk(self, x: torch.Tensor, pos: torch.Tensor, h: int, w: int):
         """conv1-as-GEMM, cls concat + pos + ln_pre, all resblocks (clip_arch.py:378-401).  Returns X f32 [B*T, D]."""
@@ -138,7 +143,7 @@ class _EngineBase:
         self._vit_blocks(X, B, T, D, self.heads, self.layers, 1e-5, ops.ACT_QUICKGELU)     # :318-321
         return X
 
-    def _vit_blocks(self, X, B, T, D, heads, n_layers, eps, act):
+    def _vit_blocks(self, X, B, T, D, heads, n_layers, eps, act, causal=False):
         """Pre-LN transformer blocks on the fp32 residual stream X [B*T, D] (in place).
         clip_arch.py:318-321 (QuickGELU, eps 1e-5) and selfmask/vision_transformer.py:160-170 (erf GELU, eps 1e-6)."""
         W_, R = self._w, B * T
@@ -152,7 +157,7 @@ class _EngineBase:
             ops.gemm(Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
             ops.attention(QKV, QKV[:, D:], QKV[:, 2 * D:], O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=D // heads,
                           ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
-                          strideO=T * D)
+                          strideO=T * D, causal=causal)
             ops.gemm(O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
             ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y)
             ops.gemm(Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
@@ -508,6 +513,76 @@ class ClipImageEncoder(_EngineBase):
         ops.gemm(cls16, W_["projT"], e32)                                                   # @ proj
         out = torch.empty((B, self.E), dtype=f32, device=x.device)
         ops.l2norm_rows(e32, B, self.E, out_f32=out)                                        # / norm(dim=-1)
+        return out
+
+
+class ClipTextEncoder(_EngineBase):
+    """CLIP text tower: `encode_text` (networks/clip_arch.py:534-547) and the prompt ensembling of
+    utils/extract_text_embeddings.py:98-115.  `params` uses the CLIP state_dict keys under `prefix`
+    (token_embedding.weight, positional_embedding, transformer.resblocks.*, ln_final.*, text_projection);
+    heads = width // 64 (clip_arch.py:606)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], prefix: str = "", chunk: int = 4096):
+        self.params, self.prefix, self.chunk = params, prefix, chunk
+        self.ctx, self.D = params[prefix + "positional_embedding"].shape
+        self.vocab = params[prefix + "token_embedding.weight"].shape[0]
+        self.E = params[prefix + "text_projection"].shape[1]
+        self.heads = self.D // 64
+        k0 = len((prefix + "transformer.resblocks.").split(".")) - 1
+        self.layers = 1 + max(int(k.split(".")[k0]) for k in params if k.startswith(prefix + "transformer.resblocks."))
+        if self.D % 64 or self.E % 4:
+            raise ZutisHipError("ClipTextEncoder: width must be a multiple of 64 and the embedding of 4")
+        self._init_base()
+
+    def _pack(self):
+        key = self._version_key()
+        if key == self._packed_key:
+            return
+        P, pre, w = self.params, self.prefix, {}
+        self._pack_resblocks(w, P, pre, self.layers)
+        w["table"] = self._c32(P[pre + "token_embedding.weight"])
+        w["pos"] = self._c32(P[pre + "positional_embedding"])
+        w["lnf.w"], w["lnf.b"] = self._c32(P[pre + "ln_final.weight"]), self._c32(P[pre + "ln_final.bias"])
+        w["projT"] = self._h(P[pre + "text_projection"].detach().t())                  # [E, D]
+        self._w, self._packed_key = w, key
+
+    def _encode_chunk(self, tok: torch.Tensor, out: torch.Tensor):
+        W_, D, ctx = self._w, self.D, self.ctx
+        n = tok.shape[0]
+        X = self._buf("X", (n * ctx, D), f32)
+        ops.embed_tokens(tok, W_["table"], W_["pos"], X)                               # :535-537
+        self._vit_blocks(X, n, ctx, D, self.heads, self.layers, 1e-5, ops.ACT_QUICKGELU, causal=True)   # :538-540
+        eot = self._buf("eot", (n, D), f32)
+        ops.eot_rows(tok, X, eot)                                                      # :545 (LN is row-wise: gather first)
+        e16 = self._buf("eot16", (n, D), f16)
+        ops.layernorm(eot, W_["lnf.w"], W_["lnf.b"], 1e-5, n, D, out_f16=e16)          # :541 ln_final
+        ops.gemm(e16, W_["projT"], out)                                                # @ text_projection
+
+    def encode_text(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens int64 [n, ctx] (clip.tokenize layout: EOT = the largest id of each row) -> f32 [n, E], not normalised."""
+        self._pack()
+        dev = self._device()
+        if tokens.dim() != 2 or tokens.shape[1] != self.ctx:
+            raise ZutisHipError(f"encode_text: expected tokens [n, {self.ctx}]")
+        tok = tokens.to(device=dev, dtype=torch.int64).contiguous()
+        if tok.numel() and (int(tok.min()) < 0 or int(tok.max()) >= self.vocab):
+            raise IndexError("encode_text: token id out of range")                      # nn.Embedding raises likewise
+        n = tok.shape[0]
+        out = torch.empty((n, self.E), dtype=f32, device=dev)
+        for i in range(0, n, self.chunk):
+            self._encode_chunk(tok[i:i + self.chunk], out[i:i + self.chunk])
+        return out
+
+    def prompt_ensemble(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens int64 [C, T, ctx] (T prompts per category) -> unit-norm f32 [C, E]: encode, L2-normalise every prompt,
+        average over T, L2-normalise (extract_text_embeddings.py:104-113) — all categories in one batch, on device."""
+        C, T, ctx = tokens.shape
+        e = self.encode_text(tokens.reshape(C * T, ctx))
+        if T == 1:
+            return e                                                                    # :107-108: single template -> raw embedding
+        ops.l2norm_rows(e, C * T, self.E, out_f32=e)
+        out = torch.empty((C, self.E), dtype=f32, device=e.device)
+        ops.group_mean_l2norm(e, out, C, T, self.E)
         return out
 
 

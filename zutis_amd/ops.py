@@ -72,14 +72,46 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
 
 
 def attention(Q, K, V, O, *, batch, heads, Tq, Tk, head_dim, ldq, ldk, ldv, ldo, strideQ, strideK, strideV, strideO,
-              scale=None):
+              scale=None, causal=False):
     L = _lib.load()
     scale = 1.0 / math.sqrt(head_dim) if scale is None else scale
+    if causal:
+        if Tq != Tk:
+            raise _lib.ZutisHipError("causal attention needs Tq == Tk")
+        args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
+                batch, heads, Tq, head_dim, float(scale), _stream())
+        _lib.check(_launch("attention_f16", 2.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_causal_f16(*args)),
+                   "zh_attention_causal_f16")
+        return O
     args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
             batch, heads, Tq, Tk, head_dim, float(scale), _stream())
     _lib.check(_launch("attention_f16", 4.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_f16(*args)),
                "zh_attention_f16")
     return O
+
+
+def embed_tokens(tokens, table, pos, out):
+    """tokens int64 [n,ctx] -> out f32 [n*ctx, D] = table[tokens] + pos (clip_arch.py:535-537)."""
+    L = _lib.load()
+    n, ctx = tokens.shape
+    _chk(table, f32, "token table"); _chk(pos, f32, "positional embedding"); _chk(out, f32, "embed out")
+    if tokens.dtype != torch.int64 or not tokens.is_contiguous():
+        raise _lib.ZutisHipError("embed_tokens: tokens must be contiguous int64")
+    _lib.check(L.zh_embed_tokens_f32(_p(tokens), _p(table), _p(pos), _p(out), n, ctx, table.shape[1], table.shape[0], _stream()),
+               "zh_embed_tokens_f32")
+
+
+def eot_rows(tokens, x, out):
+    L = _lib.load()
+    n, ctx = tokens.shape
+    _chk(x, f32, "eot x"); _chk(out, f32, "eot out")
+    _lib.check(L.zh_eot_rows_f32(_p(tokens), _p(x), _p(out), n, ctx, out.shape[1], _stream()), "zh_eot_rows_f32")
+
+
+def group_mean_l2norm(x, out, groups, T, E):
+    L = _lib.load()
+    _chk(x, f32, "group mean x"); _chk(out, f32, "group mean out")
+    _lib.check(L.zh_group_mean_l2norm(_p(x), _p(out), groups, T, E, _stream()), "zh_group_mean_l2norm")
 
 
 def layernorm(x, gamma, beta, eps, rows, D, *, out_f32=None, out_f16=None, out_f16_plus=None, out_f32_plus=None,
