@@ -197,6 +197,9 @@ def main():
                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "flops_per_launch": round(fl / nl),
                 "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
+                "measured_on": "HIP events around every GEMM launch of an instrumented eager step on one stream (kernels not "
+                               "overlapped); rocprofv3 --stats of `bench.py --inflight 1` = profiles/r01_bench_kernel_stats.csv, "
+                               "of the default two-in-flight run = profiles/r01_bench_inflight2_kernel_stats.csv",
                 "gemm_share_of_step": round(tt / (elapsed / args.steps), 3)}
         if "attention_f16" in stats:
             na, fa, ta = stats["attention_f16"]
@@ -238,18 +241,18 @@ def main():
     if rank == 0:
         total_images = world * B * args.steps
         line = {
-            "metric": "images/sec, COCO2017-val-shaped ViT-B/16 dense semantic segmentation @336px (ZUTIS forward + semantic predict)",
+            "metric": f"images/sec, COCO2017-val-shaped ViT-B/16 dense semantic segmentation @{S}px (ZUTIS forward + semantic predict)",
             "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"C2: ViT-B/16 CLIP encoder + ZUTIS head, {B}x3x{S}x{S} per GPU, {n} classes, "
+            "config": {"workload": f"{'C2' if (S, n) == (336, 81) else 'C4' if (S, n) == (518, 920) else 'custom'}: ViT-B/16 CLIP encoder + ZUTIS head, {B}x3x{S}x{S} per GPU, {n} classes, "
                                    f"predict(semantic,size=({S},{S}))", "global_batch": world * B, "image_size": S,
                        "n_classes": n, "parallelism": f"dp{world}", "accumulate": "f32", "residual_stream": "f32",
                        "collective": "all_gather(low-res logits) per step, overlapped" if dist_on else "none",
                        "steps_in_flight": n_lanes,
                        "launch": ("native launch plans, interleaved on %d HIP streams" % n_lanes) if n_lanes > 1 else "eager, 1 stream",
-                       "flops_per_image": FLOPS_PER_IMAGE_C2},
-            "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1),
+                       "flops_per_image": FLOPS_PER_IMAGE_C2 if (S, n) == (336, 81) else None},
+            "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1) if (S, n) == (336, 81) else None,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)

@@ -121,6 +121,8 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
     const half_t* sV = sVb[t & 1];
     if (t + 1 < ntiles) load_tile(kbase + KT);
 
+    // a wave whose 32 queries all lie beyond Tq (T = 442: two of the last block's four) only helps with the tile loads
+    if (q0 < p.Tq) {
     // ---- S^T = K Q^T  (two 32-key slot tiles)
     f32x16 s[2];
 #pragma unroll
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][ks], oacc[d], 0, 0, 0);
         }
       }
+    }
 
     // buffer (t+1)&1 was last read in iteration t-1; every wave passed the barrier that ended t-1 => free to overwrite
     if (t + 1 < ntiles) store_tile((t + 1) & 1);
