@@ -13,6 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzutis_hip.so")
 # float64 bilateral solver: no FMA contraction (bin edges and bistochastisation are bit-compared with NumPy/SciPy)
 EXTRA_FLAGS = {"bilateral.hip": ["-ffp-contract=off"]}
+# the MFMA kernels live at the register budget of their occupancy: a spill is a 2-3x slowdown, so it is a build error
+NO_SCRATCH = {"gemm.hip", "attention.hip"}
 SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip", "text.hip", "plan.hip"]
 
 
@@ -53,12 +55,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
             continue
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS.get(os.path.basename(src), []) + \
               ["-c", src, "-o", obj]
+        if os.path.basename(src) in NO_SCRATCH:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
+        procs.append((cmd, src, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    for cmd, src, p in procs:
+        _, err = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(err)
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        if os.path.basename(src) in NO_SCRATCH:
+            spills = [ln for ln in err.splitlines() if "ScratchSize [bytes/lane]:" in ln and not ln.split("ScratchSize [bytes/lane]:")[1].strip().startswith("0")]
+            if spills:
+                raise RuntimeError(f"{os.path.basename(src)}: a kernel spills to scratch (register budget exceeded): {spills[0].strip()}")
+        else:
+            sys.stderr.write(err)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

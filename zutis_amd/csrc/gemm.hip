@@ -178,11 +178,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 #ifndef ZH_X_NOBAR
     wait_vmcnt_barrier<AHEAD * NP>();
 #endif
-#ifndef ZH_X_NODMA
-    issue_stage((kt + STAGES - 1) % STAGES);
-#endif
+    // program order = dependence order for the compiler: an LDS-DMA is a write to `smem`, so fragment reads placed after
+    // it can never be scheduled above it.  Reads first, DMA second lets the reads spread under the first MFMAs and the DMA
+    // issues under the last ones (the other order left all 12 ds_read_b128 + their latency exposed at the end of the slice).
 #ifndef ZH_X_NOFRAG
     load_frags(kt + 1, na, nw);
+#endif
+#ifndef ZH_X_NODMA
+    issue_stage((kt + STAGES - 1) % STAGES);
 #endif
     mfma_all(fa, fw);
     constexpr int NMEM = TM + TN + NP, NMFMA = TM * TN;
@@ -203,10 +206,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     if (kt + 1 < nk) {
       // slices issued so far: 0 .. min(nk-1, kt+STAGES-2); slice kt+1 must have landed, the later ones may fly
       wait_stages_barrier<NP, AHEAD>(min(nk - 1, kt + STAGES - 2) - (kt + 1));
+      load_frags(kt + 1, na, nw);                                          // reads before the DMA: see steady()
       if (kt + STAGES - 1 < nk) issue_stage((kt + STAGES - 1) % STAGES);
-      load_frags(kt + 1, na, nw);
     }
-    mfma_all(fa, fw);
+    mfma_all(fa, fw);   // (a sched_group_barrier interleave here makes hipcc spill: 172 scratch ops, 2.6x slower)
   };
   if (nk >= STAGES - 1) wait_vmcnt_barrier<(STAGES - 2) * NP>();   // stage 0 landed; the other STAGES-2 may still be in flight
   else wait_vmcnt_barrier<0>();                                     // short K: not worth a counted wait
