@@ -96,41 +96,71 @@ extern "C" int zh_posembed_bicubic(const float* pos, float* out, int grid, int h
 // ---- x2 bilinear upsample, channels-last tokens (networks/zutis.py:491-495): [B,h,w,D] fp32 -> [B,2h,2w,D]
 //      fp16 and/or fp32.  src = max(0.5*(dst+0.5)-0.5, 0); weights {0.25,0.75} (edges clamp).
 __global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* x, float* out_f32, half_t* out_f16, int B, int h, int w, int D) {
+  // One workgroup per 2x2 output quad {2j+1,2j+2} x {2k+1,2k+2}, j in [-1,h-1], k in [-1,w-1]: the four outputs interpolate the
+  // same four inputs (rows j,j+1 x cols k,k+1, clamped), so every input float4 is loaded once per quad instead of once per
+  // output (the per-output form re-read 4x the tensor through L2 and ran at 2 TB/s).  Each output still evaluates ATen's own
+  // source-index / weight formulas, so results are bit-identical to the per-output kernel.
   const int nv = D >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)B * 4 * h * w * nv;
-  if (idx >= total) return;
-  const int c = (int)(idx % nv);
-  long t = idx / nv;
-  const int ox = (int)(t % (2 * w)); t /= (2 * w);
-  const int oy = (int)(t % (2 * h));
-  const int b = (int)(t / (2 * h));
-  const float sy = fmaxf(__fmaf_rn(0.5f, (float)oy + 0.5f, -0.5f), 0.f), sx = fmaxf(__fmaf_rn(0.5f, (float)ox + 0.5f, -0.5f), 0.f);
-  const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
-  const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-  const float ly1 = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
-  const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const int qw = w + 1, qh = h + 1;
+  const int quad = blockIdx.x;
+  const int k = quad % qw - 1;
+  const int t = quad / qw;
+  const int j = t % qh - 1;
+  const int b = t / qh;
+  const int ya = max(j, 0), yb = min(j + 1, h - 1), xa = max(k, 0), xc = min(k + 1, w - 1);
   const f32x4* xb = (const f32x4*)(x + (long)b * h * w * D);
-  const f32x4 v00 = xb[(long)(y0 * w + x0) * nv + c], v01 = xb[(long)(y0 * w + x1) * nv + c];
-  const f32x4 v10 = xb[(long)(y1 * w + x0) * nv + c], v11 = xb[(long)(y1 * w + x1) * nv + c];
-  f32x4 o;
+  const f32x4* p00 = xb + (long)(ya * w + xa) * nv;
+  const f32x4* p01 = xb + (long)(ya * w + xc) * nv;
+  const f32x4* p10 = xb + (long)(yb * w + xa) * nv;
+  const f32x4* p11 = xb + (long)(yb * w + xc) * nv;
+  float ly1[2], lx1[2];
+  long orow[2];
+  int ocol[2];
+  bool vy[2], vx[2];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float r0 = __fmaf_rn(v00[e], lx0, __fmul_rn(v01[e], lx1));
-    const float r1 = __fmaf_rn(v10[e], lx0, __fmul_rn(v11[e], lx1));
-    o[e] = __fmaf_rn(r0, ly0, __fmul_rn(r1, ly1));
+  for (int s = 0; s < 2; ++s) {
+    const int oy = 2 * j + 1 + s, ox = 2 * k + 1 + s;
+    vy[s] = oy >= 0 && oy < 2 * h;
+    vx[s] = ox >= 0 && ox < 2 * w;
+    const float sy = fmaxf(__fmaf_rn(0.5f, (float)oy + 0.5f, -0.5f), 0.f), sx = fmaxf(__fmaf_rn(0.5f, (float)ox + 0.5f, -0.5f), 0.f);
+    const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+    ly1[s] = fminf(fmaxf(sy - (float)y0, 0.f), 1.f);
+    lx1[s] = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+    orow[s] = ((long)b * 2 * h + oy) * (2 * w);
+    ocol[s] = ox;
   }
-  if (out_f32) ((f32x4*)out_f32)[idx] = o;
-  if (out_f16) {
-    half4_t hh = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-    ((half4_t*)out_f16)[idx] = hh;
+  for (int c = threadIdx.x; c < nv; c += blockDim.x) {
+    const f32x4 v00 = p00[c], v01 = p01[c], v10 = p10[c], v11 = p11[c];
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        if (!(vy[sy] && vx[sx])) continue;
+        const float lx0 = 1.f - lx1[sx], ly0 = 1.f - ly1[sy];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r0 = __fmaf_rn(v00[e], lx0, __fmul_rn(v01[e], lx1[sx]));
+          const float r1 = __fmaf_rn(v10[e], lx0, __fmul_rn(v11[e], lx1[sx]));
+          o[e] = __fmaf_rn(r0, ly0, __fmul_rn(r1, ly1[sy]));
+        }
+        const long oi = (orow[sy] + ocol[sx]) * nv + c;
+        if (out_f32) ((f32x4*)out_f32)[oi] = o;
+        if (out_f16) {
+          half4_t hh = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+          ((half4_t*)out_f16)[oi] = hh;
+        }
+      }
   }
 }
 
 extern "C" int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, hipStream_t stream) {
   ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && h > 0 && w > 0 && D > 0 && D % 4 == 0, "zh_upsample2x_bilinear_cl: bad arguments");
-  const long total = (long)B * 4 * h * w * (D / 4);
-  hipLaunchKernelGGL(upsample2x_cl_kernel, dim3(zh_cdiv(total, 256)), dim3(256), 0, stream, x, out_f32, (half_t*)out_f16, B, h, w, D);
+  const long quads = (long)B * (h + 1) * (w + 1);          // one workgroup per 2x2 output quad
+  ZH_CHECK_ARG(quads < (1L << 31), "zh_upsample2x_bilinear_cl: too many output quads");
+  const int nv = D / 4;
+  const int threads = nv >= 256 ? 256 : ((nv + 63) / 64) * 64;
+  hipLaunchKernelGGL(upsample2x_cl_kernel, dim3((unsigned)quads), dim3(threads), 0, stream, x, out_f32, (half_t*)out_f16, B, h, w, D);
   ZH_CHECK_LAUNCH("zh_upsample2x_bilinear_cl");
   return ZH_OK;
 }
