@@ -264,6 +264,21 @@ def test_upsample_argmax_bit_exact(dev, golden_dir):
         lab = torch.empty((3, H, W), dtype=torch.int64, device=dev)
         ops.upsample_argmax(torch.from_numpy(x).to(dev), lab, 3, 81, 21, 21, H, W)
         assert np.array_equal(lab.cpu().numpy(), R.bilinear_argmax_nchw(x, H, W))
+    # many classes (class chunks with a remainder), 16x upsampling (C4 geometry: 32x32 -> 518), ragged tiles
+    x = _randn((1, 150, 32, 32), 72).numpy()
+    x[0, 7] = x[0, 140]                                          # exact ties across chunks: the first index must win
+    lab = torch.empty((1, 518, 518), dtype=torch.int64, device=dev)
+    ops.upsample_argmax(torch.from_numpy(x).to(dev), lab, 1, 150, 32, 32, 518, 518)
+    ref = R.bilinear_argmax_nchw(x, 518, 518)
+    assert np.array_equal(lab.cpu().numpy(), ref) and not (ref == 140).any()
+    # NaN logits: torch.argmax / np.argmax take the FIRST NaN as the maximum; -inf everywhere -> index 0
+    x = _randn((2, 40, 6, 6), 73).numpy()
+    x[0, 35, 2, 3] = np.nan; x[0, 3, 2, 3] = np.nan; x[1, :, 4:, 4:] = -np.inf; x[1, 20, 0, 0] = np.inf
+    lab = torch.empty((2, 96, 96), dtype=torch.int64, device=dev)
+    ops.upsample_argmax(torch.from_numpy(x).to(dev), lab, 2, 40, 6, 6, 96, 96)
+    with np.errstate(invalid="ignore"):
+        ref = R.bilinear_argmax_nchw(x, 96, 96)
+    assert np.array_equal(lab.cpu().numpy(), ref) and (ref[0] == 3).any() and (ref[1][-8:, -8:] == 0).all()
 
 
 def test_confusion_hist(dev, golden_dir):

@@ -270,15 +270,22 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* lo, l
   labels[idx] = besti;
 }
 
-// LDS-staged variant: a block owns an 8 x 32 output tile; the low-res window it touches (3 x 6 pixels x n classes at the
-// 8x upsampling of 336 px) is staged once in LDS, so the class loop reads LDS broadcasts instead of 4 scattered global
-// loads per class and pixel.  Same arithmetic, same results.
-#define UA_TH 8
+// LDS two-phase variant: a block owns a 32 x 32 output tile (each thread 4 pixels of one column) and walks the classes in
+// chunks of UA_CH.  Per chunk: (0) stage the low-res window the tile touches (7 x 7 pixels at the 8x upsampling of 336 px),
+// (1) interpolate every window row ONCE along x for the tile's 32 columns — R[c][row][ox] = fma(v0, lx0, v1*lx1), the value
+// every output row of the tile would otherwise recompute — (2) per pixel and class: two conflict-free LDS reads, one
+// fma(r0, ly0, r1*ly1), compare/select.  Same operations in the same order as ATen => bit-identical labels; 5 VALU + 2 LDS
+// reads per (pixel, class) instead of 8 + 4.
+#define UA_TH 32
 #define UA_TW 32
-#define UA_LDS_FLOATS 15360
+#define UA_CH 32
+#define UA_PX (UA_TH * UA_TW / 256)
 __global__ __launch_bounds__(256) void upsample_argmax_lds_kernel(const float* lo, long long* labels, int n, int h, int w,
-                                                                  int H, int W, float scale_h, float scale_w, int tiles_x, int tiles_y) {
-  extern __shared__ __attribute__((aligned(16))) float win[];   // n * wr * wc floats, sized at launch (occupancy!)
+                                                                  int H, int W, float scale_h, float scale_w, int tiles_x, int tiles_y,
+                                                                  int wr_max, int wc_max) {
+  extern __shared__ __attribute__((aligned(16))) float ua_lds[];
+  float* win = ua_lds;                                   // [UA_CH][wr][wc]
+  float* R = ua_lds + UA_CH * wr_max * wc_max;           // [UA_CH][wr][UA_TW]
   const int b = blockIdx.x / (tiles_x * tiles_y);
   const int t = blockIdx.x - b * tiles_x * tiles_y;
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
@@ -287,39 +294,89 @@ __global__ __launch_bounds__(256) void upsample_argmax_lds_kernel(const float* l
   const int y_lo = lin_weights(oy0, h, H, scale_h).i0, y_hi = lin_weights(oy1, h, H, scale_h).i1;
   const int x_lo = lin_weights(ox0, w, W, scale_w).i0, x_hi = lin_weights(ox1, w, W, scale_w).i1;
   const int wr = y_hi - y_lo + 1, wc = x_hi - x_lo + 1, wsz = wr * wc;
+  const int txl = threadIdx.x % UA_TW, tyl = threadIdx.x / UA_TW;      // column in the tile, first row (rows tyl + 8 i)
+  const int ox = min(ox0 + txl, W - 1);
+  const LinW wx = lin_weights(ox, w, W, scale_w);
+  const int xa = wx.i0 - x_lo, xb = wx.i1 - x_lo;
+  int ra[UA_PX], rb[UA_PX];
+  float l0[UA_PX], l1[UA_PX], best[UA_PX];
+  int besti[UA_PX];
+#pragma unroll
+  for (int i = 0; i < UA_PX; ++i) {
+    const int oy = min(oy0 + tyl + (256 / UA_TW) * i, H - 1);
+    const LinW wy = lin_weights(oy, h, H, scale_h);
+    ra[i] = (wy.i0 - y_lo) * (UA_CH * UA_TW) + txl;       // R is [row][class][column]: the class stride is a constant
+    rb[i] = (wy.i1 - y_lo) * (UA_CH * UA_TW) + txl;
+    l0[i] = wy.l0; l1[i] = wy.l1;
+    best[i] = -INFINITY; besti[i] = 0;                    // all -inf -> index 0, as torch.argmax
+  }
+  __shared__ int nan_seen;
   const float* p = lo + (long)b * n * h * w;
-  for (int i = threadIdx.x; i < n * wsz; i += 256) {
-    const int c = i / wsz, r = i - c * wsz;
-    const int yy = r / wc, xx = r - yy * wc;
-    win[i] = p[((long)c * h + (y_lo + yy)) * w + (x_lo + xx)];
+  for (int c0 = 0; c0 < n; c0 += UA_CH) {
+    const int nc = min(UA_CH, n - c0);
+    __syncthreads();                                      // previous chunk's R / win no longer read
+    if (threadIdx.x == 0) nan_seen = 0;
+    // (0) window: wave per class, lane per window pixel — the (row, col) split of the pixel index is hoisted out of the class loop
+    for (int r = threadIdx.x & 63; r < wsz; r += 64) {
+      const int yy = r / wc, xx = r - yy * wc;
+      const float* src = p + ((long)c0 * h + (y_lo + yy)) * w + (x_lo + xx);
+      for (int c = threadIdx.x >> 6; c < nc; c += 4) win[c * wsz + r] = src[(long)c * h * w];
+    }
+    __syncthreads();
+    // (1) x-interpolation of every window row for the tile's 32 columns: thread = (column txl, classes tyl, tyl+8, ...)
+    bool nanflag = false;
+    for (int c = tyl; c < nc; c += 256 / UA_TW) {
+      const float* q = win + c * wsz;
+      float* dst = R + c * UA_TW + txl;
+      for (int yy = 0; yy < wr; ++yy, q += wc, dst += UA_CH * UA_TW) {
+        const float r = __fmaf_rn(q[xa], wx.l0, __fmul_rn(q[xb], wx.l1));
+        nanflag |= (r != r);
+        *dst = r;
+      }
+    }
+    if (nanflag) nan_seen = 1;
+    __syncthreads();
+    if (!nan_seen) {
+      // fast path (no NaN anywhere in this chunk's window): strict > keeps the first maximum
+#pragma unroll 4
+      for (int c = 0; c < nc; ++c) {
+#pragma unroll
+        for (int i = 0; i < UA_PX; ++i) {
+          const float v = __fmaf_rn(R[ra[i] + c * UA_TW], l0[i], __fmul_rn(R[rb[i] + c * UA_TW], l1[i]));
+          const bool gt = v > best[i];                    // false forever once a NaN has won (best = NaN)
+          best[i] = gt ? v : best[i];
+          besti[i] = gt ? c0 + c : besti[i];
+        }
+      }
+    } else {
+      for (int c = 0; c < nc; ++c) {
+#pragma unroll
+        for (int i = 0; i < UA_PX; ++i) {
+          const float v = __fmaf_rn(R[ra[i] + c * UA_TW], l0[i], __fmul_rn(R[rb[i] + c * UA_TW], l1[i]));
+          // torch.argmax: first maximal index; NaN is treated as maximal (propagates)
+          if (v > best[i] || (v != v && best[i] == best[i])) { best[i] = v; besti[i] = c0 + c; }
+        }
+      }
+    }
   }
-  __syncthreads();
-  const int oy = oy0 + threadIdx.x / UA_TW, ox = ox0 + threadIdx.x % UA_TW;
-  if (oy >= H || ox >= W) return;
-  const LinW wy = lin_weights(oy, h, H, scale_h), wx = lin_weights(ox, w, W, scale_w);
-  const int o00 = (wy.i0 - y_lo) * wc + (wx.i0 - x_lo), o01 = (wy.i0 - y_lo) * wc + (wx.i1 - x_lo);
-  const int o10 = (wy.i1 - y_lo) * wc + (wx.i0 - x_lo), o11 = (wy.i1 - y_lo) * wc + (wx.i1 - x_lo);
-  float best = 0.f;
-  int besti = 0;
-  const float* q = win;
-  for (int c = 0; c < n; ++c, q += wsz) {
-    const float r0 = __fmaf_rn(q[o00], wx.l0, __fmul_rn(q[o01], wx.l1));
-    const float r1 = __fmaf_rn(q[o10], wx.l0, __fmul_rn(q[o11], wx.l1));
-    const float v = __fmaf_rn(r0, wy.l0, __fmul_rn(r1, wy.l1));
-    if (c == 0 || v > best || (v != v && best == best)) { best = v; besti = c; }
+#pragma unroll
+  for (int i = 0; i < UA_PX; ++i) {
+    const int oy = oy0 + tyl + (256 / UA_TW) * i;
+    if (oy < H && ox0 + txl < W) labels[((long)b * H + oy) * W + ox0 + txl] = besti[i];
   }
-  labels[((long)b * H + oy) * W + ox] = besti;
 }
 
 extern "C" int zh_upsample_argmax(const float* logits_lo, long long* labels, int B, int n, int h, int w, int H, int W,
                                   float scale_h, float scale_w, hipStream_t stream) {
   ZH_CHECK_ARG(logits_lo && labels && B > 0 && n > 0 && h > 0 && w > 0 && H > 0 && W > 0, "zh_upsample_argmax: bad arguments");
-  // worst-case low-res window of an 8 x 32 output tile: ceil(extent * scale) + 2 rows / cols (identity sizes: extent)
+  // worst-case low-res window of a 32 x 32 output tile: ceil(extent * scale) + 2 rows / cols (identity sizes: extent)
   const int wr = (h == H ? UA_TH : (int)(UA_TH * scale_h) + 3), wc = (w == W ? UA_TW : (int)(UA_TW * scale_w) + 3);
-  if ((long)n * wr * wc <= UA_LDS_FLOATS) {
+  const size_t lds = (size_t)UA_CH * wr * (wc + UA_TW) * sizeof(float);
+  const long tiles = (long)B * zh_cdiv(W, UA_TW) * zh_cdiv(H, UA_TH);
+  if (lds <= 48 * 1024 && tiles < (1L << 31)) {           // upsampling by >= ~2.5x; otherwise the direct kernel
     const int tiles_y = zh_cdiv(H, UA_TH), tiles_x = zh_cdiv(W, UA_TW);
-    hipLaunchKernelGGL(upsample_argmax_lds_kernel, dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(256), (size_t)n * wr * wc * sizeof(float), stream, logits_lo, labels,
-                       n, h, w, H, W, scale_h, scale_w, tiles_x, tiles_y);
+    hipLaunchKernelGGL(upsample_argmax_lds_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, logits_lo, labels,
+                       n, h, w, H, W, scale_h, scale_w, tiles_x, tiles_y, wr, wc);
   } else {
     hipLaunchKernelGGL(upsample_argmax_kernel, dim3(zh_cdiv((long)B * H * W, 256)), dim3(256), 0, stream, logits_lo, labels, B, n, h, w, H, W, scale_h, scale_w);
   }
