@@ -8,22 +8,42 @@
 
 // ---- im2col for the stride==kernel patch-embed conv (networks/clip_arch.py:340,378): pure re-index.
 //      out[(b,py,px)][c*p*p + i*p + j] = x[b,c,py*p+i,px*p+j], zero padded to Kpad columns, fp16.
-__global__ __launch_bounds__(256) void im2col_kernel(const float* x, half_t* out, int B, int Cin, int H, int W, int p,
-                                                     int gh, int gw, int Kpad, long total) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int k = (int)(idx % Kpad);
-  const long row = idx / Kpad;
-  float v = 0.f;
-  if (k < Cin * p * p) {
-    const int c = k / (p * p), ij = k - c * p * p, i = ij / p, j = ij - i * p;
-    const int px = (int)(row % gw);
-    const long t = row / gw;
-    const int py = (int)(t % gh), b = (int)(t / gh);
-    const int yy = py * p + i, xx = px * p + j;     // beyond the image only with pad_to_patch (zero padding,
-    if (yy < H && xx < W) v = x[(((long)b * Cin + c) * H + yy) * W + xx];   // selfmask/vision_transformer.py:260-267)
+__global__ __launch_bounds__(128) void im2col_kernel(const float* x, half_t* out, int B, int Cin, int H, int W, int p,
+                                                     int gh, int gw, int Kpad, int vec) {
+  // one workgroup per patch (= GEMM row): the (b, py, px) split is block-uniform; a thread converts 8 consecutive k =
+  // 8 consecutive pixels of one patch row (two 16-byte loads, one 16-byte store) when p % 8 == 0 and rows are 16-B aligned
+  const int row = blockIdx.x;
+  const int px = row % gw;
+  const int t = row / gw;
+  const int py = t % gh, b = t / gh;
+  const int pp = p * p, kreal = Cin * pp;
+  half_t* orow = out + (long)row * Kpad;
+  for (int k0 = threadIdx.x * 8; k0 < Kpad; k0 += 128 * 8) {
+    half8_t o;
+    if (vec && k0 + 8 <= kreal) {
+      const int c = k0 / pp, ij = k0 - c * pp, i = ij / p, j = ij - i * p;
+      const int yy = py * p + i, xx = px * p + j;
+      if (yy < H && xx + 8 <= W) {
+        const f32x4* src = (const f32x4*)(x + (((long)b * Cin + c) * H + yy) * W + xx);
+        const f32x4 v0 = src[0], v1 = src[1];
+        o = (half8_t){(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3], (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
+        *(half8_t*)(orow + k0) = o;
+        continue;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + e;
+      float v = 0.f;
+      if (k < kreal) {
+        const int c = k / pp, ij = k - c * pp, i = ij / p, j = ij - i * p;
+        const int yy = py * p + i, xx = px * p + j;     // beyond the image only with pad_to_patch (zero padding,
+        if (yy < H && xx < W) v = x[(((long)b * Cin + c) * H + yy) * W + xx];   // selfmask/vision_transformer.py:260-267)
+      }
+      o[e] = (half_t)v;
+    }
+    *(half8_t*)(orow + k0) = o;
   }
-  out[idx] = (half_t)v;
 }
 
 extern "C" int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, int pad_to_patch,
@@ -33,8 +53,11 @@ extern "C" int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, i
   ZH_CHECK_ARG(Kpad >= Cin * patch * patch, "zh_im2col_f16: Kpad too small");
   const int gh = pad_to_patch ? (H + patch - 1) / patch : (H - patch) / patch + 1;
   const int gw = pad_to_patch ? (W + patch - 1) / patch : (W - patch) / patch + 1;
-  const long total = (long)B * gh * gw * Kpad;
-  hipLaunchKernelGGL(im2col_kernel, dim3(zh_cdiv(total, 256)), dim3(256), 0, stream, x, (half_t*)out, B, Cin, H, W, patch, gh, gw, Kpad, total);
+  ZH_CHECK_ARG(Kpad % 8 == 0 && ((uintptr_t)out & 15) == 0, "zh_im2col_f16: Kpad must be a multiple of 8 and out 16-byte aligned");
+  const long rows = (long)B * gh * gw;
+  ZH_CHECK_ARG(rows < (1L << 31), "zh_im2col_f16: too many patches");
+  const int vec = (patch % 8 == 0) && (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)rows), dim3(128), 0, stream, x, (half_t*)out, B, Cin, H, W, patch, gh, gw, Kpad, vec);
   ZH_CHECK_LAUNCH("zh_im2col_f16");
   return ZH_OK;
 }
