@@ -136,6 +136,12 @@ int zh_upsample_argmax(const float* logits_lo, long long* labels, int B, int n, 
 int zh_upsample_bilinear_nchw(const float* x, float* out, unsigned char* mask_u8, float threshold, long planes,
                               int h, int w, int H, int W, float scale_h, float scale_w, zh_stream_t stream);
 
+/* SelfMask inference tail, selfmask.py:207-221: per image the query with the largest objectness logit (first maximum),
+ * its mask plane [h,w] bilinearly resampled (scale_* as for zh_upsample_bilinear_nchw; H,W = cropped output) and
+ * thresholded -> out_u8 [B,H,W], index int64 [B].  objectness f32 [B,Q] (logits), masks f32 [B,Q,h,w]. */
+int zh_select_upsample_mask(const float* objectness, const float* masks, unsigned char* out_u8, long long* index, int B, int Q,
+                            int h, int w, int H, int W, float scale_h, float scale_w, float threshold, zh_stream_t stream);
+
 /* F.interpolate(mask[None,None], size=(H,W), mode="nearest") on a u8 mask: datasets/index_dataset.py:215
  * (restore the original resolution of a pseudo-mask).  scale_* = float32(in)/float32(out). */
 int zh_resize_nearest_u8(const unsigned char* x, unsigned char* out, int h, int w, int H, int W, float scale_h, float scale_w,

@@ -427,6 +427,41 @@ __global__ __launch_bounds__(256) void bilinear_nchw_kernel(const float* x, floa
   if (mask) mask[idx] = v > threshold ? 1 : 0;
 }
 
+// SelfMask inference tail (networks/selfmask/selfmask.py:207-221) without a host round trip: per image pick the query with
+// the largest objectness logit (first maximum, NaN = maximum: np/torch argmax), bilinear-upsample ONLY that mask plane
+// (ATen arithmetic as above), crop to [H,W] and threshold.
+__global__ __launch_bounds__(256) void select_upsample_mask_kernel(const float* obj, const float* masks, unsigned char* out, long long* index,
+                                                                   int Q, int h, int w, int H, int W, float scale_h, float scale_w, float threshold) {
+  const int b = blockIdx.y;
+  const float* o = obj + (long)b * Q;
+  int best = 0;
+  float bv = o[0];
+  for (int q = 1; q < Q; ++q) {
+    const float v = o[q];
+    if (v > bv || (v != v && bv == bv)) { bv = v; best = q; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) index[b] = best;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= H * W) return;
+  const int ox = idx % W, oy = idx / W;
+  const LinW wy = lin_weights(oy, h, H, scale_h), wx = lin_weights(ox, w, W, scale_w);
+  const float* p = masks + ((long)b * Q + best) * h * w;
+  const float r0 = __fmaf_rn(p[wy.i0 * w + wx.i0], wx.l0, __fmul_rn(p[wy.i0 * w + wx.i1], wx.l1));
+  const float r1 = __fmaf_rn(p[wy.i1 * w + wx.i0], wx.l0, __fmul_rn(p[wy.i1 * w + wx.i1], wx.l1));
+  const float v = __fmaf_rn(r0, wy.l0, __fmul_rn(r1, wy.l1));
+  out[(long)b * H * W + idx] = v > threshold ? 1 : 0;
+}
+
+extern "C" int zh_select_upsample_mask(const float* objectness, const float* masks, unsigned char* out_u8, long long* index, int B, int Q,
+                                       int h, int w, int H, int W, float scale_h, float scale_w, float threshold, hipStream_t stream) {
+  ZH_CHECK_ARG(objectness && masks && out_u8 && index && B > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0, "zh_select_upsample_mask: bad arguments");
+  ZH_CHECK_ARG(B < 65536 && (long)H * W < (1L << 31), "zh_select_upsample_mask: shape exceeds grid limits");
+  hipLaunchKernelGGL(select_upsample_mask_kernel, dim3(zh_cdiv((long)H * W, 256), B), dim3(256), 0, stream, objectness, masks, out_u8, index,
+                     Q, h, w, H, W, scale_h, scale_w, threshold);
+  ZH_CHECK_LAUNCH("zh_select_upsample_mask");
+  return ZH_OK;
+}
+
 extern "C" int zh_upsample_bilinear_nchw(const float* x, float* out, unsigned char* mask_u8, float threshold, long planes,
                                          int h, int w, int H, int W, float scale_h, float scale_w, hipStream_t stream) {
   ZH_CHECK_ARG(x && (out || mask_u8) && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "zh_upsample_bilinear_nchw: bad arguments");

@@ -44,6 +44,16 @@ class _EngineBase:
         self._bufs: Dict[Tuple, torch.Tensor] = {}
         self._buf_gen = 0             # bumped on every (re)allocation: launch plans check it
 
+    def fork(self):
+        """A second engine over the SAME parameters and packed weights with its own activation buffers: one per HIP stream
+        when independent inputs are processed concurrently (buffers are the only mutable state of an engine)."""
+        import copy
+        self._pack()
+        e = copy.copy(self)
+        e._bufs, e._buf_gen = {}, 0
+        e._geo = dict(self._geo)
+        return e
+
     def _version_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.params.values())
 
@@ -685,11 +695,9 @@ class SelfMaskEngine(_EngineBase):
             ops.gemm(o2, W_["ffn.2.w"], obj, bias=W_["ffn.2.b"], act=ops.ACT_SIGMOID, M=B * Q, N=1, K=D, ldc=1)
             return {"objectness": obj, "mask_pred": masks}
         ops.gemm(o2, W_["ffn.2.w"], obj, bias=W_["ffn.2.b"], M=B * Q, N=1, K=D, ldc=1)
-        # Q logits per image: the host picks WHICH plane to upsample (first max, as torch.argmax on CPU)
-        sel = obj.view(B, Q).cpu().numpy().argmax(axis=1).tolist()
-        idx = torch.tensor(sel, dtype=torch.int64)
+        # the query with the largest objectness logit is picked on the device (first maximum, as torch.argmax): x4 bilinear of
+        # that plane only, cropped to [:H,:W], > 0.5 — no host round trip, so images on different streams overlap
+        idx = torch.empty((B,), dtype=torch.int64, device=x.device)
         dts = torch.empty((B, H, Wd), dtype=torch.uint8, device=x.device)
-        for b in range(B):                            # x4 bilinear of the selected query only, cropped to [:H,:W], > 0.5
-            plane = masks[b, 0, sel[b]]
-            ops.upsample_bilinear_nchw(plane, 1, 2 * h, 2 * w, H, Wd, mask_u8=dts[b], threshold=0.5, scale_h=0.25, scale_w=0.25)
+        ops.select_upsample_mask(obj, masks, dts, idx, B, Q, 2 * h, 2 * w, H, Wd, 0.25, 0.25, 0.5)
         return {"dts": dts, "index": idx}

@@ -289,6 +289,13 @@ def bilateral_solve(rgb_u8, target, sigma_spatial=16, sigma_luma=16, sigma_chrom
     return (out, stats, n, m) if debug else (out, stats)
 
 
+def select_upsample_mask(obj, masks, out_u8, index, B, Q, h, w, H, W, scale_h, scale_w, threshold=0.5):
+    L = _lib.load()
+    _chk(obj, f32, "objectness"); _chk(masks, f32, "masks"); _chk(out_u8, torch.uint8, "mask out")
+    _lib.check(L.zh_select_upsample_mask(_p(obj), _p(masks), _p(out_u8), _p(index), B, Q, h, w, H, W, float(scale_h), float(scale_w),
+                                         float(threshold), _stream()), "zh_select_upsample_mask")
+
+
 def resize_nearest_u8(x_u8, H, W):
     """F.interpolate(x[None,None], size=(H,W), mode="nearest")[0,0] for a u8 [h,w] mask on the GPU."""
     L = _lib.load()

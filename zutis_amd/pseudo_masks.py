@@ -19,10 +19,9 @@ from . import ops, rle
 from .engine import SelfMaskEngine
 
 
-@torch.no_grad()
-def pseudo_mask(engine: SelfMaskEngine, image: torch.Tensor, original_size: Optional[Tuple[int, int]] = None,
-                bilateral_solver: bool = True) -> np.ndarray:
-    """image f32 [3,H,W] (normalised, on the GPU) -> uint8 {0,1} mask [H0,W0] (original_size or H,W) on the host."""
+def _device_mask(engine: SelfMaskEngine, image: torch.Tensor, original_size: Optional[Tuple[int, int]],
+                 bilateral_solver: bool) -> torch.Tensor:
+    """image f32 [3,H,W] (normalised, on the GPU) -> uint8 {0,1} mask [H0,W0] on the GPU, all on the current stream."""
     out = engine.forward(image[None].contiguous(), inference=True)
     dt = out["dts"][0]                                                     # u8 [H,W] on device (selfmask.py:216-222)
     if bilateral_solver:                                                   # selfmask.py:226-234
@@ -31,7 +30,14 @@ def pseudo_mask(engine: SelfMaskEngine, image: torch.Tensor, original_size: Opti
         dt = (soft > 0.5).to(torch.uint8)                                  # comparison on the device result
     if original_size is not None and tuple(original_size) != tuple(dt.shape):
         dt = ops.resize_nearest_u8(dt.contiguous(), int(original_size[0]), int(original_size[1]))   # index_dataset.py:215
-    return dt.cpu().numpy()
+    return dt
+
+
+@torch.no_grad()
+def pseudo_mask(engine: SelfMaskEngine, image: torch.Tensor, original_size: Optional[Tuple[int, int]] = None,
+                bilateral_solver: bool = True) -> np.ndarray:
+    """image f32 [3,H,W] (normalised, on the GPU) -> uint8 {0,1} mask [H0,W0] (original_size or H,W) on the host."""
+    return _device_mask(engine, image, original_size, bilateral_solver).cpu().numpy()
 
 
 def save_rle_json(mask: np.ndarray, path: str) -> Dict:
@@ -48,7 +54,42 @@ def save_rle_json(mask: np.ndarray, path: str) -> Dict:
 
 @torch.no_grad()
 def generate_pseudo_masks(engine: SelfMaskEngine, images: Sequence[torch.Tensor], original_sizes: Sequence[Tuple[int, int]],
-                          out_paths: Sequence[str], bilateral_solver: bool = True) -> List[str]:
-    for img, size, path in zip(images, original_sizes, out_paths):
-        save_rle_json(pseudo_mask(engine, img, size, bilateral_solver), path)
+                          out_paths: Sequence[str], bilateral_solver: bool = True, n_streams: int = 4) -> List[str]:
+    """The loop of IndexDataset.generate_pseudo_masks (index_dataset.py:196-226) as a pipeline: image i runs SelfMask + solver +
+    resize on HIP stream i % n_streams (one forked engine = one set of activation buffers per stream; the solver and the
+    ViT of different images overlap — a single 512x683 image is launch/latency-bound: ~110 solver launches in 0.9 ms), the
+    mask lands in pinned host memory by an async copy, and the host RLE-encodes / writes image i - n_streams meanwhile."""
+    from collections import deque
+    n_streams = max(1, min(n_streams, len(images)))
+    if n_streams == 1:
+        for img, size, path in zip(images, original_sizes, out_paths):
+            save_rle_json(pseudo_mask(engine, img, size, bilateral_solver), path)
+        return list(out_paths)
+    dev = images[0].device
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    engines = [engine] + [engine.fork() for _ in range(n_streams - 1)]
+    pinned: List[Optional[torch.Tensor]] = [None] * n_streams
+    pending = deque()
+
+    def finish(item):
+        ev, host, shape, path = item
+        ev.synchronize()
+        save_rle_json(host[: shape[0] * shape[1]].view(shape).numpy().copy(), path)
+
+    for i, (img, size, path) in enumerate(zip(images, original_sizes, out_paths)):
+        k = i % n_streams
+        if len(pending) == n_streams:                                   # slot k's previous image: buffers free after this
+            finish(pending.popleft())
+        streams[k].wait_stream(torch.cuda.current_stream(dev))          # the image may have been produced on the caller's stream
+        with torch.cuda.stream(streams[k]):
+            dt = _device_mask(engines[k], img, size, bilateral_solver)
+            n = dt.numel()
+            if pinned[k] is None or pinned[k].numel() < n:
+                pinned[k] = torch.empty((n,), dtype=torch.uint8, pin_memory=True)
+            pinned[k][:n].copy_(dt.reshape(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        pending.append((ev, pinned[k], tuple(dt.shape), path))
+    while pending:
+        finish(pending.popleft())
     return list(out_paths)
