@@ -107,3 +107,39 @@ def test_pseudo_mask_driver_end_to_end(dev, tmp_path):
     ref = (soft > 0.5)
     ref = ref[(np.arange(144) * np.float32(72 / 144)).astype(int)][:, (np.arange(200) * np.float32(100 / 200)).astype(int)]
     assert (got != ref).mean() < 1e-2          # the SelfMask mask itself comes from fp16-MFMA logits
+
+
+def test_pseudo_mask_pipeline_matches_sequential(dev, tmp_path):
+    """The multi-stream driver (forked engines, device-side query selection, pinned async D2H) writes byte-identical RLE JSON
+    to the one-stream loop, for images of different sizes."""
+    from zutis_amd import detgen, pseudo_masks
+    from zutis_amd.engine import SelfMaskEngine
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()})
+    sizes_in = [(72, 100), (64, 64), (72, 100), (80, 56), (64, 64)]
+    imgs = [torch.from_numpy(detgen.images(1, h, w, seed=20 + i))[0].to(dev) for i, (h, w) in enumerate(sizes_in)]
+    sizes_out = [(2 * h, 2 * w + 1) for h, w in sizes_in]
+    pa = [str(tmp_path / "seq" / f"{i}.json") for i in range(len(imgs))]
+    pb = [str(tmp_path / "pipe" / f"{i}.json") for i in range(len(imgs))]
+    pseudo_masks.generate_pseudo_masks(eng, imgs, sizes_out, pa, n_streams=1)
+    pseudo_masks.generate_pseudo_masks(eng, imgs, sizes_out, pb, n_streams=3)
+    for a, b in zip(pa, pb):
+        assert open(a).read() == open(b).read()
+
+
+def test_select_upsample_mask_kernel(dev):
+    """SelfMask inference tail on the device == torch: argmax(objectness) -> x4 bilinear of that plane -> crop -> > 0.5."""
+    from zutis_amd import ops
+    import torch.nn.functional as F
+    B, Q, h, w, H, W = 3, 20, 18, 26, 70, 101
+    g = torch.Generator().manual_seed(5)
+    obj = torch.randn((B, Q), generator=g)
+    obj[1, 7] = obj[1, 3] = obj[1].max() + 1.0                       # tie: the first maximum wins
+    masks = torch.rand((B, Q, h, w), generator=g)
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    idx = torch.empty((B,), dtype=torch.int64, device=dev)
+    ops.select_upsample_mask(obj.to(dev), masks.to(dev), out, idx, B, Q, h, w, H, W, 0.25, 0.25, 0.5)
+    sel = obj.argmax(dim=1)
+    assert torch.equal(idx.cpu(), sel) and int(sel[1]) == 3
+    up = F.interpolate(masks[torch.arange(B), sel][:, None], scale_factor=4, mode="bilinear", align_corners=False)[:, 0, :H, :W]
+    ref = (up > 0.5).to(torch.uint8)
+    assert (out.cpu() != ref).float().mean().item() < 2e-4          # fp32 rounding at the 0.5 threshold only
