@@ -115,6 +115,8 @@ def main():
                           "gathered": torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) if dist_on else None,
                           "pending": None})
         torch.cuda.synchronize()
+        zplan.run_many([ln["plan"] for ln in lanes], [ln["stream"].cuda_stream for ln in lanes])   # prime every lane once (setup,
+        torch.cuda.synchronize()                                                                    # like the eager warm-up above)
 
     def run_steps(first: int, count: int):
         """`count` consecutive steps; with lanes, groups of `n_lanes` steps are enqueued interleaved, one stream each."""
@@ -255,9 +257,13 @@ def main():
             "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1) if (S, n) == (336, 81) else None,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
-        print(json.dumps(line), flush=True)
     if dist_on:
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # first: RCCL prints its version banner on stdout when the communicator goes away
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)    # RCCL's banner sits in libc's stdout buffer: push it out before the result line
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
