@@ -51,3 +51,33 @@ def test_ops_refuse_cpu_tensors(lib):
     from zutis_amd import ops
     with pytest.raises(_lib.ZutisHipError):
         ops.gemm(torch.zeros(8, 64, dtype=torch.float16), torch.zeros(8, 64, dtype=torch.float16), torch.zeros(8, 8))
+
+
+def test_launch_plan_dispatcher_matches_header_and_bindings(tmp_path):
+    """The native launch-plan dispatcher is generated from include/zutis_hip.h: every plannable entry point (stream last,
+    device-pointer / scalar arguments) must exist in the ctypes table with the same arity, the generated C must call it with
+    one argument word per parameter, and the library must report the same op-id -> name mapping (no GPU needed)."""
+    import struct
+    from zutis_amd import _lib, plan
+    ops_ = plan.parse_header()
+    names = [n for n, _ in ops_]
+    assert "zh_gemm_f16" in names and "zh_attention_f16" in names and "zh_bilateral_solve" in names
+    assert not any(n.startswith("zh_plan_") for n in names) and "zh_denormalize_u8" not in names
+    for name, sig in ops_:
+        res, args = _lib._SIGS[name]
+        assert len(args) == len(sig) <= plan.MAX_ARGS + 1, name
+        assert sig[-1][0] == "zh_stream_t"
+    out = tmp_path / "gen.inc"
+    assert plan.generate_dispatch(str(out)) == names
+    txt = out.read_text()
+    for i, (name, sig) in enumerate(ops_):
+        line = [ln for ln in txt.splitlines() if ln.strip().startswith(f"case {i}:")][0]
+        assert f"return {name}(" in line and line.count("c.a[") == len(sig) - 1
+    L = _lib.load(raw=True)
+    for i, name in enumerate(names):
+        assert L.zh_plan_op_name(i).decode() == name
+    assert L.zh_plan_op_name(len(names)) is None
+    # argument words: floats by bit pattern, pointers / ints zero-extended, None -> 0
+    assert plan._word("float", 1.5) == struct.unpack("<I", struct.pack("<f", 1.5))[0]
+    assert plan._word("double", -2.0) == struct.unpack("<Q", struct.pack("<d", -2.0))[0]
+    assert plan._word("const float*", None) == 0 and plan._word("int", -1) == 0xFFFFFFFFFFFFFFFF
