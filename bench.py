@@ -104,7 +104,7 @@ def main():
     lanes = []
     if n_lanes > 1:
         for li in range(n_lanes):
-            e = eng if li == 0 else ZutisEngine(P, cfg.patch, cfg.dec_heads)
+            e = eng if li == 0 else eng.fork()       # own activation buffers, shared packed weights
             e.forward(x)                                   # eager warm-up: packs weights, sizes the buffer cache
             with zplan.Recorder() as rec:
                 out = e.forward(x)
