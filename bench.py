@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-gpu-baseline", action="store_true",
+                    help="also time the oracle (= the reference's op sequence) with stock PyTorch-ROCm fp32 eager ops on this GPU "
+                         "(SURVEY 8d: the 'reference single-GPU PyTorch' the north-star's >= 10x target is quoted against)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch intra-op threads of the CPU baseline (16 was the fastest of 8..128 on the 2x64-core GPU box)")
@@ -240,6 +243,29 @@ def main():
         parity = {"logit_max_abs_err": float(np.abs(lo - lo_ref).max()), "label_agreement": float((lab == lab_ref).mean()),
                   "miou_vs_oracle_labels": float(O.scores_from_hist(hist)[0]["Mean IoU"]), "tolerance": 1e-3}
 
+    torch_gpu = None
+    if rank == 0 and world == 1 and args.torch_gpu_baseline:
+        import torch.nn.functional as F
+        from oracle import zutis_ref as O
+        Pg = {k: v for k, v in P.items()}                 # fp32 parameters already on the device
+
+        def gpu_pass(xi):
+            with torch.no_grad():
+                o = O.zutis_forward(Pg, xi, cfg.patch, cfg.dec_heads)
+                lo = O.semantic_logits_lowres(o["patch_tokens"], text)
+                return F.interpolate(lo, size=(S, S), mode="bilinear", align_corners=False).argmax(dim=1)   # zutis.py:366-372
+        for _ in range(2):
+            gpu_pass(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            lab_t = gpu_pass(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 5
+        torch_gpu = {"value": round(B / dt, 1), "unit": "images/s", "kind": "port",
+                     "what": "oracle op sequence (F.conv2d / F.linear / softmax / F.interpolate / einsum) in stock PyTorch-ROCm fp32 eager "
+                             "on the same MI355X, batch %d, 5 timed passes after 2 warm-ups" % B}
+
     if rank == 0:
         total_images = world * B * args.steps
         line = {
@@ -256,6 +282,7 @@ def main():
                        "flops_per_image": FLOPS_PER_IMAGE_C2 if (S, n) == (336, 81) else None},
             "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1) if (S, n) == (336, 81) else None,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            **({"torch_gpu_baseline": torch_gpu} if torch_gpu else {}),
         }
     if dist_on:
         dist.destroy_process_group()      # first: RCCL prints its version banner on stdout when the communicator goes away

@@ -68,7 +68,7 @@ def interpolate_positional_embedding(pos: Tensor, h: int, w: int) -> Tensor:
     g = int(math.isqrt(pos.shape[0] - 1))
     patch = pos[1:].detach().cpu().numpy().reshape(g, g, -1)
     out = R.bicubic_cl(patch, h, w, scale_factor_h=(h + 0.1) / g, scale_factor_w=(w + 0.1) / g)
-    return torch.cat([pos[:1], torch.from_numpy(out.reshape(h * w, -1))], dim=0)
+    return torch.cat([pos[:1], torch.from_numpy(out.reshape(h * w, -1)).to(pos.device)], dim=0)
 
 
 def clip_vit_forward(P: Dict[str, Tensor], x: Tensor, patch: int, prefix: str = "encoder.") -> Tuple[Tensor, int, int]:
@@ -227,11 +227,14 @@ def zutis_forward(P: Dict[str, Tensor], x: Tensor, patch: int, dec_heads: int = 
     B = x.shape[0]
     tok, h, w = clip_vit_forward(P, x, patch)                                    # :479
     D = tok.shape[-1]
-    tok = torch.from_numpy(R.bilinear_up2_cl(tok.numpy().reshape(B, h, w, D)))   # :491-495
+    if tok.is_cuda:      # GPU-eager baseline leg of bench.py: the reference's own call (ATen CUDA kernel), :491-495
+        tok = F.interpolate(tok.reshape(B, h, w, D).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear").permute(0, 2, 3, 1)
+    else:
+        tok = torch.from_numpy(R.bilinear_up2_cl(tok.numpy().reshape(B, h, w, D)))   # :491-495
     h, w = 2 * h, 2 * w
     tok = tok.reshape(B, h * w, D)
     dec_in = mlp3(P, "ffn1", tok)                                                # :500-503
-    pos = sine_pe(h, w, D)                                                       # :507
+    pos = sine_pe(h, w, D).to(x.device)                                          # :507
     q = decoder_forward(P, dec_in, pos, P["query_embed"], dec_heads)             # :510-513
     q = mlp3(P, "ffn2", q)                                                       # :514
     q = q / q.norm(dim=-1, keepdim=True)                                         # :515
