@@ -40,6 +40,73 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: 
 FLOPS_PER_IMAGE_C2 = 124.4e9 + 0.146e9  # forward + semantic predict
 
 
+def bench_c5(args):
+    """Config 5: CLIP ViT-L/14@336 `encode_image` over synthetic batches generated on the device, images sharded by
+    rank, no communication until one final all-gather of the last step's embeddings (per-rank shards are the product)."""
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    from zutis_amd import detgen, ops
+    from zutis_amd.engine import ClipImageEncoder
+    D, L, p, g, E = 1024, 24, 14, 24, 768
+    B = 256 if args.batch == 32 else args.batch
+
+    def w(name, shape, std, mean=0.0):
+        return torch.from_numpy(detgen.det_normal("c5." + name, shape, std, mean, 5)).to(dev)
+    P = {"visual.class_embedding": w("cls", (D,), D ** -0.5), "visual.positional_embedding": w("pos", (g * g + 1, D), D ** -0.5),
+         "visual.proj": w("proj", (D, E), D ** -0.5), "visual.conv1.weight": w("conv", (D, 3, p, p), (3 * p * p) ** -0.5)}
+    for ln in ("ln_pre", "ln_post"):
+        P[f"visual.{ln}.weight"], P[f"visual.{ln}.bias"] = w(ln + "w", (D,), 0.1, 1.0), w(ln + "b", (D,), 0.1)
+    for i in range(L):
+        q = f"visual.transformer.resblocks.{i}."
+        P[q + "attn.in_proj_weight"], P[q + "attn.in_proj_bias"] = w(q + "a", (3 * D, D), D ** -0.5), w(q + "ab", (3 * D,), 0.02)
+        P[q + "attn.out_proj.weight"], P[q + "attn.out_proj.bias"] = w(q + "o", (D, D), D ** -0.5 * (2 * L) ** -0.5), w(q + "ob", (D,), 0.02)
+        P[q + "mlp.c_fc.weight"], P[q + "mlp.c_fc.bias"] = w(q + "f", (4 * D, D), (2 * D) ** -0.5), w(q + "fb", (4 * D,), 0.02)
+        P[q + "mlp.c_proj.weight"], P[q + "mlp.c_proj.bias"] = w(q + "p", (D, 4 * D), D ** -0.5 * (2 * L) ** -0.5), w(q + "pb", (D,), 0.02)
+        for ln in ("ln_1", "ln_2"):
+            P[q + ln + ".weight"], P[q + ln + ".bias"] = w(q + ln + "w", (D,), 0.1, 1.0), w(q + ln + "b", (D,), 0.1)
+    enc = ClipImageEncoder(P, p, prefix="visual.")
+    x = torch.randn((B, 3, 336, 336), generator=torch.Generator(device="cpu").manual_seed(2000 + rank)).to(dev)
+    for _ in range(max(1, args.warmup)):
+        emb = enc.encode_image(x)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb = enc.encode_image(x)
+    if world > 1:
+        allemb = torch.empty((world * B, E), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allemb, emb)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    T = g * g + 1
+    flop = L * (2 * T * (D * 3 * D + D * D + 2 * D * 4 * D) + 4 * T * T * D) + 2 * g * g * 3 * p * p * D + 2 * D * E
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        total = world * B * args.steps
+        print(json.dumps({
+            "metric": "images/sec, CLIP ViT-L/14@336 image-embedding extraction (BASELINE config 5)", "value": round(total / elapsed, 1),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"C5: CLIP ViT-L/14@336 encode_image, {B}x3x336x336 per GPU per step, embeddings fp32 [{B},{E}], "
+                                   "one all-gather of the last step's embeddings", "global_batch": world * B, "parallelism": f"dp{world}",
+                       "flops_per_image": flop},
+            "model_tflops": round(total * flop / elapsed / 1e12 / world, 1), "roofline": None, "cpu_baseline": None,
+            "embedding_norm": round(float(emb.norm(dim=1).mean().item()), 6)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +115,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE config[1]: batch 32)")
     ap.add_argument("--size", type=int, default=336)
     ap.add_argument("--classes", type=int, default=81)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 (default, the headline): ViT-B/16 @336, 81 classes, 32 / GPU.  c4: @518, 920 classes, 8 / GPU "
+                         "(BASELINE config 4).  c5: CLIP ViT-L/14@336 image-embedding extraction, 256 / GPU / step (config 5)")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,6 +128,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch intra-op threads of the CPU baseline (16 was the fastest of 8..128 on the 2x64-core GPU box)")
     args = ap.parse_args()
+    if args.workload == "c4":
+        args.size, args.classes = 518, 920
+        if args.batch == 32:
+            args.batch = 8
+    if args.workload == "c5":
+        return bench_c5(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
