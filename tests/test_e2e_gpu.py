@@ -380,3 +380,26 @@ def test_causal_attention_kernel(dev):
         ops.attention(q.to(dev), k.to(dev), v.to(dev), o, batch=B, heads=H, Tq=T, Tk=T, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D,
                       strideQ=T * D, strideK=T * D, strideV=T * D, strideO=T * D, causal=True)
         assert (o.float().cpu() - ref).abs().max().item() < 4e-3
+
+
+def test_rank_sharded_evaluation_equals_full_batch(dev):
+    """BASELINE config 2 at its full batch (32 x 336^2, 81 classes): evaluating the two contiguous rank shards [0,16) and
+    [16,32) (what world_size 2 does, zutis_amd/distributed.shard_range) and concatenating in rank order gives BITWISE the
+    logits and labels of the single-GPU batch — the all-gather in bench.py reproduces the single-GPU result exactly."""
+    from zutis_amd import detgen
+    from zutis_amd.distributed import shard_range
+    cfg = detgen.VIT_B16
+    eng = _engine(cfg, dev)
+    x = torch.from_numpy(detgen.images(32, 336, 336, seed=9)).to(dev)
+    text = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim)).to(dev)
+    full = eng.forward(x)
+    lo_full = eng.semantic_logits_lowres(full["patch_tokens"], text).clone()
+    lab_full = eng.predict_semantic(full["patch_tokens"], text, (336, 336)).clone()
+    parts_lo, parts_lab = [], []
+    for r in range(2):
+        a, b = shard_range(32, r, 2)
+        out = eng.forward(x[a:b].contiguous())
+        parts_lo.append(eng.semantic_logits_lowres(out["patch_tokens"], text).clone())
+        parts_lab.append(eng.predict_semantic(out["patch_tokens"], text, (336, 336)).clone())
+    assert torch.equal(torch.cat(parts_lo), lo_full) and torch.equal(torch.cat(parts_lab), lab_full)
+    assert int(lab_full.min()) >= 0 and int(lab_full.max()) < 81
