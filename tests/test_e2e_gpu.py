@@ -403,3 +403,23 @@ def test_rank_sharded_evaluation_equals_full_batch(dev):
         parts_lab.append(eng.predict_semantic(out["patch_tokens"], text, (336, 336)).clone())
     assert torch.equal(torch.cat(parts_lo), lo_full) and torch.equal(torch.cat(parts_lab), lab_full)
     assert int(lab_full.min()) >= 0 and int(lab_full.max()) < 81
+
+
+def test_forked_engine_eager_predict(dev):
+    """fork(): same weights, own buffers — a fork's first eager predict must not trust the parent's cached f16 copies."""
+    from zutis_amd import detgen
+    cfg = detgen.TINY
+    eng = _engine(cfg, dev)
+    text = torch.from_numpy(detgen.text_embeddings(7, cfg.embed_dim)).to(dev)
+    x = torch.from_numpy(detgen.images(2, 80, 112, seed=3)).to(dev)
+    out = eng.forward(x)
+    ref = eng.predict_semantic(out["patch_tokens"], text, (80, 112)).clone()
+    f = eng.fork()
+    out2 = f.forward(x)
+    assert torch.equal(out2["patch_tokens"], out["patch_tokens"])
+    assert torch.equal(f.predict_semantic(out2["patch_tokens"], text, (80, 112)), ref)
+    # tokens that did not come from the engine's last forward are re-cast
+    other = torch.nn.functional.normalize(torch.randn_like(out["patch_tokens"]), dim=-1)
+    a = eng.predict_semantic(other, text, (80, 112)).clone()
+    eng.forward(x)
+    assert torch.equal(eng.predict_semantic(other, text, (80, 112)), a)

@@ -48,6 +48,7 @@ class _EngineBase:
         self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
         self._bufs: Dict[Tuple, torch.Tensor] = {}
         self._buf_gen = 0             # bumped on every (re)allocation: launch plans check it
+        self._pt16_of = self._text16_of = None   # which tensors the cached f16 copies "pt16" / "text16" were made from
 
     def fork(self):
         """A second engine over the SAME parameters and packed weights with its own activation buffers: one per HIP stream
@@ -57,6 +58,7 @@ class _EngineBase:
         e = copy.copy(self)
         e._bufs, e._buf_gen = {}, 0
         e._geo = dict(self._geo)
+        e._pt16_of = e._text16_of = None       # provenance of the f16 copies held in the (new, empty) buffer cache
         return e
 
     def _version_key(self):
@@ -409,13 +411,13 @@ class ZutisEngine(_EngineBase):
         B, h, w, E = patch_tokens.shape
         n = text.shape[0]
         pt16 = self._buf("pt16", (B * h * w, E), f16)
-        if getattr(self, "_pt16_of", None) != (patch_tokens.data_ptr(), patch_tokens._version, tuple(patch_tokens.shape)):
+        if self._pt16_of != (patch_tokens.data_ptr(), patch_tokens._version, tuple(patch_tokens.shape)):
             ops.cast_f16(patch_tokens.contiguous(), pt16, B * h * w, E)     # tokens not produced by the last forward()
         t32 = text.detach().to(device=patch_tokens.device, dtype=f32).contiguous()
         t16 = self._buf("text16", (n, E), f16)
         tkey = (t32.data_ptr(), t32._version, tuple(t32.shape), self._buf_gen)
         recording = _lib_recorder() is not None                              # a launch plan always contains the cast
-        if recording or getattr(self, "_text16_of", None) != tkey:           # eager: the category embeddings rarely change
+        if recording or self._text16_of != tkey:           # eager: the category embeddings rarely change
             ops.cast_f16(t32, t16, n, E)
             self._text16_of = None if recording else tkey
         lo = torch.empty((B, n, h, w), dtype=f32, device=patch_tokens.device)
