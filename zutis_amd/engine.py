@@ -16,6 +16,7 @@ Reference call sites are cited per step (paths relative to the reference root).
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -346,7 +347,7 @@ class ZutisEngine(_EngineBase):
         ws = self._buf("gln_ws", (max(1, ops.global_ln_l2_workspace_size(B, M, self.E)),), torch.uint8)
         pt16 = self._buf("pt16", (B * M, self.E), f16)         # the f16 copy predict_semantic's class-logit GEMM consumes
         ops.global_ln_l2(ts, B, M, self.E, out_f32=pt, out_f16=pt16, eps=1e-5, l2_eps=1e-7, workspace=ws)  # :320-322
-        self._pt16_of = (pt.data_ptr(), pt._version, tuple(pt.shape))
+        self._pt16_of = (weakref.ref(pt), pt._version)           # identity, not address: a freed tensor's address can be reused
         return {"mask_proposals": masks, "patch_tokens": pt}
 
     # ------------------------------------------------------------------ hipGraph replay (latency path)
@@ -411,15 +412,18 @@ class ZutisEngine(_EngineBase):
         B, h, w, E = patch_tokens.shape
         n = text.shape[0]
         pt16 = self._buf("pt16", (B * h * w, E), f16)
-        if self._pt16_of != (patch_tokens.data_ptr(), patch_tokens._version, tuple(patch_tokens.shape)):
+        src = self._pt16_of
+        if not (src is not None and src[0]() is patch_tokens and src[1] == patch_tokens._version):
             ops.cast_f16(patch_tokens.contiguous(), pt16, B * h * w, E)     # tokens not produced by the last forward()
+            self._pt16_of = None
         t32 = text.detach().to(device=patch_tokens.device, dtype=f32).contiguous()
         t16 = self._buf("text16", (n, E), f16)
-        tkey = (t32.data_ptr(), t32._version, tuple(t32.shape), self._buf_gen)
         recording = _lib_recorder() is not None                              # a launch plan always contains the cast
-        if recording or self._text16_of != tkey:           # eager: the category embeddings rarely change
+        src = self._text16_of
+        same = src is not None and src[0]() is text and src[1] == text._version and src[2] == self._buf_gen
+        if recording or not same:                                            # eager: the category embeddings rarely change
             ops.cast_f16(t32, t16, n, E)
-            self._text16_of = None if recording else tkey
+            self._text16_of = None if recording else (weakref.ref(text), text._version, self._buf_gen)
         lo = torch.empty((B, n, h, w), dtype=f32, device=patch_tokens.device)
         ops.gemm(t16, pt16, lo, M=n, N=h * w, K=E, lda=E, ldw=E, ldc=h * w, batch=B, strideA=0, strideW=h * w * E,
                  strideC=n * h * w)
