@@ -2,7 +2,8 @@
 
 CPU restatement (plain PyTorch fp32 functional ops + NumPy) of the reference's
 ZUTIS dense-prediction hot path.  Only tests/, __graft_entry__.smoke() and
-bench.py's cpu_baseline leg may import this package; the product path
+bench.py's baseline legs (cpu_baseline; the optional --torch-gpu-baseline, which
+runs these same functions on the GPU as the "stock PyTorch" reference) may import this package; the product path
 (zutis_amd/) never does.
 
 Pinned: every function here is checked against outputs of the real reference
