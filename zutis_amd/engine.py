@@ -22,7 +22,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import ZutisHipError
 
 f16, f32 = torch.float16, torch.float32
@@ -30,11 +30,6 @@ f16, f32 = torch.float16, torch.float32
 
 def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
-
-
-def _lib_recorder():
-    from . import _lib
-    return _lib.RECORDER
 
 
 class _EngineBase:
@@ -418,7 +413,7 @@ class ZutisEngine(_EngineBase):
             self._pt16_of = None
         t32 = text.detach().to(device=patch_tokens.device, dtype=f32).contiguous()
         t16 = self._buf("text16", (n, E), f16)
-        recording = _lib_recorder() is not None                              # a launch plan always contains the cast
+        recording = _lib.RECORDER is not None                              # a launch plan always contains the cast
         src = self._text16_of
         same = src is not None and src[0]() is text and src[1] == text._version and src[2] == self._buf_gen
         if recording or not same:                                            # eager: the category embeddings rarely change
