@@ -34,7 +34,7 @@ struct GemmArgs {
   void* C; long ldc, sC;
   const float* bias;
   const float* R; long ldr, sR; int res_rows;
-  int M, N, K, act, nbm, nbn, vec_ok;
+  int M, N, K, act, nbm, nbn, vec_ok, group_m;
 #ifdef ZH_GEMM_PROBE
   long long* probe;   // developer build (tools/gemm_probe.py): 4 timestamps per block
 #endif
@@ -97,10 +97,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const int batch = wg / tiles;
   const int trem = wg - batch * tiles;
   // super-tile order: GROUP_M consecutive ids walk GROUP_M m-tiles of one n-tile
-  const int gsz = GROUP_M * p.nbn;
+  const int gsz = p.group_m * p.nbn;
   const int gid = trem / gsz;
-  const int gfirst = gid * GROUP_M;
-  const int grows = min(p.nbm - gfirst, GROUP_M);
+  const int gfirst = gid * p.group_m;
+  const int grows = min(p.nbm - gfirst, p.group_m);
   const int gl = trem - gid * gsz;
   const int tm = gfirst + gl % grows, tn = gl / grows;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -386,6 +386,9 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   p.C = C; p.ldc = ldc; p.sC = strideC;
   p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
   p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
+  // super-tile height (developer override ZH_GEMM_GROUP_M): 3..8 measure within 1 % of each other on the model, 16 / 32 lose
+  // 13 / 36 % on 8192^3 (tools/gemm_vs_blaslt.py) — the order in which an XCD's 32 resident tiles share panels matters
+  { const char* g = getenv("ZH_GEMM_GROUP_M"); p.group_m = g ? atoi(g) : GROUP_M; if (p.group_m < 1) p.group_m = GROUP_M; }
 #ifdef ZH_GEMM_PROBE
   p.probe = g_probe;
 #endif
