@@ -35,6 +35,23 @@ def _worker(rank, world, port, n_images, q):
         zd.all_reduce_confusion(hist)
         ref = torch.bincount((5 * labels + preds).reshape(-1), minlength=25).reshape(5, 5)
         assert torch.equal(hist, ref)
+        # sharded retrieval (config 5): local top-k per shard, all-gather of the candidates, identical merge on every rank.
+        # The local top-k is a GPU kernel in the product; here the oracle stands in for it so that the collective + merge
+        # bookkeeping (offsets, padding of short shards, tie order) runs on CPU.
+        from oracle import zutis_ref as O
+        from zutis_amd import retrieval
+        text = torch.randn((4, 16), generator=g)
+        images = torch.randn((n_images + 4, 16), generator=g)
+        images[5] = images[2]                                            # exact score tie across shards: smaller index first
+        def cpu_topk(t, im, k):
+            i, v = O.retrieve_topk(t.numpy(), im.numpy(), k)
+            return torch.from_numpy(i), torch.from_numpy(v)
+        retrieval.retrieve_topk = cpu_topk
+        lo2, hi2 = zd.shard_range(images.shape[0], rank, world)
+        k = 6                                                            # > the smaller shard: exercises the -1 / -inf padding
+        idx, val = retrieval.retrieve_topk_sharded(text, images[lo2:hi2], lo2, k)
+        ri, rv = cpu_topk(text, images, k)
+        assert torch.equal(idx, ri) and torch.allclose(val, rv)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

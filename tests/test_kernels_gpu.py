@@ -354,3 +354,23 @@ def test_mask_runs_device_rle_matches_host_encoder(dev):
             assert boxes[j] == rle.mask_to_box(m)
     rles2, _, _ = ZutisEngine.encode_masks(None, dm, np.array([0], np.int32), max_runs=16)     # overflow -> host fallback
     assert rles2[0] == rle.encode(masks[0])
+
+
+def test_retrieval_shard_merge_equals_unsharded(dev):
+    """Per-shard device top-k + merge_topk (what retrieve_topk_sharded does after its all-gather) == retrieve_topk over all
+    images, including an exact cross-shard score tie (smaller global index first) and a shard shorter than k."""
+    from zutis_amd import retrieval, detgen
+    C, E, N, k = 5, 64, 700, 40
+    t = detgen.text_embeddings(C, E, seed=3)
+    im = detgen.text_embeddings(N, E, seed=4)
+    im[650] = im[10]
+    td, imd = torch.from_numpy(t).to(dev), torch.from_numpy(im).to(dev)
+    ref_i, ref_v = retrieval.retrieve_topk(td, imd, k)
+    cand_i, cand_v = [], []
+    for lo, hi in ((0, 30), (30, 400), (400, 700)):                   # first shard shorter than k
+        i, v = retrieval.retrieve_topk(td, imd[lo:hi], min(k, hi - lo))
+        pi = torch.full((C, k), -1, dtype=torch.int64, device=dev); pv = torch.full((C, k), float("-inf"), device=dev)
+        pi[:, : i.shape[1]] = i + lo; pv[:, : v.shape[1]] = v
+        cand_i.append(pi); cand_v.append(pv)
+    mi, mv = retrieval.merge_topk(torch.cat(cand_i, 1), torch.cat(cand_v, 1), k)
+    assert torch.equal(mi, ref_i) and torch.equal(mv, ref_v)
