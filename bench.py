@@ -120,6 +120,9 @@ def main():
                          "(BASELINE config 4).  c5: CLIP ViT-L/14@336 image-embedding extraction, 256 / GPU / step (config 5)")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
+    ap.add_argument("--precision", default="fast", choices=["fast", "exact", "f16"],
+                    help="engine precision (zutis_amd/engine.py): fast = fp16 MFMA operands in the transformer bodies + the fp32-class "
+                         "x3 mode on the output-facing contractions (passes tests/test_precision_gpu.py at 1e-3); exact = x3 everywhere")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-gpu-baseline", action="store_true",
                     help="also time the oracle (= the reference's op sequence) with stock PyTorch-ROCm fp32 eager ops on this GPU "
@@ -158,7 +161,7 @@ def main():
     cfg = detgen.VIT_B16
     B, S, n = args.batch, args.size, args.classes
     P = {k: torch.from_numpy(v).to(dev) for k, v in detgen.zutis_state_dict(cfg).items()}
-    eng = ZutisEngine(P, cfg.patch, cfg.dec_heads)
+    eng = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=args.precision)
     text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
     # rank r owns global images [r*B, (r+1)*B): contiguous shards so a gather reproduces reference order
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)

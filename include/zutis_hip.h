@@ -11,6 +11,10 @@
  *     frees or synchronises.  Scratch is passed in (void* workspace, size_t bytes) with a *_workspace_size query.
  *   - Last argument: the hipStream_t to launch on (pass torch.cuda.current_stream().cuda_stream).
  *   - Layout: contiguous row-major, tokens channels-last [B, T, D].  "f16" = IEEE half; fp32 accumulate everywhere.
+ *   - Split pairs (the reference-equivalent "f16x3" precision): a tensor x stored as two fp16 planes, hi = f16(x) at the
+ *     pointer and lo = f16(x - hi) `lo_plane` ELEMENTS further on (22 significand bits).  Producers take a `lo_plane`
+ *     argument (0 = write the plain fp16 tensor only; the hi plane alone IS that tensor); zh_gemm_f16x3 and the split-pair
+ *     form of zh_attention_f16 consume them.
  *   - Re-entrant; no global mutable state.
  */
 #ifndef ZUTIS_HIP_H
@@ -51,19 +55,34 @@ int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, 
                 const float* bias, const float* residual, long ldr, long strideR, int res_rows,
                 int act, int M, int N, int K, int batch, zh_stream_t stream);
 
+/* The same contraction at the reference's precision (the reference computes every Linear / einsum in fp32:
+ * clip_arch.py:286-292 keeps LayerNorm fp32, zutis.py:55 casts the CLIP weights to fp32).  A and W are split pairs
+ * (planeA / planeW = element offset of the lo plane); the kernel accumulates Ah.Wh + Ah.Wl + Al.Wh in fp32 (dropped
+ * term: 2^-22 relative) and multiplies the accumulator by out_scale (weights are packed as W * 2^s, out_scale = 2^-s,
+ * so that lo planes stay normal fp16 numbers) before the bias.  out_kind: 0 = f32 (residual allowed), 1 = f16,
+ * 2 = split pair (lo plane at C + planeC). */
+int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void* W, long ldw, long strideW, long planeW,
+                  void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
+                  const float* bias, const float* residual, long ldr, long strideR, int res_rows,
+                  int act, int M, int N, int K, int batch, zh_stream_t stream);
+
 /* Flash attention: O = softmax(scale * Q K^T) V per (image, head); Q [Tq, heads*dh] rows with stride ldq, etc.
  * f16 in/out, fp32 softmax/accumulate; head_dim in {64, 96}.
+ * planeQ / planeK != 0 (both or neither): Q and K are split pairs and the scores are Kh.Qh + Kl.Qh + Kh.Ql (fp32-class
+ * exponents; P.V stays fp16 x fp16).  planeO != 0: O is written as a split pair.
  * Replaces nn.MultiheadAttention core at clip_arch.py:314-316, transformer.py:272-286,
  * selfmask/vision_transformer.py:110-133 (which materialises [B,heads,T,T]). */
 int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                      const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
-                     int batch, int heads, int Tq, int Tk, int head_dim, float scale, zh_stream_t stream);
+                     int batch, int heads, int Tq, int Tk, int head_dim, float scale,
+                     long planeQ, long planeK, long planeO, zh_stream_t stream);
 
 /* The same under CLIP's causal mask (build_attention_mask, clip_arch.py:525-531: -inf above the diagonal), Tq = Tk = T:
  * the text tower's resblocks (clip_arch.py:534-541). */
 int zh_attention_causal_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                             const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
-                            int batch, int heads, int T, int head_dim, float scale, zh_stream_t stream);
+                            int batch, int heads, int T, int head_dim, float scale,
+                            long planeQ, long planeK, long planeO, zh_stream_t stream);
 
 /* Text tower glue.  x = token_embedding(text) + positional_embedding (clip_arch.py:535-537): tokens int64 [n,ctx],
  * table f32 [vocab,D], pos f32 [ctx,D] -> out f32 [n*ctx, D]. */
@@ -84,7 +103,7 @@ int zh_layernorm_f32(const float* x, long in_group_rows, long in_group_stride, l
                      long out_group_rows, long out_group_stride, long out_offset,
                      const float* gamma, const float* beta, float eps,
                      float* out_f32, void* out_f16, void* out_f16_plus, float* out_f32_plus,
-                     const float* add, int add_rows, int rows, int D, zh_stream_t stream);
+                     const float* add, int add_rows, int rows, int D, long lo_plane, zh_stream_t stream);
 
 /* cat(class_embedding, patch_emb) + pos_embed, then ln_pre: clip_arch.py:384-397.  out [B,T,D] f32.
  * gamma = beta = NULL: no LayerNorm (DINO ViT prepare_tokens, selfmask/vision_transformer.py:269-281). */
@@ -93,18 +112,18 @@ int zh_assemble_tokens_ln(const float* patch_emb, const float* class_embedding, 
                           int B, int T, int D, zh_stream_t stream);
 
 /* x / (||x||_2 + eps) per row: queries (eps = 0) zutis.py:515; averaged tokens (eps = 1e-7) zutis.py:413. */
-int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, zh_stream_t stream);
+int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, long lo_plane, zh_stream_t stream);
 
 /* F.layer_norm over the whole (h,w,c) volume per image (no affine) then x/(||x||_c + l2_eps): zutis.py:320-322. */
 size_t zh_global_ln_l2_workspace_size(int B, int M, int C);
 int zh_global_ln_l2(const float* x, float* out_f32, void* out_f16, float eps, float l2_eps,
-                    int B, int M, int C, void* workspace, size_t workspace_bytes, zh_stream_t stream);
+                    int B, int M, int C, void* workspace, size_t workspace_bytes, long lo_plane, zh_stream_t stream);
 
 /* im2col of the stride==kernel patch conv (pure re-index): clip_arch.py:340,378; selfmask/vision_transformer.py:182.
  * out f16 [B*gh*gw, Kpad], k = c*p*p + i*p + j, zero padded.  pad_to_patch = 0: gh = floor((H-p)/p)+1 (CLIP, trailing
  * pixels dropped); 1: gh = ceil(H/p) with zero pixels (make_input_divisible, selfmask/vision_transformer.py:260-267). */
 int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, int pad_to_patch,
-                  zh_stream_t stream);
+                  long lo_plane, zh_stream_t stream);
 
 /* Bicubic positional-embedding resample: clip_arch.py:356-374 (scale = float(1/((h+0.1)/g))) and
  * selfmask/vision_transformer.py:377-401 (scale = g/h).  pos [has_cls + g*g, D] -> out [has_cls + h*w, D]. */
@@ -112,19 +131,22 @@ int zh_posembed_bicubic(const float* pos, float* out, int grid, int h, int w, in
                         int has_cls, zh_stream_t stream);
 
 /* F.interpolate(scale_factor=2, bilinear) on channels-last tokens: zutis.py:491-495. */
-int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, zh_stream_t stream);
+int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, long lo_plane,
+                              zh_stream_t stream);
 
 /* PositionEmbeddingSine(normalize=True): positional_embedding.py:29-52 -> [h*w, D] channels-last. */
 int zh_sine_pe(float* out, int h, int w, int D, float temperature, zh_stream_t stream);
 
-/* memory + pos (transformer.py:281): out f16 = a f16 + add f32[r % add_rows]. */
-int zh_add_rowperiodic_f16(const void* a, const float* add, void* out, long rows, int D, int add_rows, zh_stream_t stream);
+/* memory + pos (transformer.py:281): out f16 = a f16 + add f32[r % add_rows].  a_lo_plane != 0: a is a split pair. */
+int zh_add_rowperiodic_f16(const void* a, const float* add, void* out, long rows, int D, int add_rows, long a_lo_plane,
+                           long lo_plane, zh_stream_t stream);
 
 /* x[i] = value (tgt = zeros_like(queries), zutis.py:164) — a kernel so that it can be part of a launch plan. */
 int zh_fill_f32(float* x, float value, long n, zh_stream_t stream);
 
 /* f32 -> f16 (optionally + add[r % add_rows]). */
-int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, zh_stream_t stream);
+int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, long lo_plane,
+                    zh_stream_t stream);
 
 /* argmax_c(F.interpolate(logits, size=(H,W), bilinear)) fused, bit-identical to ATen incl. ties: zutis.py:366-372.
  * logits_lo f32 [B,n,h,w] -> labels int64 [B,H,W].  scale_* = float32(in)/float32(out) computed by the host. */

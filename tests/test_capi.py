@@ -34,8 +34,13 @@ def test_argument_validation_without_gpu(lib):
     # shape/alignment checks happen before any launch, so they are testable on CPU
     rc = lib.zh_gemm_f16(None, 0, 0, None, 0, 0, None, 0, 0, 0, None, None, 0, 0, 0, 0, 8, 8, 64, 1, None)
     assert rc == -1 and b"null" in lib.zh_last_error()
-    rc = lib.zh_attention_f16(16, 8, 8, 16, 8, 8, 16, 8, 8, 16, 8, 8, 1, 1, 4, 4, 80, 1.0, None)
+    rc = lib.zh_attention_f16(16, 8, 8, 16, 8, 8, 16, 8, 8, 16, 8, 8, 1, 1, 4, 4, 80, 1.0, 0, 0, 0, None)
     assert rc == -1 and b"head_dim" in lib.zh_last_error()
+    rc = lib.zh_attention_f16(16, 8, 8, 16, 8, 8, 16, 8, 8, 16, 8, 8, 1, 1, 4, 4, 64, 1.0, 64, 0, 0, None)
+    assert rc == -1 and b"lo planes of both" in lib.zh_last_error()
+    # the reference-equivalent GEMM refuses plain fp16 operands (no silent precision downgrade)
+    rc = lib.zh_gemm_f16x3(16, 64, 0, 0, 16, 64, 0, 0, 16, 8, 0, 0, 0, 1.0, None, None, 0, 0, 0, 0, 8, 8, 64, 1, None)
+    assert rc == -1 and b"split pairs" in lib.zh_last_error()
     assert lib.zh_global_ln_l2_workspace_size(2, 1764, 512) == 2 * ((1764 * 512 + 4095) // 4096) * 16
 
 
@@ -81,3 +86,17 @@ def test_launch_plan_dispatcher_matches_header_and_bindings(tmp_path):
     assert plan._word("float", 1.5) == struct.unpack("<I", struct.pack("<f", 1.5))[0]
     assert plan._word("double", -2.0) == struct.unpack("<Q", struct.pack("<d", -2.0))[0]
     assert plan._word("const float*", None) == 0 and plan._word("int", -1) == 0xFFFFFFFFFFFFFFFF
+
+
+def test_precision_site_sets():
+    """Host logic (no kernels): named precisions and the closure of custom site sets."""
+    from zutis_amd import engine as E
+    assert E.resolve_precision("f16") == frozenset()
+    assert E.resolve_precision("exact") == frozenset(E.ALL_SITES)
+    assert E.resolve_precision("fast") == frozenset(E.HEAD_SITES)
+    assert E.resolve_precision(["attn"]) == {"attn", "qkv"}
+    assert E.resolve_precision(["mask"]) == {"mask", "ffn1"}
+    with pytest.raises(E.ZutisHipError):
+        E.resolve_precision("bf16")
+    with pytest.raises(E.ZutisHipError):
+        E.resolve_precision(["nope"])

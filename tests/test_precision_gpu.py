@@ -1,0 +1,242 @@
+"""-m gpu: the precision ladder (SURVEY.md §7 "Precision vs roofline").
+
+The reference computes in fp32 end to end (networks/clip_arch.py:286-292, networks/zutis.py:55).  This file pins
+ (1) the reference-equivalent contraction mode — fp16 split pairs, three MFMA products (zh_gemm_f16x3, split-pair scores in
+     zh_attention_f16) — against float64 references on operands that are NOT fp16-representable;
+ (2) the whole forward on the outlier-channel stress model (detgen.stress_state_dict: x100 residual channels, sharpened
+     attention, true-fp32 weights) against the fp32 oracle, for both engine precisions:
+       "exact" (x3 everywhere): logits / masks within 2e-5 / 2e-4 — fp32-reordering class;
+       "fast"  (x3 on the output-facing contractions, fp16 operands in the transformer bodies): within the north-star
+               tolerance 1e-3 with margin (asserted at 2.5e-4 / 1e-3).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+f16, f32, f64 = torch.float16, torch.float32, torch.float64
+
+
+def _randn(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _split_act(x32, dev):
+    """fp32 [rows, K] -> Act split pair on the device (what a producer kernel with lo_plane != 0 writes)."""
+    from zutis_amd.ops import Act
+    hi = x32.to(f16)
+    lo = (x32 - hi.float()).to(f16)
+    return Act(torch.stack([hi, lo]).contiguous().to(dev))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 64, 64), (300, 200, 192), (442, 768, 768), (1500, 2304, 768), (2100, 768, 3072),
+                                   (100, 1764, 768), (81, 1764, 512), (37, 52, 128), (600, 1, 384)])
+def test_gemm_x3_matches_float64(dev, M, N, K):
+    """Generic fp32 operands with a x1000 dynamic range: |err| <= 2e-6 * sum_k |a||w| (fp32-class), where the fp16-operand
+    GEMM on the same data is ~500x worse."""
+    from zutis_amd import ops
+    A = _randn((M, K), 1) * torch.exp(_randn((M, K), 11) * 1.5)
+    W = _randn((N, K), 2, 0.03) * torch.exp(_randn((N, K), 12) * 1.5)
+    bias = _randn((N,), 3)
+    ref = A.double() @ W.double().t() + bias.double()
+    bound = (A.abs().double() @ W.abs().double().t())
+    out = torch.empty((M, N), dtype=f32, device=dev)
+    ops.gemm_x3(_split_act(A, dev), ops.split_weight(W.to(dev)), out, bias=bias.to(dev))
+    err = (out.cpu().double() - ref).abs()
+    assert float((err / (bound + 1e-30)).max()) < 2e-6
+    out16 = torch.empty((M, N), dtype=f32, device=dev)
+    if K % 64 == 0 and N % 4 == 0:
+        ops.gemm(A.to(f16).to(dev), W.to(f16).to(dev), out16, bias=bias.to(dev))
+        e16 = (out16.cpu().double() - ref).abs()
+        assert float(err.max()) * 50 < float(e16.max())
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_gemm_x3_epilogues_and_outputs(dev, act):
+    """bias + activation + residual (f32 out), f16 out, and split-pair out whose hi + lo reproduces the fp32 result to 22 bits;
+    batched form with a shared A."""
+    import torch.nn.functional as F
+    from zutis_amd import ops, _lib
+    from zutis_amd.ops import Act
+    M, N, K = 520, 264, 128
+    A, W = _randn((M, K), 3, 0.5), _randn((N, K), 4, 0.2)
+    bias, res = _randn((N,), 5), _randn((50, N), 6)
+    y = A.double() @ W.double().t() + bias.double()
+    y = [y, y * torch.sigmoid(1.702 * y), F.relu(y), torch.sigmoid(y), F.gelu(y)][act]
+    Ad, Wd = _split_act(A, dev), ops.split_weight(W.to(dev))
+    if act in (0, 3):
+        out = torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm_x3(Ad, Wd, out, bias=bias.to(dev), residual=res.to(dev), res_rows=50, act=act)
+        ref = y + res.double()[torch.arange(M) % 50]
+        assert float((out.cpu().double() - ref).abs().max()) < 3e-6
+    if act != 3:
+        o16 = Act.empty((M, N), False, dev)
+        ops.gemm_x3(Ad, Wd, o16, bias=bias.to(dev), act=act)
+        assert torch.allclose(o16.hi.float().cpu().double(), y, atol=4e-3, rtol=1e-3)
+        osp = Act.empty((M, N), True, dev)
+        ops.gemm_x3(Ad, Wd, osp, bias=bias.to(dev), act=act)
+        assert torch.equal(osp.hi, o16.hi)                               # the hi plane IS the plain fp16 tensor
+        both = osp.t[0].float() + osp.t[1].float()
+        tol = 2e-6 if act != 4 else 2e-5                                 # erff on the device vs torch's erf
+        assert float((both.cpu().double() - y).abs().max()) < tol * max(1.0, float(y.abs().max()))
+    else:
+        with pytest.raises(_lib.ZutisHipError):
+            ops.gemm_x3(Ad, Wd, Act.empty((M, N), False, dev), act=act)
+
+
+def test_gemm_x3_batched_activation_operands(dev):
+    """The mask einsum form (zutis.py:196-198): both operands are activations (split pairs, scale 1), batched."""
+    from zutis_amd import ops
+    B, Q, Mpix, D = 3, 100, 1764, 768
+    q, t = _randn((B * Q, D), 1, 0.05), _randn((B * Mpix, D), 2, 2.0)
+    out = torch.empty((B, Q, Mpix), dtype=f32, device=dev)
+    ops.gemm_x3(_split_act(q, dev), _split_act(t, dev), out, act=ops.ACT_SIGMOID, M=Q, N=Mpix, K=D, lda=D, ldw=D, ldc=Mpix,
+                batch=B, strideA=Q * D, strideW=Mpix * D, strideC=Q * Mpix)
+    ref = torch.sigmoid(torch.einsum("bqc,bnc->bqn", q.view(B, Q, D).double(), t.view(B, Mpix, D).double()))
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-6
+
+
+def test_gemm_x3_race_screen_bitwise_repeatable(dev):
+    """The x3 K loop is a 3-slot LDS-DMA ring with counted vmcnt waits: a mis-counted wait shows up as rare wrong tiles."""
+    from zutis_amd import ops
+    for (M, N, K) in [(3000, 2304, 768), (1500, 768, 3072), (700, 640, 192), (300, 200, 64), (5000, 512, 128)]:
+        A, W = _split_act(_randn((M, K), 100 + M), dev), ops.split_weight(_randn((N, K), 200 + N, 0.05).to(dev))
+        outs = []
+        for _ in range(6):
+            o = torch.empty((M, N), dtype=f32, device=dev)
+            ops.gemm_x3(A, W, o)
+            outs.append(o)
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        ref = (A.t[0].double() + A.t[1].double()) @ ((W.t[0].double() + W.t[1].double()) * W.out_scale).t()
+        assert float((outs[0].double() - ref).abs().max()) < 1e-4 * math.sqrt(K / 64)
+
+
+def test_split_producers_write_hi_plus_lo(dev):
+    """Every producer with a lo_plane argument: hi plane == the plain fp16 output, hi + lo == the fp32 value to ~2^-22."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    rows, D = 300, 768
+    x = (_randn((rows, D), 1) * torch.exp(_randn((rows, D), 2))).to(dev)
+    g, b = _randn((D,), 3, 0.1).add(1).to(dev), _randn((D,), 4, 0.1).to(dev)
+
+    def check(pair: Act, plain: Act, ref32, tol=3e-7):
+        assert torch.equal(pair.hi, plain.hi)
+        both = pair.t[0].float() + pair.t[1].float()
+        scale = ref32.abs().clamp_min(0.25)
+        assert float(((both - ref32).abs() / scale).max()) < tol
+
+    y32 = torch.empty((rows, D), dtype=f32, device=dev)
+    sp, pl = Act.empty((rows, D), True, dev), Act.empty((rows, D), False, dev)
+    ops.layernorm(x, g, b, 1e-5, rows, D, out_f32=y32, out_f16=sp)
+    ops.layernorm(x, g, b, 1e-5, rows, D, out_f16=pl)
+    check(sp, pl, y32)
+    ops.cast_f16(x, sp, rows, D); ops.cast_f16(x, pl, rows, D)
+    check(sp, pl, x)
+    ops.l2norm_rows(x, rows, D, out_f32=y32, out_f16=sp); ops.l2norm_rows(x, rows, D, out_f16=pl)
+    check(sp, pl, y32)
+    B, h, w = 2, 5, 7
+    t = _randn((B, h * w, D), 5).to(dev)
+    u32 = torch.empty((B * 4 * h * w, D), dtype=f32, device=dev)
+    usp, upl = Act.empty((B * 4 * h * w, D), True, dev), Act.empty((B * 4 * h * w, D), False, dev)
+    ops.upsample2x_cl(t, B, h, w, D, out_f32=u32, out_f16=usp); ops.upsample2x_cl(t, B, h, w, D, out_f16=upl)
+    check(usp, upl, u32)
+    pe = _randn((4 * h * w, D), 6).to(dev)
+    ksp, kpl = Act.empty((B * 4 * h * w, D), True, dev), Act.empty((B * 4 * h * w, D), False, dev)
+    ops.add_rowperiodic_f16(usp, pe, ksp, B * 4 * h * w, D, 4 * h * w)
+    ref = (usp.t[0].float() + usp.t[1].float()) + pe.repeat(B, 1)
+    both = ksp.t[0].float() + ksp.t[1].float()
+    assert float(((both - ref).abs() / ref.abs().clamp_min(0.25)).max()) < 3e-7
+    ops.add_rowperiodic_f16(upl, pe, kpl, B * 4 * h * w, D, 4 * h * w)
+    assert torch.equal(kpl.hi, (upl.hi.float() + pe.repeat(B, 1)).to(f16))
+    # im2col: scalar and vector paths, zero padding of K
+    img = _randn((2, 3, 80, 112), 7).to(dev)
+    Kp = 768
+    csp, cpl = Act.empty((2 * 5 * 7, Kp), True, dev), Act.empty((2 * 5 * 7, Kp), False, dev)
+    ops.im2col(img, csp, 16, Kp); ops.im2col(img, cpl, 16, Kp)
+    cols = torch.nn.functional.unfold(img, 16, stride=16).transpose(1, 2).reshape(-1, 768)
+    check(csp, cpl, cols)
+    img2 = _randn((1, 3, 37, 45), 8).to(dev)
+    c2 = Act.empty((5 * 6, 192), True, dev)
+    ops.im2col(img2, c2, 8, 192, pad_to_patch=True)
+    pad = torch.nn.functional.pad(img2, (0, 3, 0, 3))
+    cols2 = torch.nn.functional.unfold(pad, 8, stride=8).transpose(1, 2).reshape(-1, 192)
+    assert float(((c2.t[0].float() + c2.t[1].float()) - cols2).abs().max()) < 1e-6
+    # global LN + L2
+    ts = _randn((2, 4 * h * w, 512), 9).to(dev).contiguous()
+    p32 = torch.empty_like(ts)
+    psp, ppl = Act.empty((2 * 4 * h * w, 512), True, dev), Act.empty((2 * 4 * h * w, 512), False, dev)
+    ops.global_ln_l2(ts, 2, 4 * h * w, 512, out_f32=p32, out_f16=psp); ops.global_ln_l2(ts, 2, 4 * h * w, 512, out_f16=ppl)
+    assert torch.equal(psp.hi, ppl.hi)
+    assert float(((psp.t[0].float() + psp.t[1].float()).view_as(p32) - p32).abs().max()) < 1e-7
+
+
+@pytest.mark.parametrize("dh,heads,Tq,Tk,causal", [(64, 3, 442, 442, False), (96, 2, 100, 1764, False), (64, 2, 77, 77, True), (64, 1, 130, 700, False)])
+def test_attention_x3_scores(dev, dh, heads, Tq, Tk, causal):
+    """Split-pair scores: large, sharply peaked logits (|s| up to ~60) where fp16 operand rounding moves the softmax by ~1e-2
+    but the x3 form stays at the fp16-P/V floor."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    B, D = 2, heads * dh
+    q, k, v = _randn((B * Tq, D), 1, 2.5), _randn((B * Tk, D), 2, 2.5), _randn((B * Tk, D), 3)
+    qd, kd = q.view(B, Tq, heads, dh).transpose(1, 2).double(), k.view(B, Tk, heads, dh).transpose(1, 2).double()
+    vd = v.to(f16).view(B, Tk, heads, dh).transpose(1, 2).double()
+    s = qd @ kd.transpose(-1, -2) / math.sqrt(dh)
+    if causal:
+        s = s + torch.full((Tq, Tk), float("-inf"), dtype=f64).triu_(1)
+    ref = (torch.softmax(s, -1) @ vd).transpose(1, 2).reshape(B * Tq, D)
+    Q, K, V = _split_act(q, dev), _split_act(k, dev), Act(v.to(f16).to(dev)[None].contiguous())
+    kw = dict(batch=B, heads=heads, Tq=Tq, Tk=Tk, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=Tq * D, strideK=Tk * D,
+              strideV=Tk * D, strideO=Tq * D, causal=causal)
+    O3, O1 = Act.empty((B * Tq, D), True, dev), Act.empty((B * Tq, D), False, dev)
+    ops.attention(Q, K, V, O3, x3=True, **kw)
+    ops.attention(Q, K, V, O1, x3=False, **kw)
+    e3 = float(((O3.t[0].float() + O3.t[1].float()).cpu().double() - ref).abs().max())
+    e1 = float((O1.hi.float().cpu().double() - ref).abs().max())
+    assert e3 < 2e-3 and e3 * 4 < e1, (e3, e1)
+
+
+# ------------------------------------------------------------------------------------------- whole-model stress test
+def _stress_case(dev, B, S, sharp=3.0):
+    from zutis_amd import detgen
+    from oracle import zutis_ref as O
+    cfg = detgen.VIT_B16
+    sd = detgen.stress_state_dict(cfg, 100.0)
+    D = cfg.width
+    for i in range(cfg.layers):                    # sharpen the encoder's attention: |scores| up to ~50 instead of ~6
+        sd[f"encoder.transformer.resblocks.{i}.attn.in_proj_weight"][:2 * D] *= np.float32(sharp)
+    x = torch.from_numpy(detgen.images(B, S, S))
+    text = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim))
+    with torch.no_grad():
+        ref = O.zutis_forward(O.to_torch_params(sd), x, cfg.patch, cfg.dec_heads)
+        lo_ref = O.semantic_logits_lowres(ref["patch_tokens"], text).numpy()
+        lab_ref = O.predict_semantic(ref["patch_tokens"], text, size=(S, S))
+    return cfg, sd, x, text, ref, lo_ref, lab_ref
+
+
+@pytest.fixture(scope="module")
+def stress(dev):
+    return _stress_case(dev, 2, 336)
+
+
+@pytest.mark.parametrize("precision,tol_logit,tol_mask,min_agree", [("exact", 2e-5, 2e-4, 0.9999), ("fast", 2.5e-4, 1e-3, 0.999)])
+def test_stress_model_c2(dev, stress, precision, tol_logit, tol_mask, min_agree):
+    """ViT-B/16 @336 (config 2 geometry), x100 outlier residual channels, sharpened attention, generic fp32 weights:
+    HIP engine vs the fp32 oracle.  North-star tolerance: logits within 1e-3."""
+    from zutis_amd.engine import ZutisEngine
+    cfg, sd, x, text, ref, lo_ref, lab_ref = stress
+    eng = ZutisEngine({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, cfg.patch, cfg.dec_heads, precision=precision)
+    out = eng.forward(x.to(dev))
+    lo = eng.semantic_logits_lowres(out["patch_tokens"], text.to(dev)).cpu().numpy()
+    lab = eng.predict_semantic(out["patch_tokens"], text.to(dev), (336, 336)).cpu().numpy()
+    e_lo = float(np.abs(lo - lo_ref).max())
+    e_m = float((out["mask_proposals"].cpu() - ref["mask_proposals"]).abs().max())
+    e_pt = float((out["patch_tokens"].cpu() - ref["patch_tokens"]).abs().max())
+    agree = float((lab == lab_ref).mean())
+    print(f"stress[{precision}]: logits {e_lo:.2e} masks {e_m:.2e} patch_tokens {e_pt:.2e} labels {agree:.6f}")
+    assert e_lo < tol_logit and e_pt < tol_logit and e_m < tol_mask and agree >= min_agree, (e_lo, e_pt, e_m, agree)

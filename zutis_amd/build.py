@@ -14,9 +14,9 @@ LIB = os.path.join(HERE, "libzutis_hip.so")
 # float64 bilateral solver: no FMA contraction (bin edges and bistochastisation are bit-compared with NumPy/SciPy)
 EXTRA_FLAGS = {"bilateral.hip": ["-ffp-contract=off"]}
 # the MFMA kernels live at the register budget of their occupancy: a spill is a 2-3x slowdown, so it is a build error
-NO_SCRATCH = {"gemm.hip", "attention.hip"}
+NO_SCRATCH = {"gemm.hip", "gemm_x3.hip", "attention.hip"}
 MAX_SCRATCH = 0    # bytes per lane tolerated: the MFMA loops must not spill
-SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip", "text.hip", "plan.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm_x3.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip", "text.hip", "plan.hip"]
 
 
 def _hipcc() -> str:
@@ -34,7 +34,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h")]
+    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_kernel.h"),
+                        os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -50,6 +51,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(HERE, "_obj", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         deps = [src, os.path.join(CSRC, "common.h")]
+        if os.path.basename(src).startswith("gemm"):
+            deps.append(os.path.join(CSRC, "gemm_kernel.h"))
         if os.path.basename(src) == "plan.hip":                     # includes the dispatcher generated from the header
             deps.append(os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h"))
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):

@@ -25,6 +25,7 @@ struct AttnArgs {
   int Tq, Tk, H;
   float scale_log2;
   int causal;       // keys > query masked (CLIP text tower, clip_arch.py:525-531)
+  long planeQ, planeK, planeO;   // X3 kernels: lo planes of the split-pair Q / K inputs; planeO != 0: O is written as a split pair
 };
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -33,7 +34,11 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 #define KT 64
 #define VS 96
 
-template <int DH, int NWAVE>
+// X3 = 1 (reference-equivalent scores): Q and K arrive as split pairs (hi = f16(x), lo = f16(x - hi)) and
+// S = Kh.Qh + Kl.Qh + Kh.Ql in fp32 — the softmax exponent sees fp32-class scores, which is where fp16 operand rounding is
+// amplified (|s| * 2^-11 absolute).  P.V stays fp16 x fp16: P in [0,1] and V carry independent relative roundings that the
+// weighted average does not amplify.
+template <int DH, int NWAVE, int X3>
 __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   constexpr int NT = 64 * NWAVE;
   constexpr int KS = DH + 8;          // K row stride (halves)
@@ -43,6 +48,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   constexpr int NLD = (KT * CPR) / NT;
   static_assert((KT * CPR) % NT == 0, "tile chunks must divide over the block");
   __shared__ __attribute__((aligned(16))) half_t sKb[2][KT * KS];   // double-buffered: one barrier per key tile
+  __shared__ __attribute__((aligned(16))) half_t sKl[X3 ? 2 : 1][X3 ? KT * KS : 8];   // lo plane of K (X3)
   __shared__ __attribute__((aligned(16))) half_t sVb[2][KT * VS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,13 +62,17 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   const half_t* V = p.V + (long)img * p.sV + hoff;
 
   // Q fragments (B operand: col = query, k = d)
-  half8_t qf[NKS];
+  half8_t qf[NKS], qfl[X3 ? NKS : 1];
   {
     int qr = q0 + ql;
     qr = qr < p.Tq ? qr : p.Tq - 1;
     const half_t* qp = Q + (long)qr * p.ldq + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const half8_t*)(qp + 16 * ks);
+    if (X3) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) qfl[ks] = *(const half8_t*)(qp + p.planeQ + 16 * ks);
+    }
   }
 
   f32x16 oacc[NDT];
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   float m_run = -INFINITY, l_run = 0.f;
 
   // cooperative tile loads: chunk c -> (row = c / CPR, col chunk = c % CPR)
-  half8_t kreg[NLD], vreg[NLD];
+  half8_t kreg[NLD], vreg[NLD], klreg[X3 ? NLD : 1];
   auto load_tile = [&](int kbase) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -83,9 +93,11 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
       if (key < p.Tk) {
         kreg[i] = *(const half8_t*)(K + (long)key * p.ldk + cc * 8);
         vreg[i] = *(const half8_t*)(V + (long)key * p.ldv + cc * 8);
+        if (X3) klreg[i] = *(const half8_t*)(K + p.planeK + (long)key * p.ldk + cc * 8);
       } else {
         kreg[i] = (half8_t)(half_t)0;
         vreg[i] = (half8_t)(half_t)0;
+        if (X3) klreg[i] = (half8_t)(half_t)0;
       }
     }
   };
@@ -96,6 +108,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
       const int row = c / CPR, cc = c - row * CPR;
       *(half8_t*)(sKb[buf] + row * KS + cc * 8) = kreg[i];
       *(half8_t*)(sVb[buf] + row * VS + cc * 8) = vreg[i];
+      if (X3) *(half8_t*)(sKl[buf] + row * KS + cc * 8) = klreg[i];
     }
   };
 
@@ -134,6 +147,11 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
       for (int ks = 0; ks < NKS; ++ks) {
         half8_t kf = *(const half8_t*)(kp + 16 * ks);
         s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[u], 0, 0, 0);
+        if (X3) {
+          half8_t kl = *(const half8_t*)(sKl[t & 1] + (32 * u + krow) * KS + 8 * hh + 16 * ks);
+          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf[ks], s[u], 0, 0, 0);
+          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qfl[ks], s[u], 0, 0, 0);
+        }
       }
     }
     // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
@@ -206,9 +224,8 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        half4_t o = {(half_t)(oacc[d][4 * g] * inv), (half_t)(oacc[d][4 * g + 1] * inv),
-                     (half_t)(oacc[d][4 * g + 2] * inv), (half_t)(oacc[d][4 * g + 3] * inv)};
-        *(half4_t*)(op + 32 * d + 8 * g) = o;
+        const f32x4 o = {oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
+        zh_store_h4(op + 32 * d + 8 * g, p.planeO, o);
       }
   }
 }
@@ -216,16 +233,17 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
 static int attention_launch(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                             const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                             int batch, int heads, int Tq, int Tk, int head_dim, float scale, int causal,
-                            hipStream_t stream) {
+                            long planeQ, long planeK, long planeO, hipStream_t stream) {
   ZH_CHECK_ARG(Q && K && V && O, "zh_attention_f16: null operand");
   ZH_CHECK_ARG(batch > 0 && heads > 0 && Tq > 0 && Tk > 0, "zh_attention_f16: bad shape");
   ZH_CHECK_ARG(head_dim == 64 || head_dim == 96, "zh_attention_f16: head_dim %d not in {64, 96}", head_dim);
   ZH_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && strideQ % 8 == 0 && strideK % 8 == 0 &&
-                   strideV % 8 == 0 && strideO % 4 == 0,
-               "zh_attention_f16: row/batch strides must keep 16-byte (Q,K,V) / 8-byte (O) alignment");
+                   strideV % 8 == 0 && strideO % 4 == 0 && planeQ % 8 == 0 && planeK % 8 == 0 && planeO % 4 == 0,
+               "zh_attention_f16: row/batch/plane strides must keep 16-byte (Q,K,V) / 8-byte (O) alignment");
   ZH_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 && ((uintptr_t)O & 7) == 0,
                "zh_attention_f16: misaligned pointer");
   ZH_CHECK_ARG(heads < 65536 && batch < 65536, "zh_attention_f16: heads/batch exceed grid limits");
+  ZH_CHECK_ARG((planeQ != 0) == (planeK != 0), "zh_attention_f16: split-pair scores need the lo planes of both Q and K");
   AttnArgs p;
   p.Q = (const half_t*)Q; p.ldq = ldq; p.sQ = strideQ;
   p.K = (const half_t*)K; p.ldk = ldk; p.sK = strideK;
@@ -234,11 +252,18 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   p.Tq = Tq; p.Tk = Tk; p.H = heads;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.causal = causal;
+  p.planeQ = planeQ; p.planeK = planeK; p.planeO = planeO;
   // 128-query (4-wave) blocks: each K/V tile is shared four ways.  A 64-query (2-wave) variant was measured slower on
   // every shape of the model (encoder 301 vs 423 TF, cross-attention 230 vs 397 TF) and was dropped.
   dim3 grid(zh_cdiv(Tq, 128), heads, batch);
-  if (head_dim == 64) hipLaunchKernelGGL((attn_f16_kernel<64, 4>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((attn_f16_kernel<96, 4>), grid, dim3(256), 0, stream, p);
+  const bool x3 = planeQ != 0;
+  if (head_dim == 64) {
+    if (x3) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_f16_kernel<64, 4, 0>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (x3) hipLaunchKernelGGL((attn_f16_kernel<96, 4, 1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_f16_kernel<96, 4, 0>), grid, dim3(256), 0, stream, p);
+  }
   ZH_CHECK_LAUNCH("zh_attention_f16");
   return ZH_OK;
 }
@@ -246,14 +271,15 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
 extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                                 const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                                 int batch, int heads, int Tq, int Tk, int head_dim, float scale,
-                                hipStream_t stream) {
+                                long planeQ, long planeK, long planeO, hipStream_t stream) {
   return attention_launch(Q, ldq, strideQ, K, ldk, strideK, V, ldv, strideV, O, ldo, strideO, batch, heads, Tq, Tk, head_dim,
-                          scale, 0, stream);
+                          scale, 0, planeQ, planeK, planeO, stream);
 }
 
 extern "C" int zh_attention_causal_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                                        const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
-                                       int batch, int heads, int T, int head_dim, float scale, hipStream_t stream) {
+                                       int batch, int heads, int T, int head_dim, float scale,
+                                       long planeQ, long planeK, long planeO, hipStream_t stream) {
   return attention_launch(Q, ldq, strideQ, K, ldk, strideK, V, ldv, strideV, O, ldo, strideO, batch, heads, T, T, head_dim,
-                          scale, 1, stream);
+                          scale, 1, planeQ, planeK, planeO, stream);
 }

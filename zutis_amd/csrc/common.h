@@ -50,6 +50,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// fp16 store of 4 consecutive values, optionally as a split pair for the f16x3 GEMM mode (gemm_x3.hip): hi = f16(y) at p,
+// lo = f16(y - hi) at p + lo_plane.  lo_plane == 0: hi only (the plain fp16 tensor every other consumer reads).
+__device__ __forceinline__ void zh_store_h4(half_t* p, long lo_plane, f32x4 y) {
+  const half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+  *(half4_t*)p = h;
+  if (lo_plane) {
+    const half4_t l = {(half_t)(y[0] - (float)h[0]), (half_t)(y[1] - (float)h[1]), (half_t)(y[2] - (float)h[2]),
+                       (half_t)(y[3] - (float)h[3])};
+    *(half4_t*)(p + lo_plane) = l;
+  }
+}
+__device__ __forceinline__ void zh_store_h1(half_t* p, long lo_plane, float y) {
+  const half_t h = (half_t)y;
+  *p = h;
+  if (lo_plane) p[lo_plane] = (half_t)(y - (float)h);
+}
+
 // activation codes shared by the GEMM epilogue (include/zutis_hip.h ZH_ACT_*)
 #define ZH_ACT_NONE 0
 #define ZH_ACT_QUICKGELU 1   // x * sigmoid(1.702 x)      networks/clip_arch.py:295-297

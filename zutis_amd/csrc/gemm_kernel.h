@@ -1,0 +1,488 @@
+// fp16-input / fp32-accumulate MFMA GEMM with fused epilogues (gfx950).
+//
+//   C[b][m][n] = act( sum_k A[b][m][k] * W[b][n][k] + bias[n] ) + R[b][m % res_rows][n]
+//
+// Both operands are K-contiguous ("NT" form = torch Linear layout, networks/clip_arch.py:304-310),
+// so one kernel family serves every contraction on the hot path: patch-embed conv-as-GEMM
+// (clip_arch.py:378), QKV/out-proj/MLP (clip_arch.py:314-320), ffn1/ffn2 (zutis.py:546-549),
+// decoder projections/FFN (transformer.py:272-290), the mask einsum (zutis.py:196-198, batched, sigmoid
+// epilogue), the text-space projection (zutis.py:319) and the class-logit einsum (zutis.py:361-365).
+//
+// Design (MI355X):
+//  * v_mfma_f32_16x16x32_f16; operand roles swapped (MFMA-A = W rows, MFMA-B = A rows) so a lane's 4
+//    accumulator registers are 4 consecutive n of one output row -> 16-byte row-major stores and float4
+//    bias/residual loads.
+//  * Block tiles 256x256 / 256x192 (8 waves, 2x4) for the big GEMMs, 128x128 (4 waves) for small ones; the
+//    first profile showed the 128x128x64 double-buffered version was load-LATENCY bound (K-step time == loaded
+//    L2 latency ~1.2 us), so the K loop is now a 4-stage ring of BK=32 slices: HBM/L2 -> LDS by
+//    global_load_lds_dwordx4 issued THREE slices ahead, retired by a counted s_waitcnt vmcnt(N) + one raw
+//    s_barrier per slice (never vmcnt(0) in the steady state).  Per-lane source pointers are advanced by a
+//    constant, so a slice costs 4 DMA issues + 4 pointer adds per wave.
+//  * LDS image is lane-linear (64-byte rows, 16 rows per 1-KiB DMA piece); ds_read_b128 bank conflicts are
+//    removed by XOR-ing the 16-byte chunk index with (-(row>>2))&3 on the DMA *source* address and on the read
+//    address (conflict-free for the 16x16x32 operand lane groups).
+//  * SPLIT = 1 ("f16x3", the reference-equivalent mode): both operands arrive as a pair of fp16 planes hi = f16(x),
+//    lo = f16(x - hi) (22 significand bits), a K slice stages four row sets (A hi, A lo, W hi, W lo) and every
+//    accumulator gets three MFMAs, hi*hi + lo_w*hi_a + hi_w*lo_a, in fp32 (the dropped lo*lo term is 2^-22 relative).
+//    1.5x the MFMA work per staged byte of the plain kernel; 3-slot ring with prefetch distance 3.
+//  * Block ids: XCD-aware bijective remap, then 8-row super-tiles so one XCD's concurrent tiles share panels in
+//    its 4 MiB L2 (measured L2 hit rate 82 %).
+#pragma once
+#include "common.h"
+#include <stdlib.h>
+
+#define BK 32
+#define GROUP_M 8
+
+struct GemmArgs {
+  const half_t* A; long lda, sA;
+  const half_t* W; long ldw, sW;
+  void* C; long ldc, sC;
+  long planeA, planeW, planeC;   // SPLIT: element offset hi plane -> lo plane of A / W / (OUT == 2) C
+  float out_scale;               // SPLIT: accumulators are multiplied by this before the bias (weights packed as W * 2^s)
+  const float* bias;
+  const float* R; long ldr, sR; int res_rows;
+  int M, N, K, act, nbm, nbn, vec_ok, group_m;
+#ifdef ZH_GEMM_PROBE
+  long long* probe;   // developer build (tools/gemm_probe.py): 4 timestamps per block
+#endif
+};
+#ifdef ZH_GEMM_PROBE
+static long long* g_probe = nullptr;
+#ifdef ZH_GEMM_MAIN
+extern "C" void zh_gemm_set_probe(long long* p) { g_probe = p; }
+#endif
+#define ZH_PROBE(i) do { if (p.probe && tid == 0) { p.probe[(long)blockIdx.x * 8 + (i)] = wall_clock64(); p.probe[(long)blockIdx.x * 8 + 4 + (i)] = clock64(); } } while (0)
+#else
+#define ZH_PROBE(i)
+#endif
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// runtime count of whole stages (0 .. MAXC) that may stay in flight, NP DMA issues each
+template <int NP, int MAXC>
+__device__ __forceinline__ void wait_stages_barrier(int c) {
+  static_assert(MAXC <= 5, "extend the switch");
+  switch (c) {
+    case 0: wait_vmcnt_barrier<0>(); break;
+    case 1: wait_vmcnt_barrier<NP>(); break;
+    case 2: if (MAXC >= 2) { wait_vmcnt_barrier<(MAXC >= 2 ? 2 : 0) * NP>(); break; }
+    case 3: if (MAXC >= 3) { wait_vmcnt_barrier<(MAXC >= 3 ? 3 : 0) * NP>(); break; }
+    case 4: if (MAXC >= 4) { wait_vmcnt_barrier<(MAXC >= 4 ? 4 : 0) * NP>(); break; }
+    default: wait_vmcnt_barrier<MAXC * NP>(); break;
+  }
+}
+
+// WM x WN waves; each wave owns TM x TN subtiles of 16x16.  Block tile = (WM*TM*16) x (WN*TN*16).
+// STAGES = depth of the LDS ring: 4 for the big tiles; 8 for the small-tile variants used when a GEMM has fewer tiles than
+// the chip has CUs — those are bound by bytes in flight per CU (3 x 16 KiB per 128x128 block = 24 GB/s per CU at ~2 us of
+// loaded latency), so the ring, not the tile, is what has to grow.
+// OUT: 0 = f32, 1 = f16, 2 = split pair (hi plane at C, lo plane at C + planeC).  SPLIT: operands are split pairs.
+template <int WM, int WN, int TM, int TN, int STAGES, int OUT, int ACT, int VEC, int SPLIT>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM * TN) >= 96 ? 2 : 1)) void gemm_f16_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int NPL = SPLIT ? 2 : 1;        // operand planes
+  constexpr int OUT_F16 = OUT == 1;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int ROWS = NPL * (BM + BN);     // LDS rows per stage (A planes then W planes), 64 B each
+  constexpr int PIECES = ROWS / 16;         // 1-KiB DMA pieces per stage
+  constexpr int NP = (PIECES + NW - 1) / NW;  // DMA issues per wave per stage (duplicates pad uneven splits)
+  static_assert(NP >= 2 && NP <= 8 && STAGES >= 3 && STAGES <= 8, "unsupported pieces-per-wave count / ring depth");
+  // Prefetch distance: slice kt+STAGES-1 goes into the slot whose fragments were consumed before the current barrier.
+  constexpr int DIST = STAGES - 1;
+  constexpr int AHEAD = SPLIT ? 1 : DIST - 2; // whole stages that may still be in flight at a steady-state barrier
+  static_assert(AHEAD >= 1 && AHEAD * NP < 64, "ring too shallow / vmcnt overflow");
+  constexpr int STAGE_HALVES = ROWS * BK;
+  __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE_HALVES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform values live in SGPRs
+  const int wr = wave / WN, wc = wave % WN;
+  ZH_PROBE(0);
+
+  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous id range
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles = p.nbm * p.nbn;
+  const int batch = wg / tiles;
+  const int trem = wg - batch * tiles;
+  // super-tile order: GROUP_M consecutive ids walk GROUP_M m-tiles of one n-tile
+  const int gsz = p.group_m * p.nbn;
+  const int gid = trem / gsz;
+  const int gfirst = gid * p.group_m;
+  const int grows = min(p.nbm - gfirst, p.group_m);
+  const int gl = trem - gid * gsz;
+  const int tm = gfirst + gl % grows, tn = gl / grows;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const half_t* A = p.A + (long)batch * p.sA;
+  const half_t* W = p.W + (long)batch * p.sW;
+
+  // DMA sources: piece pc covers LDS rows [16*pc, 16*pc+16); lane -> row (lane>>2), phys chunk lane&3.
+  // LDS row order: A hi [BM] (A lo [BM]) W hi [BN] (W lo [BN]).  A piece never straddles two row sets, so its source is a
+  // wave-uniform base (SGPR pair, advanced by BK per slice) + a per-lane 32-bit element offset that never changes.
+  const half_t* gbase[NP];
+  unsigned goff[NP];
+  int lds_piece[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    int pc = wave + i * NW;
+    pc = pc < PIECES ? pc : PIECES - 1;
+    lds_piece[i] = pc * 16 * BK;
+    const int R0 = pc * 16;                       // uniform
+    const int rl = lane >> 2;
+    const int c = (lane & 3) ^ ((-(rl >> 2)) & 3);    // (R0 + rl) >> 2 == R0/4 + (rl >> 2), R0/4 % 4 == 0
+    if (R0 < NPL * BM) {
+      const int pl = SPLIT ? (R0 >= BM) : 0;
+      int row = m0 + (R0 - pl * BM) + rl;
+      row = row < p.M ? row : p.M - 1;
+      gbase[i] = A + pl * p.planeA;
+      goff[i] = (unsigned)row * (unsigned)p.lda + c * 8;
+    } else {
+      const int Rw = R0 - NPL * BM;
+      const int pl = SPLIT ? (Rw >= BN) : 0;
+      int row = n0 + (Rw - pl * BN) + rl;
+      row = row < p.N ? row : p.N - 1;
+      gbase[i] = W + pl * p.planeW;
+      goff[i] = (unsigned)row * (unsigned)p.ldw + c * 8;
+    }
+  }
+  auto issue_stage = [&](int slot) {
+    half_t* sb = smem + slot * STAGE_HALVES;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase[i] + goff[i]), (lds_ptr_t)(sb + lds_piece[i]), 16, 0, 0);
+      gbase[i] += BK;
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;                    // even: K % 64 == 0
+  const int frow = lane & 15, fk = lane >> 4;
+  const int foff = frow * BK + ((fk ^ ((-(frow >> 2)) & 3)) * 8);   // per-lane offset inside a 16-row subtile
+  const half_t* rdA = smem + (wr * TM * 16) * BK + foff;
+  const half_t* rdW = smem + (NPL * BM + wc * TN * 16) * BK + foff;
+
+  if constexpr (SPLIT) {
+    // ---- f16x3 loop.  Fragments are single-buffered (hi + lo of both operands = 64 registers at 64x64 per wave; a second
+    // set does not fit next to the accumulators at two waves per SIMD): slice kt's fragments are read right after the
+    // barrier of iteration kt, hi planes first, and the first sweep of MFMAs (hi*hi) starts as soon as those arrive while
+    // the lo planes and the DMA issues of slice kt+DIST trickle in underneath.  A slice carries 3*TM*TN MFMAs (~770 cycles
+    // per wave), so two slices of prefetch cover ~1.5 us of load latency with a 3-slot ring.
+    constexpr int DISTX = STAGES - 1, AHEADX = STAGES - 2;
+    static_assert(AHEADX >= 1 && AHEADX * NP < 64, "ring too shallow / vmcnt overflow");
+#pragma unroll
+    for (int s = 0; s < DISTX; ++s)
+      if (s < nk) issue_stage(s);
+    half8_t fa[2 * TM], fw[2 * TN];
+    int slot = 0, wslot = DISTX % STAGES;
+    auto read_frags = [&]() {
+      const int so = slot * STAGE_HALVES;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fa[pl * TM + t] = *(const half8_t*)(rdA + so + (pl * BM + t * 16) * BK);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fw[pl * TN + t] = *(const half8_t*)(rdW + so + (pl * BN + t * 16) * BK);
+      }
+    };
+    // three sweeps over the accumulators keep dependent MFMAs TM*TN issues apart: hi*hi, lo_w*hi_a, hi_w*lo_a
+    auto sweeps = [&]() {
+#pragma unroll
+      for (int sw = 0; sw < 3; ++sw)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[(sw == 1 ? TN : 0) + nt], fa[(sw == 2 ? TM : 0) + mt], acc[nt][mt], 0, 0, 0);
+    };
+    auto advance = [&]() {
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+      wslot = wslot + 1 == STAGES ? 0 : wslot + 1;
+    };
+    int kt = 0;
+    for (; kt + DISTX < nk; ++kt) {      // steady: branch-free body so the reads / DMA issues interleave with the MFMAs
+      wait_vmcnt_barrier<AHEADX * NP>();
+      read_frags();
+      issue_stage(wslot);
+      sweeps();
+      // hi fragments first, then 2 MFMAs per lo-fragment read / DMA issue
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+      for (int i = 0; i < TM + TN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      advance();
+    }
+    for (; kt < nk; ++kt) {              // tail: slices kt .. nk-1 are in flight, slice kt must have landed
+      wait_stages_barrier<NP, AHEADX>(nk - 1 - kt);
+      read_frags();
+      sweeps();
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+      for (int i = 0; i < TM + TN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      advance();
+    }
+  } else {
+#pragma unroll
+  for (int s = 0; s < DIST; ++s)
+    if (s < nk) issue_stage(s % STAGES);
+
+  // Register double-buffered fragments: while the MFMAs of slice kt run, the ds_read_b128 of slice kt+1 are in
+  // flight (the LDS latency at the head of every slice was exposed on all 8 waves at once behind the barrier).
+  // Slice kt+1 must therefore have landed one iteration earlier: counted waits are vmcnt(AHEAD*NP) in the steady state.
+  half8_t fa0[TM], fw0[TN], fa1[TM], fw1[TN];
+  auto load_frags = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN]) {
+    const int so = (kt % STAGES) * STAGE_HALVES;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) fa[t] = *(const half8_t*)(rdA + so + t * 16 * BK);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) fw[t] = *(const half8_t*)(rdW + so + t * 16 * BK);
+  };
+  auto mfma_all = [&](half8_t (&fa)[TM], half8_t (&fw)[TN]) {
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+  };
+  // steady-state phase (kt + DIST < nk): branch-free so the scheduler can interleave — every group of MFMAs shadows one
+  // LDS fragment read or one LDS-DMA issue of the NEXT slices; the wave's stream stays MFMA-paced instead of
+  // front-loading 16 memory instructions behind the barrier.
+  auto steady = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
+#ifndef ZH_X_NOBAR
+    wait_vmcnt_barrier<AHEAD * NP>();
+#endif
+    // program order = dependence order for the compiler: an LDS-DMA is a write to `smem`, so fragment reads placed after
+    // it can never be scheduled above it.  Reads first, DMA second lets the reads spread under the first MFMAs and the DMA
+    // issues under the last ones (the other order left all 12 ds_read_b128 + their latency exposed at the end of the slice).
+#ifndef ZH_X_NOFRAG
+    load_frags(kt + 1, na, nw);
+#endif
+#ifndef ZH_X_NODMA
+    issue_stage((kt + DIST) % STAGES);
+#endif
+    mfma_all(fa, fw);
+    constexpr int NMEM = TM + TN + NP, NMFMA = TM * TN;
+    if (NMFMA >= NMEM) {
+#pragma unroll
+      for (int i = 0; i < TM + TN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NMEM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+  };
+  auto tail = [&](int kt, half8_t (&fa)[TM], half8_t (&fw)[TN], half8_t (&na)[TM], half8_t (&nw)[TN]) {
+    if (kt + 1 < nk) {
+      // slices issued so far: 0 .. min(nk-1, kt+DIST-1); slice kt+1 must have landed, the later ones may fly
+      wait_stages_barrier<NP, AHEAD>(min(nk - 1, kt + DIST - 1) - (kt + 1));
+      load_frags(kt + 1, na, nw);                                          // reads before the DMA: see steady()
+      if (kt + DIST < nk) issue_stage((kt + DIST) % STAGES);
+    }
+    mfma_all(fa, fw);   // (a sched_group_barrier interleave here makes hipcc spill: 172 scratch ops, 2.6x slower)
+  };
+  if (nk >= DIST) wait_vmcnt_barrier<(DIST - 1) * NP>();   // stage 0 landed; the other DIST-1 may still be in flight
+  else wait_vmcnt_barrier<0>();                            // short K: not worth a counted wait
+  ZH_PROBE(1);
+  load_frags(0, fa0, fw0);
+  int kt = 0;
+  for (; kt + DIST + 1 < nk; kt += 2) {
+    steady(kt, fa0, fw0, fa1, fw1);
+    steady(kt + 1, fa1, fw1, fa0, fw0);
+  }
+  for (; kt < nk; kt += 2) {
+    tail(kt, fa0, fw0, fa1, fw1);
+    tail(kt + 1, fa1, fw1, fa0, fw0);
+  }
+  }
+
+  ZH_PROBE(2);
+  // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4).  ACT / VEC are template
+  // parameters: a runtime switch unrolled 32x blew the instruction cache (fc GEMM 1.4x slower in the model).
+  const long cb = (long)batch * p.sC;
+  const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+  const float osc = SPLIT ? p.out_scale : 1.0f;
+  if (VEC == 2) {
+    // LDS-staged epilogue: the direct form stores 32-byte runs (4 lanes x 8 B) into 16 different 128-B lines per
+    // instruction and measured 2.4 TB/s, fully exposed (34 % of a K=768 tile).  Here each wave transposes its tile through
+    // a private, conflict-free LDS slab (row stride +16 B) and writes whole rows with 16 B per lane (split pairs: the
+    // slab holds fp32 and each lane writes 8 B to the hi plane and 8 B to the lo plane).
+    constexpr int ESZ = OUT_F16 ? 2 : 4;
+    constexpr int RS = TN * 16 * ESZ + 16;                  // slab row stride (bytes)
+    constexpr int PR = (OUT_F16 ? 64 : 32) < TM * 16 ? (OUT_F16 ? 64 : 32) : TM * 16;   // rows per pass
+    constexpr int MTP = PR / 16;
+    constexpr int CPRW = TN * 16 * ESZ / 16;                // 16-B chunks per row
+    constexpr int NIT = PR * CPRW / 64;
+    static_assert((PR * CPRW) % 64 == 0, "epilogue slab must divide into full wave reads");
+    static_assert(NW * PR * RS <= (int)sizeof(smem), "epilogue slabs exceed the ring");
+    __syncthreads();                                        // ring no longer read; every LDS-DMA has landed
+    char* slab = (char*)smem + wave * (PR * RS);
+#pragma clang loop unroll(full)
+    for (int pass = 0; pass < TM / MTP; ++pass) {
+#pragma clang loop unroll(full)
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+#pragma clang loop unroll(full)
+        for (int ml = 0; ml < MTP; ++ml) {
+          f32x4 v = SPLIT ? acc[nt][pass * MTP + ml] * osc + bv : acc[nt][pass * MTP + ml] + bv;
+          if (ACT != ZH_ACT_NONE) {
+            v[0] = zh_act(v[0], ACT); v[1] = zh_act(v[1], ACT); v[2] = zh_act(v[2], ACT); v[3] = zh_act(v[3], ACT);
+          }
+          char* dst = slab + (ml * 16 + frow) * RS + (nt * 16 + fk * 4) * ESZ;
+          if (OUT_F16) {
+            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *(half4_t*)dst = h;
+          } else {
+            *(f32x4*)dst = v;
+          }
+        }
+      }
+#pragma clang loop unroll(full)
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 64 + lane;
+        const int row = c / CPRW, ch = c - row * CPRW;
+        const int m = m0 + wr * TM * 16 + pass * PR + row;
+        const int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
+        f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
+        if (m < p.M && n < p.N) {
+          if (OUT == 0 && R) d += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
+          if (OUT == 1) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
+          else if (OUT == 0) *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
+          else {
+            half4_t hi = {(half_t)d[0], (half_t)d[1], (half_t)d[2], (half_t)d[3]};
+            half4_t lo = {(half_t)(d[0] - (float)hi[0]), (half_t)(d[1] - (float)hi[1]), (half_t)(d[2] - (float)hi[2]),
+                          (half_t)(d[3] - (float)hi[3])};
+            half_t* ch_ = (half_t*)p.C + cb + (long)m * p.ldc + n;
+            *(half4_t*)ch_ = hi;
+            *(half4_t*)(ch_ + p.planeC) = lo;
+          }
+        }
+      }
+    }
+  } else if (VEC) {
+#pragma clang loop unroll(full)
+    for (int nt = 0; nt < TN; ++nt) {
+      const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+      const bool nok = n < p.N;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && nok) bv = *(const f32x4*)(p.bias + n);
+#pragma clang loop unroll(full)
+      for (int mt = 0; mt < TM; ++mt) {
+        const int m = m0 + (wr * TM + mt) * 16 + frow;
+        if (nok && m < p.M) {
+          f32x4 v = acc[nt][mt] * osc + bv;
+          if (ACT != ZH_ACT_NONE) {
+            v[0] = zh_act(v[0], ACT); v[1] = zh_act(v[1], ACT); v[2] = zh_act(v[2], ACT); v[3] = zh_act(v[3], ACT);
+          }
+          if (R) v += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
+          if (OUT == 1) {
+            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *(half4_t*)((half_t*)p.C + cb + (long)m * p.ldc + n) = h;
+          } else if (OUT == 0) {
+            *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = v;
+          } else {
+            half4_t hi = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            half4_t lo = {(half_t)(v[0] - (float)hi[0]), (half_t)(v[1] - (float)hi[1]), (half_t)(v[2] - (float)hi[2]),
+                          (half_t)(v[3] - (float)hi[3])};
+            half_t* ch_ = (half_t*)p.C + cb + (long)m * p.ldc + n;
+            *(half4_t*)ch_ = hi;
+            *(half4_t*)(ch_ + p.planeC) = lo;
+          }
+        }
+      }
+    }
+  } else {   // unaligned / odd-N fallback: scalar stores (rare: odd pixel counts)
+#pragma clang loop unroll(full)
+    for (int mt = 0; mt < TM; ++mt) {
+      const int m = m0 + (wr * TM + mt) * 16 + frow;
+      const long rrow = R ? (long)(m % p.res_rows) * p.ldr : 0;
+#pragma clang loop unroll(full)
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+#pragma clang loop unroll(full)
+        for (int e = 0; e < 4; ++e) {
+          if (m < p.M && n + e < p.N) {
+            float x = acc[nt][mt][e] * osc;
+            if (p.bias) x += p.bias[n + e];
+            x = zh_act(x, ACT);
+            if (R) x += R[rrow + n + e];
+            const long ci = cb + (long)m * p.ldc + n + e;
+            if (OUT == 1) ((half_t*)p.C)[ci] = (half_t)x;
+            else if (OUT == 0) ((float*)p.C)[ci] = x;
+            else {
+              const half_t hi = (half_t)x;
+              ((half_t*)p.C)[ci] = hi;
+              ((half_t*)p.C)[ci + p.planeC] = (half_t)(x - (float)hi);
+            }
+          }
+        }
+      }
+    }
+  }
+#ifdef ZH_GEMM_PROBE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ZH_PROBE(3);
+#endif
+}
+
+
+
+template <int WM, int WN, int TM, int TN, int STAGES, int OUT, int ACT, int VEC, int SPLIT>
+static void launch_one(GemmArgs p, int batch, hipStream_t stream) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  p.nbm = zh_cdiv(p.M, BM);
+  p.nbn = zh_cdiv(p.N, BN);
+  const unsigned nblk = (unsigned)((long)p.nbm * p.nbn * batch);
+  hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, STAGES, OUT, ACT, VEC, SPLIT>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
+}
+
+// Relative time estimate of a tiling: rounds of the 256-CU chip x time of one round.  With `bpc` blocks resident
+// per CU a round takes bpc x the tile's own time; `eff` is the measured relative speed of the tile shape at
+// K=768 (256x256: 1.0, 256x192: 0.95, 128x128: 0.8 — tools/gemm_bench.py on MI355X).
+static inline double tiling_cost(long M, long N, int batch, int BM, int BN, int bpc, double eff) {
+  const long tiles = (long)zh_cdiv(M, BM) * zh_cdiv(N, BN) * batch;
+  const long slots = 256L * bpc;
+  const long rounds = (tiles + slots - 1) / slots;
+  return (double)rounds * BM * BN * bpc / eff;
+}
+
+// Developer overrides, read ONCE per process (never per launch): ZH_GEMM_GROUP_M = super-tile height,
+// ZH_GEMM_TILE = forced tile code (validated by the caller; unknown codes are an argument error).
+struct GemmDevOverrides { int group_m; int tile; };
+static inline const GemmDevOverrides& gemm_dev_overrides() {
+  static const GemmDevOverrides o = [] {
+    GemmDevOverrides v{GROUP_M, 0};
+    if (const char* g = getenv("ZH_GEMM_GROUP_M")) { const int x = atoi(g); if (x >= 1) v.group_m = x; }
+    if (const char* t = getenv("ZH_GEMM_TILE")) v.tile = atoi(t);
+    return v;
+  }();
+  return o;
+}

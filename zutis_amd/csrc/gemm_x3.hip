@@ -1,0 +1,80 @@
+// zh_gemm_f16x3: the reference-equivalent GEMM mode.  The reference computes every contraction in fp32
+// (networks/clip_arch.py:286-292 keeps LayerNorm in fp32, networks/zutis.py:55 casts the CLIP weights back to fp32);
+// gfx950 has no fast fp32 matrix path (v_mfma_f32_*_f32: 157 TFLOP/s dense against 2.5 PFLOP/s for fp16), so fp32-class
+// products are built from fp16 MFMAs: each operand x is carried as the pair hi = f16(x), lo = f16(x - hi) — 22
+// significand bits — and  A.W = Ah.Wh + Ah.Wl + Al.Wh  accumulates in fp32 (dropped Al.Wl term: 2^-22 relative).
+// Weights are packed as W * 2^s (s chosen per matrix so that lo stays a normal fp16 number); `out_scale` = 2^-s is applied
+// to the accumulator before the bias.  Kernel: gemm_kernel.h with SPLIT = 1.
+#include "gemm_kernel.h"
+
+template <int WM, int WN, int TM, int TN, int STAGES, int VEC>
+static bool launch_x3(const GemmArgs& p, int batch, int out_kind, hipStream_t stream) {
+  const int key = out_kind * 8 + p.act;
+  switch (key) {
+    case 0 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 0, ZH_ACT_NONE, VEC, 1>(p, batch, stream); return true;
+    case 0 + ZH_ACT_SIGMOID: launch_one<WM, WN, TM, TN, STAGES, 0, ZH_ACT_SIGMOID, VEC, 1>(p, batch, stream); return true;
+    case 8 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_NONE, VEC, 1>(p, batch, stream); return true;
+    case 16 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_NONE, VEC, 1>(p, batch, stream); return true;
+    default: break;
+  }
+  if (VEC == 2) {   // activations feeding another GEMM only occur on 16-byte aligned rows
+    switch (key) {
+      case 8 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_QUICKGELU, 2, 1>(p, batch, stream); return true;
+      case 8 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_RELU, 2, 1>(p, batch, stream); return true;
+      case 8 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_GELU_ERF, 2, 1>(p, batch, stream); return true;
+      case 16 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_QUICKGELU, 2, 1>(p, batch, stream); return true;
+      case 16 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_RELU, 2, 1>(p, batch, stream); return true;
+      case 16 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_GELU_ERF, 2, 1>(p, batch, stream); return true;
+      default: break;
+    }
+  }
+  return false;
+}
+
+extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void* W, long ldw, long strideW, long planeW,
+                             void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
+                             const float* bias, const float* residual, long ldr, long strideR, int res_rows,
+                             int act, int M, int N, int K, int batch, hipStream_t stream) {
+  ZH_CHECK_ARG(A && W && C, "zh_gemm_f16x3: null operand");
+  ZH_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "zh_gemm_f16x3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  ZH_CHECK_ARG(K % 64 == 0, "zh_gemm_f16x3: K=%d must be a multiple of 64", K);
+  ZH_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && strideA % 8 == 0 && strideW % 8 == 0 && planeA % 8 == 0 && planeW % 8 == 0,
+               "zh_gemm_f16x3: lda/ldw/strides/planes must be multiples of 8 halves (16-byte rows)");
+  ZH_CHECK_ARG(planeA != 0 && planeW != 0, "zh_gemm_f16x3: operands must be split pairs (plane offset of the lo half)");
+  ZH_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "zh_gemm_f16x3: A/W must be 16-byte aligned");
+  ZH_CHECK_ARG(act >= 0 && act <= 4, "zh_gemm_f16x3: bad activation %d", act);
+  ZH_CHECK_ARG(out_kind >= 0 && out_kind <= 2, "zh_gemm_f16x3: out_kind %d not in {0 f32, 1 f16, 2 split pair}", out_kind);
+  ZH_CHECK_ARG(out_kind != 2 || (planeC != 0 && planeC % 4 == 0), "zh_gemm_f16x3: split output needs planeC (multiple of 4)");
+  ZH_CHECK_ARG(!residual || (res_rows > 0 && out_kind == 0), "zh_gemm_f16x3: residual needs res_rows > 0 and an f32 output");
+  ZH_CHECK_ARG(out_scale > 0.0f, "zh_gemm_f16x3: out_scale must be positive");
+  GemmArgs p;
+  p.A = (const half_t*)A; p.lda = lda; p.sA = strideA; p.planeA = planeA;
+  p.W = (const half_t*)W; p.ldw = ldw; p.sW = strideW; p.planeW = planeW;
+  p.C = C; p.ldc = ldc; p.sC = strideC; p.planeC = planeC; p.out_scale = out_scale;
+  p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
+  p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
+  p.group_m = gemm_dev_overrides().group_m;
+#ifdef ZH_GEMM_PROBE
+  p.probe = g_probe;
+#endif
+  const int esz = out_kind == 0 ? 4 : 2;
+  p.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && (strideC % 4 == 0) && (((uintptr_t)C & (4 * esz - 1)) == 0) &&
+             (!bias || ((uintptr_t)bias & 15) == 0) &&
+             (!residual || (ldr % 4 == 0 && strideR % 4 == 0 && ((uintptr_t)residual & 15) == 0));
+  ZH_CHECK_ARG((long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch < (1L << 31), "zh_gemm_f16x3: grid too large");
+  // the LDS-staged epilogue reads the slab in 16-byte chunks: f32 / split rows need N % 4 == 0 (vec_ok), f16 rows N % 8 == 0
+  const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&
+                       (out_kind == 1 ? (N % 8 == 0) : true) && (out_kind != 2 || (ldc % 8 == 0 && planeC % 8 == 0 && N % 8 == 0));
+  // 256 x 128 (8 waves, 144 KiB ring, one block per CU) when it fills the chip at least ~1.5 times, else 128 x 64 (4 waves, two per CU)
+  const long big_tiles = (long)zh_cdiv(M, 256) * zh_cdiv(N, 128) * batch;
+  const int forced = gemm_dev_overrides().tile;
+  const bool big = forced ? (forced == 256) : big_tiles >= 384;
+  bool ok;
+  if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
+  else if (!wide_ok) ok = launch_x3<2, 2, 4, 2, 3, 1>(p, batch, out_kind, stream);
+  else if (big) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
+  else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
+  ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
+  ZH_CHECK_LAUNCH("zh_gemm_f16x3");
+  return ZH_OK;
+}

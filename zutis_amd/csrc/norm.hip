@@ -36,6 +36,7 @@ struct LnArgs {
   half_t* out_f16_plus; const float* add; int add_rows;             // out_f16_plus = fp16(y + add[r % add_rows])
   float* out_f32_plus;                                              // optional fp32 copy of y + add
   int rows, D; float eps;
+  long lo_plane;                                                    // != 0: fp16 outputs are split pairs (lo half at + lo_plane)
 };
 
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
@@ -59,16 +60,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
       f32x4 y = row.v[j];
       if (p.gamma) y = y * ((const f32x4*)p.gamma)[c] + ((const f32x4*)p.beta)[c];
       if (p.out_f32) ((f32x4*)(p.out_f32 + ob))[c] = y;
-      if (p.out_f16) {
-        half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
-        ((half4_t*)(p.out_f16 + ob))[c] = h;
-      }
+      if (p.out_f16) zh_store_h4(p.out_f16 + ob + 4 * c, p.lo_plane, y);
       if (p.add) {
         f32x4 z = y + ((const f32x4*)(p.add + ab))[c];
-        if (p.out_f16_plus) {
-          half4_t h = {(half_t)z[0], (half_t)z[1], (half_t)z[2], (half_t)z[3]};
-          ((half4_t*)(p.out_f16_plus + ob))[c] = h;
-        }
+        if (p.out_f16_plus) zh_store_h4(p.out_f16_plus + ob + 4 * c, p.lo_plane, z);
         if (p.out_f32_plus) ((f32x4*)(p.out_f32_plus + ob))[c] = z;
       }
     }
@@ -79,14 +74,15 @@ extern "C" int zh_layernorm_f32(const float* x, long in_group_rows, long in_grou
                                 long out_group_rows, long out_group_stride, long out_offset,
                                 const float* gamma, const float* beta, float eps,
                                 float* out_f32, void* out_f16, void* out_f16_plus, float* out_f32_plus,
-                                const float* add, int add_rows, int rows, int D, hipStream_t stream) {
+                                const float* add, int add_rows, int rows, int D, long lo_plane, hipStream_t stream) {
   ZH_CHECK_ARG(x && rows > 0, "zh_layernorm_f32: bad input");
+  ZH_CHECK_ARG(lo_plane % 4 == 0, "zh_layernorm_f32: lo_plane must be a multiple of 4 halves");
   ZH_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV && D > 0, "zh_layernorm_f32: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXV);
   ZH_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "zh_layernorm_f32: gamma and beta must both be given or both null");
   ZH_CHECK_ARG(in_group_rows > 0 && out_group_rows > 0, "zh_layernorm_f32: group_rows must be > 0");
   ZH_CHECK_ARG(!(out_f16_plus || out_f32_plus) || (add && add_rows > 0), "zh_layernorm_f32: *_plus outputs need add/add_rows");
   LnArgs p{x, in_group_rows, in_group_stride, in_offset, out_group_rows, out_group_stride, out_offset, gamma, beta, out_f32, (half_t*)out_f16,
-           (half_t*)out_f16_plus, add, add_rows, out_f32_plus, rows, D, eps};
+           (half_t*)out_f16_plus, add, add_rows, out_f32_plus, rows, D, eps, lo_plane};
   hipLaunchKernelGGL(layernorm_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, p);
   ZH_CHECK_LAUNCH("zh_layernorm_f32");
   return ZH_OK;
@@ -132,7 +128,8 @@ extern "C" int zh_assemble_tokens_ln(const float* patch_emb, const float* class_
 }
 
 // ---- row L2 normalise: queries / ||queries||  (networks/zutis.py:515, no eps) -> fp16 and/or fp32
-__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float* out_f32, half_t* out_f16, int rows, int D, float eps) {
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float* out_f32, half_t* out_f16, int rows, int D, float eps,
+                                                          long lo_plane) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -153,18 +150,17 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float*
     if (c < nv) {
       f32x4 y = v[j] * inv;
       if (out_f32) ((f32x4*)(out_f32 + r * D))[c] = y;
-      if (out_f16) {
-        half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
-        ((half4_t*)(out_f16 + r * D))[c] = h;
-      }
+      if (out_f16) zh_store_h4(out_f16 + r * D + 4 * c, lo_plane, y);
     }
   }
 }
 
-extern "C" int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, hipStream_t stream) {
-  ZH_CHECK_ARG(x && (out_f32 || out_f16) && rows > 0, "zh_l2norm_rows: bad arguments");
+extern "C" int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, long lo_plane,
+                              hipStream_t stream) {
+  ZH_CHECK_ARG(x && (out_f32 || out_f16) && rows > 0 && lo_plane % 4 == 0, "zh_l2norm_rows: bad arguments");
   ZH_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV && D > 0, "zh_l2norm_rows: D=%d unsupported", D);
-  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, x, out_f32, (half_t*)out_f16, rows, D, eps);
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, x, out_f32, (half_t*)out_f16, rows, D, eps,
+                     lo_plane);
   ZH_CHECK_LAUNCH("zh_l2norm_rows");
   return ZH_OK;
 }
@@ -218,7 +214,8 @@ __global__ __launch_bounds__(256) void gln_partial_kernel(const float* x, float*
 }
 
 __global__ __launch_bounds__(256) void gln_apply_kernel(const float* x, const float* part, float* out_f32, half_t* out_f16,
-                                                        long per_image, int nchunks, int M, int C, float eps, float l2_eps) {
+                                                        long per_image, int nchunks, int M, int C, float eps, float l2_eps,
+                                                        long lo_plane) {
   const int img = blockIdx.y;
   const int lane = threadIdx.x & 63;
   // combine partials (every wave redundantly; nchunks is a few hundred)
@@ -258,10 +255,7 @@ __global__ __launch_bounds__(256) void gln_apply_kernel(const float* x, const fl
     if (c < nv) {
       f32x4 y = v[j] * inv;
       if (out_f32) ((f32x4*)(out_f32 + ob))[c] = y;
-      if (out_f16) {
-        half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
-        ((half4_t*)(out_f16 + ob))[c] = h;
-      }
+      if (out_f16) zh_store_h4(out_f16 + ob + 4 * c, lo_plane, y);
     }
   }
 }
@@ -272,8 +266,8 @@ extern "C" size_t zh_global_ln_l2_workspace_size(int B, int M, int C) {
 }
 
 extern "C" int zh_global_ln_l2(const float* x, float* out_f32, void* out_f16, float eps, float l2_eps,
-                               int B, int M, int C, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && M > 0, "zh_global_ln_l2: bad arguments");
+                               int B, int M, int C, void* workspace, size_t workspace_bytes, long lo_plane, hipStream_t stream) {
+  ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && M > 0 && lo_plane % 4 == 0, "zh_global_ln_l2: bad arguments");
   ZH_CHECK_ARG(C % 4 == 0 && C <= 256 * LN_MAXV && C > 0, "zh_global_ln_l2: C=%d unsupported", C);
   ZH_CHECK_ARG(B < 65536, "zh_global_ln_l2: batch too large");
   const long per_image = (long)M * C;
@@ -284,7 +278,7 @@ extern "C" int zh_global_ln_l2(const float* x, float* out_f32, void* out_f16, fl
   }
   hipLaunchKernelGGL(gln_partial_kernel, dim3(nchunks, B), dim3(256), 0, stream, x, (float*)workspace, per_image, nchunks);
   hipLaunchKernelGGL(gln_apply_kernel, dim3(zh_cdiv(M, 4), B), dim3(256), 0, stream, x, (const float*)workspace, out_f32,
-                     (half_t*)out_f16, per_image, nchunks, M, C, eps, l2_eps);
+                     (half_t*)out_f16, per_image, nchunks, M, C, eps, l2_eps, lo_plane);
   ZH_CHECK_LAUNCH("zh_global_ln_l2");
   return ZH_OK;
 }

@@ -9,7 +9,7 @@
 // ---- im2col for the stride==kernel patch-embed conv (networks/clip_arch.py:340,378): pure re-index.
 //      out[(b,py,px)][c*p*p + i*p + j] = x[b,c,py*p+i,px*p+j], zero padded to Kpad columns, fp16.
 __global__ __launch_bounds__(128) void im2col_kernel(const float* x, half_t* out, int B, int Cin, int H, int W, int p,
-                                                     int gh, int gw, int Kpad, int vec) {
+                                                     int gh, int gw, int Kpad, int vec, long lo_plane) {
   // one workgroup per patch (= GEMM row): the (b, py, px) split is block-uniform; a thread converts 8 consecutive k =
   // 8 consecutive pixels of one patch row (two 16-byte loads, one 16-byte store) when p % 8 == 0 and rows are 16-B aligned
   const int row = blockIdx.x;
@@ -26,8 +26,8 @@ __global__ __launch_bounds__(128) void im2col_kernel(const float* x, half_t* out
       if (yy < H && xx + 8 <= W) {
         const f32x4* src = (const f32x4*)(x + (((long)b * Cin + c) * H + yy) * W + xx);
         const f32x4 v0 = src[0], v1 = src[1];
-        o = (half8_t){(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3], (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
-        *(half8_t*)(orow + k0) = o;
+        zh_store_h4(orow + k0, lo_plane, v0);
+        zh_store_h4(orow + k0 + 4, lo_plane, v1);
         continue;
       }
     }
@@ -41,13 +41,15 @@ __global__ __launch_bounds__(128) void im2col_kernel(const float* x, half_t* out
         if (yy < H && xx < W) v = x[(((long)b * Cin + c) * H + yy) * W + xx];   // selfmask/vision_transformer.py:260-267)
       }
       o[e] = (half_t)v;
+      if (lo_plane) orow[lo_plane + k] = (half_t)(v - (float)o[e]);
     }
     *(half8_t*)(orow + k0) = o;
   }
 }
 
 extern "C" int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int patch, int Kpad, int pad_to_patch,
-                             hipStream_t stream) {
+                             long lo_plane, hipStream_t stream) {
+  ZH_CHECK_ARG(lo_plane % 8 == 0, "zh_im2col_f16: lo_plane must be a multiple of 8 halves");
   ZH_CHECK_ARG(x && out && B > 0 && Cin > 0 && patch > 0 && H > 0 && W > 0, "zh_im2col_f16: bad arguments");
   ZH_CHECK_ARG(pad_to_patch || (H >= patch && W >= patch), "zh_im2col_f16: image smaller than one patch");
   ZH_CHECK_ARG(Kpad >= Cin * patch * patch, "zh_im2col_f16: Kpad too small");
@@ -57,7 +59,8 @@ extern "C" int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, i
   const long rows = (long)B * gh * gw;
   ZH_CHECK_ARG(rows < (1L << 31), "zh_im2col_f16: too many patches");
   const int vec = (patch % 8 == 0) && (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
-  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)rows), dim3(128), 0, stream, x, (half_t*)out, B, Cin, H, W, patch, gh, gw, Kpad, vec);
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)rows), dim3(128), 0, stream, x, (half_t*)out, B, Cin, H, W, patch, gh, gw, Kpad, vec,
+                     lo_plane);
   ZH_CHECK_LAUNCH("zh_im2col_f16");
   return ZH_OK;
 }
@@ -118,7 +121,8 @@ extern "C" int zh_posembed_bicubic(const float* pos, float* out, int grid, int h
 
 // ---- x2 bilinear upsample, channels-last tokens (networks/zutis.py:491-495): [B,h,w,D] fp32 -> [B,2h,2w,D]
 //      fp16 and/or fp32.  src = max(0.5*(dst+0.5)-0.5, 0); weights {0.25,0.75} (edges clamp).
-__global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* x, float* out_f32, half_t* out_f16, int B, int h, int w, int D) {
+__global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* x, float* out_f32, half_t* out_f16, int B, int h, int w, int D,
+                                                          long lo_plane) {
   // One workgroup per 2x2 output quad {2j+1,2j+2} x {2k+1,2k+2}, j in [-1,h-1], k in [-1,w-1]: the four outputs interpolate the
   // same four inputs (rows j,j+1 x cols k,k+1, clamped), so every input float4 is loaded once per quad instead of once per
   // output (the per-output form re-read 4x the tensor through L2 and ran at 2 TB/s).  Each output still evaluates ATen's own
@@ -169,21 +173,21 @@ __global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* x, floa
         }
         const long oi = (orow[sy] + ocol[sx]) * nv + c;
         if (out_f32) ((f32x4*)out_f32)[oi] = o;
-        if (out_f16) {
-          half4_t hh = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-          ((half4_t*)out_f16)[oi] = hh;
-        }
+        if (out_f16) zh_store_h4(out_f16 + 4 * oi, lo_plane, o);
       }
   }
 }
 
-extern "C" int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, hipStream_t stream) {
-  ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && h > 0 && w > 0 && D > 0 && D % 4 == 0, "zh_upsample2x_bilinear_cl: bad arguments");
+extern "C" int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, long lo_plane,
+                                         hipStream_t stream) {
+  ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && h > 0 && w > 0 && D > 0 && D % 4 == 0 && lo_plane % 4 == 0,
+               "zh_upsample2x_bilinear_cl: bad arguments");
   const long quads = (long)B * (h + 1) * (w + 1);          // one workgroup per 2x2 output quad
   ZH_CHECK_ARG(quads < (1L << 31), "zh_upsample2x_bilinear_cl: too many output quads");
   const int nv = D / 4;
   const int threads = nv >= 256 ? 256 : ((nv + 63) / 64) * 64;
-  hipLaunchKernelGGL(upsample2x_cl_kernel, dim3((unsigned)quads), dim3(threads), 0, stream, x, out_f32, (half_t*)out_f16, B, h, w, D);
+  hipLaunchKernelGGL(upsample2x_cl_kernel, dim3((unsigned)quads), dim3(threads), 0, stream, x, out_f32, (half_t*)out_f16, B, h, w, D,
+                     lo_plane);
   ZH_CHECK_LAUNCH("zh_upsample2x_bilinear_cl");
   return ZH_OK;
 }
@@ -214,7 +218,9 @@ extern "C" int zh_sine_pe(float* out, int h, int w, int D, float temperature, hi
 }
 
 // ---- out_f16[r][:] = fp16(a_f16[r][:] + add_f32[r % add_rows][:])   (memory + pos, networks/transformer.py:281)
-__global__ __launch_bounds__(256) void add_rowperiodic_kernel(const half_t* a, const float* add, half_t* out, long rows, int D, int add_rows) {
+// Split pairs (a_lo_plane / lo_plane != 0): the sum is formed from hi + lo in fp32 and re-split.
+__global__ __launch_bounds__(256) void add_rowperiodic_kernel(const half_t* a, const float* add, half_t* out, long rows, int D, int add_rows,
+                                                              long a_lo_plane, long lo_plane) {
   const int nv = D >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= rows * nv) return;
@@ -222,19 +228,27 @@ __global__ __launch_bounds__(256) void add_rowperiodic_kernel(const half_t* a, c
   const int c = (int)(idx - r * nv);
   const half4_t h = ((const half4_t*)a)[idx];
   const f32x4 p = ((const f32x4*)add)[(r % add_rows) * nv + c];
-  half4_t o = {(half_t)((float)h[0] + p[0]), (half_t)((float)h[1] + p[1]), (half_t)((float)h[2] + p[2]), (half_t)((float)h[3] + p[3])};
-  ((half4_t*)out)[idx] = o;
+  f32x4 v = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  if (a_lo_plane) {
+    const half4_t l = *(const half4_t*)(a + a_lo_plane + 4 * idx);
+    v += (f32x4){(float)l[0], (float)l[1], (float)l[2], (float)l[3]};
+  }
+  zh_store_h4(out + 4 * idx, lo_plane, v + p);
 }
 
-extern "C" int zh_add_rowperiodic_f16(const void* a, const float* add, void* out, long rows, int D, int add_rows, hipStream_t stream) {
-  ZH_CHECK_ARG(a && add && out && rows > 0 && D > 0 && D % 4 == 0 && add_rows > 0, "zh_add_rowperiodic_f16: bad arguments");
-  hipLaunchKernelGGL(add_rowperiodic_kernel, dim3(zh_cdiv(rows * (D / 4), 256)), dim3(256), 0, stream, (const half_t*)a, add, (half_t*)out, rows, D, add_rows);
+extern "C" int zh_add_rowperiodic_f16(const void* a, const float* add, void* out, long rows, int D, int add_rows, long a_lo_plane,
+                                      long lo_plane, hipStream_t stream) {
+  ZH_CHECK_ARG(a && add && out && rows > 0 && D > 0 && D % 4 == 0 && add_rows > 0 && a_lo_plane % 4 == 0 && lo_plane % 4 == 0,
+               "zh_add_rowperiodic_f16: bad arguments");
+  hipLaunchKernelGGL(add_rowperiodic_kernel, dim3(zh_cdiv(rows * (D / 4), 256)), dim3(256), 0, stream, (const half_t*)a, add, (half_t*)out, rows, D, add_rows,
+                     a_lo_plane, lo_plane);
   ZH_CHECK_LAUNCH("zh_add_rowperiodic_f16");
   return ZH_OK;
 }
 
 // ---- fp32 -> fp16 cast (optionally adding a row-periodic fp32 matrix first)
-__global__ __launch_bounds__(256) void cast_kernel(const float* x, const float* add, half_t* out, long n4, int nv, int add_rows) {
+__global__ __launch_bounds__(256) void cast_kernel(const float* x, const float* add, half_t* out, long n4, int nv, int add_rows,
+                                                   long lo_plane) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n4) return;
   f32x4 v = ((const f32x4*)x)[idx];
@@ -242,15 +256,16 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* x, const float* 
     const long r = idx / nv;
     v += ((const f32x4*)add)[(r % add_rows) * nv + (idx - r * nv)];
   }
-  half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-  ((half4_t*)out)[idx] = o;
+  zh_store_h4(out + 4 * idx, lo_plane, v);
 }
 
-extern "C" int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, hipStream_t stream) {
-  ZH_CHECK_ARG(x && out && rows > 0 && D > 0 && D % 4 == 0, "zh_cast_f32_f16: bad arguments");
+extern "C" int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, long lo_plane,
+                               hipStream_t stream) {
+  ZH_CHECK_ARG(x && out && rows > 0 && D > 0 && D % 4 == 0 && lo_plane % 4 == 0, "zh_cast_f32_f16: bad arguments");
   ZH_CHECK_ARG(!add || add_rows > 0, "zh_cast_f32_f16: add needs add_rows");
   const long n4 = rows * (D / 4);
-  hipLaunchKernelGGL(cast_kernel, dim3(zh_cdiv(n4, 256)), dim3(256), 0, stream, x, add, (half_t*)out, n4, D / 4, add_rows > 0 ? add_rows : 1);
+  hipLaunchKernelGGL(cast_kernel, dim3(zh_cdiv(n4, 256)), dim3(256), 0, stream, x, add, (half_t*)out, n4, D / 4, add_rows > 0 ? add_rows : 1,
+                     lo_plane);
   ZH_CHECK_LAUNCH("zh_cast_f32_f16");
   return ZH_OK;
 }

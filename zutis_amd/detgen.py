@@ -139,6 +139,32 @@ def zutis_state_dict(cfg: ZutisConfig, seed: int = 1234) -> "OrderedDict[str, np
                        for k, (shp, std, mean) in zutis_param_shapes(cfg).items())
 
 
+STRESS_FIXED_CHANNELS = (7, 300, 611)     # same large value at every token ("outlier feature dimensions")
+STRESS_TOKEN_CHANNEL = 123                # large, token-dependent value ("massive activations")
+
+
+def stress_state_dict(cfg: ZutisConfig, magnitude: float = 100.0, seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+    """zutis_state_dict() with the residual-stream outliers real CLIP checkpoints have and random init lacks
+    (SURVEY.md §7 "Precision vs roofline"): from encoder block 0 on, three residual channels carry a constant of
+    +-`magnitude` (x the ~unit scale of the other channels) at every token, and from block 1 on one more channel carries a
+    token-dependent value of that scale.  LayerNorm gains are left near 1 (no attenuation: the worst case), weights are
+    generic fp32 (not fp16-representable), and the encoder's last block gets ordinary weights so the outliers also
+    reach ln_post and the head."""
+    sd = zutis_state_dict(cfg, seed)
+    D = cfg.width
+    ch = [c % D for c in STRESS_FIXED_CHANNELS]
+    b = sd["encoder.transformer.resblocks.0.mlp.c_proj.bias"].copy()
+    for j, c in enumerate(ch):
+        b[c] += magnitude * (1.0 if j % 2 == 0 else -1.0)
+    sd["encoder.transformer.resblocks.0.mlp.c_proj.bias"] = b
+    if cfg.layers > 1:
+        w = sd["encoder.transformer.resblocks.1.mlp.c_proj.weight"].copy()
+        # c_proj output std at init ~ proj_std * sqrt(4D) * rms(quickgelu(h)) ~ 0.25: scale one row to ~magnitude / 2
+        w[STRESS_TOKEN_CHANNEL % D] *= np.float32(2.0 * magnitude)
+        sd["encoder.transformer.resblocks.1.mlp.c_proj.weight"] = w
+    return sd
+
+
 def selfmask_param_shapes(n_queries: int = 20, D: int = 384, depth: int = 12, patch: int = 8, dec_layers: int = 6,
                           pos_grid: int = 28):
     """SelfMask state_dict (267 keys): DINO ViT-S/8 encoder + 6-layer decoder + objectness MLP

@@ -11,6 +11,13 @@ Data layout in HBM (one GPU, B images, T = 1 + h*w encoder tokens, M = 4*h*w dec
   KALL/VALL f16 [B*M, L*D]     cross-attention K / V of all L decoder layers from ONE GEMM each
   weights  f16, packed once per parameter version ([N,K] row-major = torch Linear layout, K contiguous)
 
+Precision (DESIGN.md "Precision"): the reference computes in fp32 end to end.  Every contraction here is a *site* with a
+mode: "f16" = fp16 MFMA operands, fp32 accumulate; "x3" = the reference-equivalent mode — operands carried as fp16 split
+pairs (hi + lo, 22 bits) and three MFMA products per accumulator (zh_gemm_f16x3, split-pair scores in flash attention).
+`precision=` picks the map: "exact" = x3 everywhere; "fast" (default) = x3 on the contractions whose rounding reaches an
+output directly (ffn1, ffn2, mask einsum, text-space projection, class logits) and f16 in the transformer bodies, which
+tests/test_precision_gpu.py holds to the north-star tolerance on the outlier-channel stress model; "f16" = no x3 at all.
+
 Reference call sites are cited per step (paths relative to the reference root).
 """
 from __future__ import annotations
@@ -25,7 +32,43 @@ import torch
 from . import _lib, ops
 from ._lib import ZutisHipError
 
+from .ops import Act
+
+
+def P_shape0(w) -> int:
+    """Rows (= output features) of a packed weight, plain fp16 tensor or split pair."""
+    return (w.hi if isinstance(w, Act) else w).shape[0]
+
 f16, f32 = torch.float16, torch.float32
+
+# contraction sites (see the module docstring)
+ENCODER_SITES = ("conv", "qkv", "attn", "out", "fc", "proj")
+DECODER_SITES = ("dec_kv", "dec")
+HEAD_SITES = ("ffn1", "ffn2", "mask", "textproj", "logits", "embed")
+ALL_SITES = ENCODER_SITES + DECODER_SITES + HEAD_SITES
+PRECISIONS = {
+    "f16": frozenset(),
+    "fast": frozenset(HEAD_SITES),
+    "exact": frozenset(ALL_SITES),
+}
+
+
+def resolve_precision(precision) -> frozenset:
+    """"f16" | "fast" | "exact" | an iterable of site names -> the set of sites computed in the x3 mode."""
+    if isinstance(precision, str):
+        if precision not in PRECISIONS:
+            raise ZutisHipError(f"precision {precision!r} not in {sorted(PRECISIONS)}")
+        return PRECISIONS[precision]
+    sites = set(precision)
+    bad = sites - set(ALL_SITES)
+    if bad:
+        raise ZutisHipError(f"unknown precision sites {sorted(bad)} (known: {ALL_SITES})")
+    # a split-pair consumer needs the producer of its operand to write lo planes: close the set under those requirements
+    if "attn" in sites:
+        sites.add("qkv")                      # Q / K lo planes come from the x3 QKV projection
+    if sites & {"mask", "dec_kv"}:
+        sites.add("ffn1")                     # decoder_input's lo plane comes from the x3 ffn1
+    return frozenset(sites)
 
 
 def _rup(x: int, m: int) -> int:
@@ -38,7 +81,9 @@ class _EngineBase:
 
     params: Dict[str, torch.Tensor]
 
-    def _init_base(self):
+    def _init_base(self, precision="fast"):
+        self.x3_sites = resolve_precision(precision)
+        self.precision = precision if isinstance(precision, str) else "custom"
         self._packed_key = None
         self._w: Dict[str, torch.Tensor] = {}
         self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
@@ -84,9 +129,26 @@ class _EngineBase:
             self._buf_gen += 1
         return b
 
+    def _x3(self, *sites) -> bool:
+        return any(s in self.x3_sites for s in sites)
+
+    def _abuf(self, name: str, shape, split: bool) -> Act:
+        """Cached fp16 activation buffer, a split pair when a consumer runs in the x3 mode."""
+        return Act(self._buf(name, ((2 if split else 1),) + tuple(shape), f16))
+
     @staticmethod
     def _h(t):
         return t.detach().to(f16).contiguous()
+
+    def _hw(self, t, site) -> "torch.Tensor | Act":
+        """A [N,K] weight packed for its site: plain fp16, or a scaled split pair for the x3 mode."""
+        return ops.split_weight(t.detach().contiguous()) if self._x3(site) else self._h(t)
+
+    def _gemm(self, site, A, W, out, **kw):
+        """One contraction at its site's precision.  x3: A and W must be split pairs (the producers were told so)."""
+        if self._x3(site):
+            return ops.gemm_x3(A, W, out, **kw)
+        return ops.gemm(A, W, out, **kw)
 
     @staticmethod
     def _c32(t):
@@ -95,7 +157,8 @@ class _EngineBase:
     def _pack_decoder(self, w, P, D, n_layers):
         """decoder.layers.{i}.* (transformer.py:231-251) -> dec.{i}.*; the cross-attention K / V weights of all layers
         are concatenated so the memory tokens are projected by ONE GEMM each."""
-        h, c32 = self._h, self._c32
+        c32 = self._c32
+        h = lambda t: self._hw(t, "dec")
         kw, kb, vw, vb = [], [], [], []
         for i in range(n_layers):
             p, q = f"decoder.layers.{i}.", f"dec.{i}."
@@ -111,8 +174,8 @@ class _EngineBase:
             w[q + "l2_w"], w[q + "l2_b"] = h(P[p + "linear2.weight"]), c32(P[p + "linear2.bias"])
             for n in ("norm1", "norm2", "norm3"):
                 w[q + n + ".w"], w[q + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
-        w["ca_k_w"], w["ca_k_b"] = h(torch.cat(kw, 0)), c32(torch.cat(kb, 0))       # [L*D, D]
-        w["ca_v_w"], w["ca_v_b"] = h(torch.cat(vw, 0)), c32(torch.cat(vb, 0))
+        w["ca_k_w"], w["ca_k_b"] = self._hw(torch.cat(kw, 0), "dec_kv"), c32(torch.cat(kb, 0))       # [L*D, D]
+        w["ca_v_w"], w["ca_v_b"] = self._hw(torch.cat(vw, 0), "dec_kv"), c32(torch.cat(vb, 0))
         w["dec.norm.w"], w["dec.norm.b"] = c32(P["decoder.norm.weight"]), c32(P["decoder.norm.bias"])
         w["query_embed"] = c32(P["query_embed"])
 
@@ -121,23 +184,25 @@ class _EngineBase:
         h, c32 = self._h, self._c32
         kc = 3 * patch * patch
         self.Kc = _rup(kc, 64)
-        wc = torch.zeros((D, self.Kc), dtype=f16, device=self._device())
-        wc[:, :kc] = P[prefix + "conv1.weight"].detach().reshape(D, kc).to(f16)
-        w["conv"] = wc
+        wc = torch.zeros((D, self.Kc), dtype=f32, device=self._device())
+        wc[:, :kc] = P[prefix + "conv1.weight"].detach().reshape(D, kc)
+        w["conv"] = self._hw(wc, "conv")
         for name in ("class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias", "ln_post.weight", "ln_post.bias"):
             w["encoder." + name] = c32(P[prefix + name])
         self._pack_resblocks(w, P, prefix, layers)
-        w["projT"] = h(P[prefix + "proj"].detach().t())                                # [E, D]
+        w["projT"] = self._hw(P[prefix + "proj"].detach().t(), self._proj_site)        # [E, D]
+
+    _proj_site = "textproj"      # the site of the visual projection: text-space tokens (ZUTIS) / the CLS embedding (encode_image)
 
     def _pack_resblocks(self, w, P, prefix: str, layers: int):
         """{prefix}transformer.resblocks.{i}.* (ResidualAttentionBlock, clip_arch.py:300-321) -> enc.{i}.*"""
-        h, c32 = self._h, self._c32
+        hw, c32 = self._hw, self._c32
         for i in range(layers):
             p, q = f"{prefix}transformer.resblocks.{i}.", f"enc.{i}."
-            w[q + "qkv_w"], w[q + "qkv_b"] = h(P[p + "attn.in_proj_weight"]), c32(P[p + "attn.in_proj_bias"])
-            w[q + "out_w"], w[q + "out_b"] = h(P[p + "attn.out_proj.weight"]), c32(P[p + "attn.out_proj.bias"])
-            w[q + "fc_w"], w[q + "fc_b"] = h(P[p + "mlp.c_fc.weight"]), c32(P[p + "mlp.c_fc.bias"])
-            w[q + "proj_w"], w[q + "proj_b"] = h(P[p + "mlp.c_proj.weight"]), c32(P[p + "mlp.c_proj.bias"])
+            w[q + "qkv_w"], w[q + "qkv_b"] = hw(P[p + "attn.in_proj_weight"], "qkv"), c32(P[p + "attn.in_proj_bias"])
+            w[q + "out_w"], w[q + "out_b"] = hw(P[p + "attn.out_proj.weight"], "out"), c32(P[p + "attn.out_proj.bias"])
+            w[q + "fc_w"], w[q + "fc_b"] = hw(P[p + "mlp.c_fc.weight"], "fc"), c32(P[p + "mlp.c_fc.bias"])
+            w[q + "proj_w"], w[q + "proj_b"] = hw(P[p + "mlp.c_proj.weight"], "proj"), c32(P[p + "mlp.c_proj.bias"])
             for ln, ln2 in (("ln_1", "ln1"), ("ln_2", "ln2")):
                 w[q + ln2 + ".w"], w[q + ln2 + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
 
@@ -146,10 +211,10 @@ class _EngineBase:
         W_, D, p = self._w, self.D, self.patch
         B = x.shape[0]
         T, R = 1 + h * w, B * (1 + h * w)
-        col = self._buf("col", (B * h * w, self.Kc), f16)
+        col = self._abuf("col", (B * h * w, self.Kc), self._x3("conv"))
         ops.im2col(x, col, p, self.Kc)                                                   # :378 conv1 as GEMM
         pe32 = self._buf("patch_emb", (B * h * w, D), f32)
-        ops.gemm(col, W_["conv"], pe32)
+        self._gemm("conv", col, W_["conv"], pe32)
         X = self._buf("X", (R, D), f32)
         ops.assemble_tokens_ln(pe32, W_["encoder.class_embedding"], pos, W_["encoder.ln_pre.weight"],
                                W_["encoder.ln_pre.bias"], 1e-5, X, B, T, D)                # :384-397
@@ -160,21 +225,24 @@ class _EngineBase:
         """Pre-LN transformer blocks on the fp32 residual stream X [B*T, D] (in place).
         clip_arch.py:318-321 (QuickGELU, eps 1e-5) and selfmask/vision_transformer.py:160-170 (erf GELU, eps 1e-6)."""
         W_, R = self._w, B * T
-        Y = self._buf("Y16", (R, D), f16)
-        QKV = self._buf("QKV16", (R, 3 * D), f16)
-        O = self._buf("O16", (R, D), f16)
-        Hh = self._buf("H16", (R, W_["enc.0.fc_w"].shape[0]), f16)
+        Fd = P_shape0(W_["enc.0.fc_w"])
+        Y = self._abuf("Y16", (R, D), self._x3("qkv", "fc"))
+        xa = self._x3("attn")                              # split-pair scores: lo planes written by the x3 QKV GEMM
+        QKV = self._abuf("QKV16", (R, 3 * D), xa)
+        O = self._abuf("O16", (R, D), self._x3("out"))
+        Hh = self._abuf("H16", (R, Fd), self._x3("proj"))
+        q_, k_, v_ = QKV, QKV.view(QKV.hi[:, D:]), QKV.view(QKV.hi[:, 2 * D:])
         for i in range(n_layers):
             pp = f"enc.{i}."
             ops.layernorm(X, W_[pp + "ln1.w"], W_[pp + "ln1.b"], eps, R, D, out_f16=Y)
-            ops.gemm(Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
-            ops.attention(QKV, QKV[:, D:], QKV[:, 2 * D:], O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=D // heads,
+            self._gemm("qkv", Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
+            ops.attention(q_, k_, v_, O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=D // heads,
                           ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
-                          strideO=T * D, causal=causal)
-            ops.gemm(O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
+                          strideO=T * D, causal=causal, x3=xa)
+            self._gemm("out", O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
             ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y)
-            ops.gemm(Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
-            ops.gemm(Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
+            self._gemm("fc", Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
+            self._gemm("proj", Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
 
     def _decoder(self, MEM16, KIN16, B, M, D, Q, L, heads, stack_all: bool):
         """transformer.py:114-152 over :262-291 (post-norm), tgt = zeros, query_pos = query_embed.
@@ -182,21 +250,24 @@ class _EngineBase:
         decoder.norm applied: every layer stacked as [B,L,Q,D] (stack_all) or the last layer only [B*Q, D]; the fp32
         copy of the last layer's normed output is left in buffer "dec_out32"."""
         W_, dh, R = self._w, D // heads, B * Q
-        KALL = self._buf("KALL", (B * M, L * D), f16)
-        VALL = self._buf("VALL", (B * M, L * D), f16)
-        ops.gemm(KIN16, W_["ca_k_w"], KALL, bias=W_["ca_k_b"])                             # all layers' K / V at once
-        ops.gemm(MEM16, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
+        xd = self._x3("dec")
+        Ff = P_shape0(W_["dec.0.l1_w"])
+        xk = xd and self._x3("dec_kv")                                                     # K lo planes feed the x3 scores
+        KALL = self._abuf("KALL", (B * M, L * D), xk)
+        VALL = self._abuf("VALL", (B * M, L * D), False)
+        self._gemm("dec_kv", KIN16, W_["ca_k_w"], KALL, bias=W_["ca_k_b"])                 # all layers' K / V at once
+        self._gemm("dec_kv", MEM16, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
         qpos = W_["query_embed"]
         tgt = self._buf("tgt", (R, D), f32)
         t1 = self._buf("t1", (R, D), f32)
-        tgt16 = self._buf("tgt16", (R, D), f16)
-        qin16 = self._buf("qin16", (R, D), f16)
-        qk16 = self._buf("qk16", (R, 2 * D), f16)
-        v16 = self._buf("v16", (R, D), f16)
-        qc16 = self._buf("qc16", (R, D), f16)
-        o16 = self._buf("do16", (R, D), f16)
-        ff16 = self._buf("ff16", (R, W_["dec.0.l1_w"].shape[0]), f16)
-        inter16 = self._buf("inter16", (B * (L if stack_all else 1) * Q, D), f16)
+        tgt16 = self._abuf("tgt16", (R, D), xd)
+        qin16 = self._abuf("qin16", (R, D), xd)
+        qk16 = self._abuf("qk16", (R, 2 * D), xd)
+        v16 = self._abuf("v16", (R, D), False)
+        qc16 = self._abuf("qc16", (R, D), xd)
+        o16 = self._abuf("do16", (R, D), xd)
+        ff16 = self._abuf("ff16", (R, Ff), xd)
+        inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
         out32 = self._buf("dec_out32", (R, D), f32)
         # tgt = zeros (zutis.py:164): layer 0's f16 inputs are constants of (B, weights) — zeros and f16(query_pos) — kept in
         # their own buffers, and its first residual add (+0) is skipped, so nothing is filled or cast per forward
@@ -204,27 +275,28 @@ class _EngineBase:
         init = self._geo.get(ikey)
         if init is None:
             z = torch.zeros((R, D), dtype=f32, device=self._device())
-            init = {"tgt16": torch.zeros((R, D), dtype=f16, device=self._device()),
-                    "qin16": torch.empty((R, D), dtype=f16, device=self._device())}
+            init = {"tgt16": Act(torch.zeros((2 if xd else 1, R, D), dtype=f16, device=self._device())),
+                    "qin16": Act.empty((R, D), xd, self._device())}
             ops.cast_f16(z, init["qin16"], R, D, add=qpos, add_rows=Q)
             self._geo_put(ikey, init)
         for l in range(L):
             pp = f"dec.{l}."
             a_qk, a_v = (init["qin16"], init["tgt16"]) if l == 0 else (qin16, tgt16)
-            ops.gemm(a_qk, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])               # q = k = tgt + query_pos
-            ops.gemm(a_v, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])                   # v = tgt
-            ops.attention(qk16, qk16[:, D:], v16, o16, batch=B, heads=heads, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D, ldk=2 * D,
-                          ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D)
-            ops.gemm(o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=tgt if l > 0 else None)   # tgt == 0 at l == 0
+            self._gemm("dec", a_qk, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])     # q = k = tgt + query_pos
+            self._gemm("dec", a_v, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])         # v = tgt
+            ops.attention(qk16, qk16.view(qk16.hi[:, D:]), v16, o16, batch=B, heads=heads, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D,
+                          ldk=2 * D, ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D, x3=xd)
+            self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=tgt if l > 0 else None)   # tgt == 0 at l == 0
             ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=tgt, out_f16_plus=qin16,
                           add=qpos, add_rows=Q)
-            ops.gemm(qin16, W_[pp + "ca_q_w"], qc16, bias=W_[pp + "ca_q_b"])
-            ops.attention(qc16, KALL[:, l * D:], VALL[:, l * D:], o16, batch=B, heads=heads, Tq=Q, Tk=M, head_dim=dh, ldq=D,
-                          ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D, strideO=Q * D)
-            ops.gemm(o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt)
+            self._gemm("dec", qin16, W_[pp + "ca_q_w"], qc16, bias=W_[pp + "ca_q_b"])
+            ops.attention(qc16, KALL.view(KALL.hi[:, l * D:]), VALL.view(VALL.hi[:, l * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=M,
+                          head_dim=dh, ldq=D, ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D,
+                          strideO=Q * D, x3=xk)
+            self._gemm("dec", o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt)
             ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
-            ops.gemm(tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
-            ops.gemm(ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
+            self._gemm("dec", tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
+            self._gemm("dec", ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
             ops.layernorm(t1, W_[pp + "norm3.w"], W_[pp + "norm3.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16,
                           out_f16_plus=qin16, add=qpos, add_rows=Q)
             if stack_all:                                                                   # :140-150, stacked [B,L,Q,D]
@@ -234,12 +306,14 @@ class _EngineBase:
                 ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16, out_f32=out32)
         return inter16
 
+    _dec_out_sites = ("ffn2",)   # sites consuming the decoder's normed outputs (ZUTIS: ffn2; SelfMask: mask einsum + objectness MLP)
+
 
 class ZutisEngine(_EngineBase):
     """Inference engine for one ZUTIS network.  `params` maps reference state_dict keys to fp32 CUDA tensors
     (typically the nn.Parameters of the drop-in module, so load_state_dict() is picked up via version counters)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], patch: int, dec_heads: int = 8):
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int, dec_heads: int = 8, precision="fast"):
         self.params = params
         self.patch = patch
         self.D = params["encoder.class_embedding"].shape[0]
@@ -253,7 +327,7 @@ class ZutisEngine(_EngineBase):
         self.grid = int(math.isqrt(params["encoder.positional_embedding"].shape[0] - 1))
         if self.dec_dh not in (64, 96):
             raise ZutisHipError(f"decoder head_dim {self.dec_dh} unsupported by zh_attention_f16 (64 or 96)")
-        self._init_base()
+        self._init_base(precision)
 
     # ------------------------------------------------------------------ packing
     def _pack(self):
@@ -266,7 +340,7 @@ class ZutisEngine(_EngineBase):
         self._pack_clip_visual(w, P, "encoder.", D, self.layers, self.patch)
         for ffn in ("ffn1", "ffn2"):
             for j in range(3):
-                w[f"{ffn}.{j}.w"], w[f"{ffn}.{j}.b"] = h(P[f"{ffn}.layers.{j}.weight"]), c32(P[f"{ffn}.layers.{j}.bias"])
+                w[f"{ffn}.{j}.w"], w[f"{ffn}.{j}.b"] = self._hw(P[f"{ffn}.layers.{j}.weight"], ffn), c32(P[f"{ffn}.layers.{j}.bias"])
         self._pack_decoder(w, P, D, self.dec_layers)
         self._w, self._packed_key = w, key
         self._geo.clear()
@@ -312,35 +386,36 @@ class ZutisEngine(_EngineBase):
         h2, w2 = 2 * h, 2 * w
         M = h2 * w2
         geo = self._geometry(h, w)
-        TOK = self._buf("TOK16", (B * M, D), f16)
+        TOK = self._abuf("TOK16", (B * M, D), self._x3("ffn1", "textproj"))
         ops.upsample2x_cl(tok, B, h, w, D, out_f16=TOK)                                     # :491-495
-        Fh = W_["ffn1.0.w"].shape[0]
-        f1 = self._buf("ffn_h1", (B * M, Fh), f16)
-        f2 = self._buf("ffn_h2", (B * M, Fh), f16)
-        DEC = self._buf("DEC16", (B * M, D), f16)
-        ops.gemm(TOK, W_["ffn1.0.w"], f1, bias=W_["ffn1.0.b"], act=ops.ACT_RELU)            # :500-503
-        ops.gemm(f1, W_["ffn1.1.w"], f2, bias=W_["ffn1.1.b"], act=ops.ACT_RELU)
-        ops.gemm(f2, W_["ffn1.2.w"], DEC, bias=W_["ffn1.2.b"])
-        KIN = self._buf("KIN16", (B * M, D), f16)
+        Fh = P_shape0(W_["ffn1.0.w"])
+        f1 = self._abuf("ffn_h1", (B * M, Fh), self._x3("ffn1"))
+        f2 = self._abuf("ffn_h2", (B * M, Fh), self._x3("ffn1"))
+        # decoder_input feeds the K/V projections, memory + pos and the mask einsum: a split pair needs the x3 ffn1 to fill it
+        DEC = self._abuf("DEC16", (B * M, D), self._x3("mask", "dec_kv"))
+        self._gemm("ffn1", TOK, W_["ffn1.0.w"], f1, bias=W_["ffn1.0.b"], act=ops.ACT_RELU)  # :500-503
+        self._gemm("ffn1", f1, W_["ffn1.1.w"], f2, bias=W_["ffn1.1.b"], act=ops.ACT_RELU)
+        self._gemm("ffn1", f2, W_["ffn1.2.w"], DEC, bias=W_["ffn1.2.b"])
+        KIN = self._abuf("KIN16", (B * M, D), self._x3("dec_kv"))
         ops.add_rowperiodic_f16(DEC, geo["pe"], KIN, B * M, D, M)                           # transformer.py:281 memory+pos
         inter16 = self._decoder(DEC, KIN, B, M, D, Q, L, self.dec_heads, stack_all=True)    # transformer.py:114-152
         RQ = B * L * Q
-        g1 = self._buf("ffn2_h1", (RQ, Fh), f16)
-        g2 = self._buf("ffn2_h2", (RQ, Fh), f16)
+        g1 = self._abuf("ffn2_h1", (RQ, Fh), self._x3("ffn2"))
+        g2 = self._abuf("ffn2_h2", (RQ, Fh), self._x3("ffn2"))
         q32 = self._buf("q32", (RQ, D), f32)
-        q16 = self._buf("q16", (RQ, D), f16)
-        ops.gemm(inter16, W_["ffn2.0.w"], g1, bias=W_["ffn2.0.b"], act=ops.ACT_RELU)        # zutis.py:514
-        ops.gemm(g1, W_["ffn2.1.w"], g2, bias=W_["ffn2.1.b"], act=ops.ACT_RELU)
-        ops.gemm(g2, W_["ffn2.2.w"], q32, bias=W_["ffn2.2.b"])
+        q16 = self._abuf("q16", (RQ, D), self._x3("mask"))
+        self._gemm("ffn2", inter16, W_["ffn2.0.w"], g1, bias=W_["ffn2.0.b"], act=ops.ACT_RELU)        # zutis.py:514
+        self._gemm("ffn2", g1, W_["ffn2.1.w"], g2, bias=W_["ffn2.1.b"], act=ops.ACT_RELU)
+        self._gemm("ffn2", g2, W_["ffn2.2.w"], q32, bias=W_["ffn2.2.b"])
         ops.l2norm_rows(q32, RQ, D, out_f16=q16)                                            # :515
         masks = torch.empty((B, L, Q, h2, w2), dtype=f32, device=x.device)
-        ops.gemm(q16, DEC, masks, act=ops.ACT_SIGMOID, M=L * Q, N=M, K=D, lda=D, ldw=D, ldc=M, batch=B,
-                 strideA=L * Q * D, strideW=M * D, strideC=L * Q * M)                       # :196-198,209
+        self._gemm("mask", q16, DEC, masks, act=ops.ACT_SIGMOID, M=L * Q, N=M, K=D, lda=D, ldw=D, ldc=M,
+                   batch=B, strideA=L * Q * D, strideW=M * D, strideC=L * Q * M)            # :196-198,209
         ts = self._buf("textspace", (B * M, self.E), f32)
-        ops.gemm(TOK, W_["projT"], ts)                                                      # :319
+        self._gemm("textproj", TOK, W_["projT"], ts)                                        # :319
         pt = torch.empty((B, h2, w2, self.E), dtype=f32, device=x.device)
         ws = self._buf("gln_ws", (max(1, ops.global_ln_l2_workspace_size(B, M, self.E)),), torch.uint8)
-        pt16 = self._buf("pt16", (B * M, self.E), f16)         # the f16 copy predict_semantic's class-logit GEMM consumes
+        pt16 = self._abuf("pt16", (B * M, self.E), self._x3("logits"))   # the copy predict_semantic's class-logit GEMM consumes
         ops.global_ln_l2(ts, B, M, self.E, out_f32=pt, out_f16=pt16, eps=1e-5, l2_eps=1e-7, workspace=ws)  # :320-322
         self._pt16_of = (weakref.ref(pt), pt._version)           # identity, not address: a freed tensor's address can be reused
         return {"mask_proposals": masks, "patch_tokens": pt}
@@ -406,13 +481,14 @@ class ZutisEngine(_EngineBase):
         """einsum("nc,bchw->bnhw") zutis.py:361-365 -> f32 [B,n,h,w]."""
         B, h, w, E = patch_tokens.shape
         n = text.shape[0]
-        pt16 = self._buf("pt16", (B * h * w, E), f16)
+        xl = self._x3("logits")
+        pt16 = self._abuf("pt16", (B * h * w, E), xl)
         src = self._pt16_of
         if not (src is not None and src[0]() is patch_tokens and src[1] == patch_tokens._version):
             ops.cast_f16(patch_tokens.contiguous(), pt16, B * h * w, E)     # tokens not produced by the last forward()
             self._pt16_of = None
         t32 = text.detach().to(device=patch_tokens.device, dtype=f32).contiguous()
-        t16 = self._buf("text16", (n, E), f16)
+        t16 = self._abuf("text16", (n, E), xl)
         recording = _lib.RECORDER is not None                              # a launch plan always contains the cast
         src = self._text16_of
         same = src is not None and src[0]() is text and src[1] == text._version and src[2] == self._buf_gen
@@ -420,8 +496,8 @@ class ZutisEngine(_EngineBase):
             ops.cast_f16(t32, t16, n, E)
             self._text16_of = None if recording else (weakref.ref(text), text._version, self._buf_gen)
         lo = torch.empty((B, n, h, w), dtype=f32, device=patch_tokens.device)
-        ops.gemm(t16, pt16, lo, M=n, N=h * w, K=E, lda=E, ldw=E, ldc=h * w, batch=B, strideA=0, strideW=h * w * E,
-                 strideC=n * h * w)
+        self._gemm("logits", t16, pt16, lo, M=n, N=h * w, K=E, lda=E, ldw=E, ldc=h * w, batch=B, strideA=0, strideW=h * w * E,
+                   strideC=n * h * w)
         return lo
 
     def predict_semantic(self, patch_tokens: torch.Tensor, text: torch.Tensor, size: Optional[Tuple[int, int]],
@@ -508,14 +584,16 @@ class ClipImageEncoder(_EngineBase):
     restated from the original forward kept in clip_arch.py:413-431,531-532): fixed positional embedding, CLS token ->
     ln_post -> @proj, then L2 normalisation.  `params` uses the CLIP visual state_dict keys under `prefix`."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], patch: int, prefix: str = "visual."):
+    _proj_site = "embed"
+
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int, prefix: str = "visual.", precision="fast"):
         self.params, self.patch, self.prefix = params, patch, prefix
         self.D = params[prefix + "class_embedding"].shape[0]
         self.heads = self.D // 64
         self.layers = 1 + max(int(k[len(prefix):].split(".")[2]) for k in params if k.startswith(prefix + "transformer.resblocks."))
         self.E = params[prefix + "proj"].shape[1]
         self.grid = int(math.isqrt(params[prefix + "positional_embedding"].shape[0] - 1))
-        self._init_base()
+        self._init_base(precision)
 
     def _pack(self):
         key = self._version_key()
@@ -537,11 +615,11 @@ class ClipImageEncoder(_EngineBase):
             raise ZutisHipError(f"encode_image: input {H}x{Wd} gives a {h}x{w} grid; CLIP's fixed pos-embed needs {g}x{g}")
         W_, D = self._w, self.D
         X = self._clip_trunk(x.contiguous(), W_["encoder.positional_embedding"], h, w)
-        cls16 = self._buf("cls16", (B, D), f16)
+        cls16 = self._abuf("cls16", (B, D), self._x3("embed"))
         ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B, D, out_f16=cls16,
                       in_group_rows=1, in_group_stride=1 + h * w, in_offset=0)              # ln_post(x[:, 0, :])
         e32 = self._buf("emb32", (B, self.E), f32)
-        ops.gemm(cls16, W_["projT"], e32)                                                   # @ proj
+        self._gemm("embed", cls16, W_["projT"], e32)                                        # @ proj
         out = torch.empty((B, self.E), dtype=f32, device=x.device)
         ops.l2norm_rows(e32, B, self.E, out_f32=out)                                        # / norm(dim=-1)
         return out
@@ -553,7 +631,7 @@ class ClipTextEncoder(_EngineBase):
     (token_embedding.weight, positional_embedding, transformer.resblocks.*, ln_final.*, text_projection);
     heads = width // 64 (clip_arch.py:606)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], prefix: str = "", chunk: int = 4096):
+    def __init__(self, params: Dict[str, torch.Tensor], prefix: str = "", chunk: int = 4096, precision="fast"):
         self.params, self.prefix, self.chunk = params, prefix, chunk
         self.ctx, self.D = params[prefix + "positional_embedding"].shape
         self.vocab = params[prefix + "token_embedding.weight"].shape[0]
@@ -563,7 +641,7 @@ class ClipTextEncoder(_EngineBase):
         self.layers = 1 + max(int(k.split(".")[k0]) for k in params if k.startswith(prefix + "transformer.resblocks."))
         if self.D % 64 or self.E % 4:
             raise ZutisHipError("ClipTextEncoder: width must be a multiple of 64 and the embedding of 4")
-        self._init_base()
+        self._init_base(precision)
 
     def _pack(self):
         key = self._version_key()
@@ -574,7 +652,7 @@ class ClipTextEncoder(_EngineBase):
         w["table"] = self._c32(P[pre + "token_embedding.weight"])
         w["pos"] = self._c32(P[pre + "positional_embedding"])
         w["lnf.w"], w["lnf.b"] = self._c32(P[pre + "ln_final.weight"]), self._c32(P[pre + "ln_final.bias"])
-        w["projT"] = self._h(P[pre + "text_projection"].detach().t())                  # [E, D]
+        w["projT"] = self._hw(P[pre + "text_projection"].detach().t(), "embed")        # [E, D]
         self._w, self._packed_key = w, key
 
     def _encode_chunk(self, tok: torch.Tensor, out: torch.Tensor):
@@ -585,9 +663,9 @@ class ClipTextEncoder(_EngineBase):
         self._vit_blocks(X, n, ctx, D, self.heads, self.layers, 1e-5, ops.ACT_QUICKGELU, causal=True)   # :538-540
         eot = self._buf("eot", (n, D), f32)
         ops.eot_rows(tok, X, eot)                                                      # :545 (LN is row-wise: gather first)
-        e16 = self._buf("eot16", (n, D), f16)
+        e16 = self._abuf("eot16", (n, D), self._x3("embed"))
         ops.layernorm(eot, W_["lnf.w"], W_["lnf.b"], 1e-5, n, D, out_f16=e16)          # :541 ln_final
-        ops.gemm(e16, W_["projT"], out)                                                # @ text_projection
+        self._gemm("embed", e16, W_["projT"], out)                                     # @ text_projection
 
     def encode_text(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens int64 [n, ctx] (clip.tokenize layout: EOT = the largest id of each row) -> f32 [n, E], not normalised."""
@@ -622,7 +700,9 @@ class SelfMaskEngine(_EngineBase):
     (vision_transformer.py:260-304) -> 6-layer decoder, 20 queries, no memory pos -> x2 upsampled tokens . queries ->
     objectness MLP; inference picks the argmax-objectness query, x4 bilinear, crop, > 0.5."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], patch: int = 8, heads: int = 6):
+    _dec_out_sites = ("mask", "ffn2")
+
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int = 8, heads: int = 6, precision="fast"):
         self.params = params
         self.patch, self.heads = patch, heads
         self.D = params["encoder.cls_token"].shape[-1]
@@ -633,7 +713,7 @@ class SelfMaskEngine(_EngineBase):
         self.grid = int(math.isqrt(self.n_pos))
         if self.D // heads != 64:
             raise ZutisHipError("SelfMaskEngine: head_dim must be 64")
-        self._init_base()
+        self._init_base(precision)
 
     def _pack(self):
         key = self._version_key()
@@ -641,26 +721,26 @@ class SelfMaskEngine(_EngineBase):
             return
         P, D, w = self.params, self.D, {}
         dev = self._device()
-        h, c32 = self._h, self._c32
+        hw, c32 = self._hw, self._c32
         kc = 3 * self.patch * self.patch
         self.Kc = _rup(kc, 64)
-        wc = torch.zeros((D, self.Kc), dtype=f16, device=dev)
-        wc[:, :kc] = P["encoder.patch_embed.proj.weight"].detach().reshape(D, kc).to(f16)
-        w["conv"], w["conv_b"] = wc, c32(P["encoder.patch_embed.proj.bias"])
+        wc = torch.zeros((D, self.Kc), dtype=f32, device=dev)
+        wc[:, :kc] = P["encoder.patch_embed.proj.weight"].detach().reshape(D, kc)
+        w["conv"], w["conv_b"] = hw(wc, "conv"), c32(P["encoder.patch_embed.proj.bias"])
         w["cls"] = c32(P["encoder.cls_token"].reshape(D))
         w["pos"] = c32(P["encoder.pos_embed"].reshape(-1, D))
         w["norm.w"], w["norm.b"] = c32(P["encoder.norm.weight"]), c32(P["encoder.norm.bias"])
         for i in range(self.layers):
             p, q = f"encoder.blocks.{i}.", f"enc.{i}."
-            w[q + "qkv_w"], w[q + "qkv_b"] = h(P[p + "attn.qkv.weight"]), c32(P[p + "attn.qkv.bias"])
-            w[q + "out_w"], w[q + "out_b"] = h(P[p + "attn.proj.weight"]), c32(P[p + "attn.proj.bias"])
-            w[q + "fc_w"], w[q + "fc_b"] = h(P[p + "mlp.fc1.weight"]), c32(P[p + "mlp.fc1.bias"])
-            w[q + "proj_w"], w[q + "proj_b"] = h(P[p + "mlp.fc2.weight"]), c32(P[p + "mlp.fc2.bias"])
+            w[q + "qkv_w"], w[q + "qkv_b"] = hw(P[p + "attn.qkv.weight"], "qkv"), c32(P[p + "attn.qkv.bias"])
+            w[q + "out_w"], w[q + "out_b"] = hw(P[p + "attn.proj.weight"], "out"), c32(P[p + "attn.proj.bias"])
+            w[q + "fc_w"], w[q + "fc_b"] = hw(P[p + "mlp.fc1.weight"], "fc"), c32(P[p + "mlp.fc1.bias"])
+            w[q + "proj_w"], w[q + "proj_b"] = hw(P[p + "mlp.fc2.weight"], "proj"), c32(P[p + "mlp.fc2.bias"])
             for ln, ln2 in (("norm1", "ln1"), ("norm2", "ln2")):
                 w[q + ln2 + ".w"], w[q + ln2 + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
         self._pack_decoder(w, P, D, self.dec_layers)
         for j in range(3):
-            w[f"ffn.{j}.w"], w[f"ffn.{j}.b"] = h(P[f"ffn.layers.{j}.weight"]), c32(P[f"ffn.layers.{j}.bias"])
+            w[f"ffn.{j}.w"], w[f"ffn.{j}.b"] = hw(P[f"ffn.layers.{j}.weight"], "ffn2"), c32(P[f"ffn.layers.{j}.bias"])
         self._w, self._packed_key = w, key
         self._geo.clear()
 
@@ -690,32 +770,32 @@ class SelfMaskEngine(_EngineBase):
         B, _, H, Wd = x.shape
         h, w = (H + p - 1) // p, (Wd + p - 1) // p                                       # make_input_divisible :260-267
         T, R, M = 1 + h * w, B * (1 + h * w), 4 * h * w
-        col = self._buf("col", (B * h * w, self.Kc), f16)
+        col = self._abuf("col", (B * h * w, self.Kc), self._x3("conv"))
         ops.im2col(x, col, p, self.Kc, pad_to_patch=True)
         pe32 = self._buf("patch_emb", (B * h * w, D), f32)
-        ops.gemm(col, W_["conv"], pe32, bias=W_["conv_b"])                               # PatchEmbed :182 (conv WITH bias)
+        self._gemm("conv", col, W_["conv"], pe32, bias=W_["conv_b"])                     # PatchEmbed :182 (conv WITH bias)
         X = self._buf("X", (R, D), f32)
         ops.assemble_tokens_ln(pe32, W_["cls"], self._pos(h, w), None, None, 0.0, X, B, T, D)   # prepare_tokens :269-281
         self._vit_blocks(X, B, T, D, self.heads, self.layers, 1e-6, ops.ACT_GELU_ERF)    # Block :160-170
         tok = self._buf("tok", (B, h * w, D), f32)
-        tok16 = self._buf("tok16", (B * h * w, D), f16)
+        tok16 = self._abuf("tok16", (B * h * w, D), self._x3("dec_kv"))
         ops.layernorm(X, W_["norm.w"], W_["norm.b"], 1e-6, B * h * w, D, out_f32=tok, out_f16=tok16,
                       in_group_rows=h * w, in_group_stride=T, in_offset=1)               # norm(x)[:, 1:]  :298, selfmask.py:94-100
         q16 = self._decoder(tok16, tok16, B, h * w, D, Q, L, self.heads, stack_all=False)    # selfmask.py:110-116 (pos=None)
-        FEAT = self._buf("FEAT16", (B * M, D), f16)
+        FEAT = self._abuf("FEAT16", (B * M, D), self._x3("mask"))
         ops.upsample2x_cl(tok, B, h, w, D, out_f16=FEAT)                                 # forward_pixel_decoder :131-135
         masks = torch.empty((B, 1, Q, 2 * h, 2 * w), dtype=f32, device=x.device)
-        ops.gemm(q16, FEAT, masks, act=ops.ACT_SIGMOID, M=Q, N=M, K=D, lda=D, ldw=D, ldc=M, batch=B,
-                 strideA=Q * D, strideW=M * D, strideC=Q * M)                             # einsum("bqn,bnhw->bqhw") + sigmoid :181
-        o1 = self._buf("obj_h1", (B * Q, D), f16)
-        o2 = self._buf("obj_h2", (B * Q, D), f16)
-        ops.gemm(q16, W_["ffn.0.w"], o1, bias=W_["ffn.0.b"], act=ops.ACT_RELU)           # objectness MLP :182
-        ops.gemm(o1, W_["ffn.1.w"], o2, bias=W_["ffn.1.b"], act=ops.ACT_RELU)
+        self._gemm("mask", q16, FEAT, masks, act=ops.ACT_SIGMOID, M=Q, N=M, K=D, lda=D, ldw=D, ldc=M, batch=B,
+                   strideA=Q * D, strideW=M * D, strideC=Q * M)                           # einsum("bqn,bnhw->bqhw") + sigmoid :181
+        o1 = self._abuf("obj_h1", (B * Q, D), self._x3("ffn2"))
+        o2 = self._abuf("obj_h2", (B * Q, D), self._x3("ffn2"))
+        self._gemm("ffn2", q16, W_["ffn.0.w"], o1, bias=W_["ffn.0.b"], act=ops.ACT_RELU)  # objectness MLP :182
+        self._gemm("ffn2", o1, W_["ffn.1.w"], o2, bias=W_["ffn.1.b"], act=ops.ACT_RELU)
         obj = torch.empty((B, 1, Q, 1), dtype=f32, device=x.device)
         if not inference:
-            ops.gemm(o2, W_["ffn.2.w"], obj, bias=W_["ffn.2.b"], act=ops.ACT_SIGMOID, M=B * Q, N=1, K=D, ldc=1)
+            self._gemm("ffn2", o2, W_["ffn.2.w"], obj, bias=W_["ffn.2.b"], act=ops.ACT_SIGMOID, M=B * Q, N=1, K=D, ldc=1)
             return {"objectness": obj, "mask_pred": masks}
-        ops.gemm(o2, W_["ffn.2.w"], obj, bias=W_["ffn.2.b"], M=B * Q, N=1, K=D, ldc=1)
+        self._gemm("ffn2", o2, W_["ffn.2.w"], obj, bias=W_["ffn.2.b"], M=B * Q, N=1, K=D, ldc=1)
         # the query with the largest objectness logit is picked on the device (first maximum, as torch.argmax): x4 bilinear of
         # that plane only, cropped to [:H,:W], > 0.5 — no host round trip, so images on different streams overlap
         idx = torch.empty((B,), dtype=torch.int64, device=x.device)

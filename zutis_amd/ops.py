@@ -55,11 +55,87 @@ def _chk(t: torch.Tensor, dtype, name: str):
         raise _lib.ZutisHipError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
 
 
+class Act:
+    """An fp16 activation (or weight) tensor, optionally stored as a split pair for the f16x3 precision (zutis_hip.h):
+    `t` has shape [P, ...] with P = 1 (plain fp16) or 2 (hi, lo); `hi` = t[0] is the plain fp16 tensor every fp16 consumer
+    reads; `plane` = element offset hi -> lo (0 when not split); `out_scale` = 2^-s for weights packed as W * 2^s."""
+    __slots__ = ("t", "hi", "plane", "out_scale")
+
+    def __init__(self, t: torch.Tensor, out_scale: float = 1.0):
+        assert t.dtype == f16 and t.shape[0] in (1, 2)
+        self.t, self.hi = t, t[0]
+        self.plane = t.stride(0) if t.shape[0] == 2 else 0
+        self.out_scale = float(out_scale)
+
+    @staticmethod
+    def empty(shape, split: bool, device) -> "Act":
+        return Act(torch.empty((2 if split else 1,) + tuple(shape), dtype=f16, device=device))
+
+    def view(self, t_hi: torch.Tensor) -> "Act":
+        """The same pair seen through a view of the hi plane (column / row slices keep the plane offset)."""
+        a = Act.__new__(Act)
+        a.t, a.hi, a.plane, a.out_scale = self.t, t_hi, self.plane, self.out_scale
+        return a
+
+
+def split_weight(w32: torch.Tensor) -> Act:
+    """Pack-time split of an fp32 weight for zh_gemm_f16x3: W * 2^s with s chosen so that max|W| lands in [2^13, 2^14)
+    (hi far from overflow, lo = f16(W*2^s - hi) a normal fp16 number); out_scale = 2^-s is exact."""
+    w = w32.detach().to(f32)
+    m = float(w.abs().max()) if w.numel() else 0.0
+    s = 0 if m == 0.0 or not math.isfinite(m) else 13 - math.floor(math.log2(m))
+    s = max(-14, min(24, s))
+    ws = w * (2.0 ** s)
+    hi = ws.to(f16)
+    lo = (ws - hi.to(f32)).to(f16)
+    return Act(torch.stack([hi, lo]).contiguous(), out_scale=2.0 ** -s)
+
+
+def _hp(a):
+    """(hi tensor, lo-plane offset) of an Act or a plain fp16 tensor."""
+    return (a.hi, a.plane) if isinstance(a, Act) else (a, 0)
+
+
+def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, act: int = ACT_NONE, *, M=None, N=None, K=None,
+            lda=None, ldw=None, ldc=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None,
+            strideR: int = 0):
+    """out = act((A @ W^T) * W.out_scale + bias) + residual at the reference's fp32-class precision: A and W are split pairs
+    (Act with plane != 0); out is an f32 tensor, an fp16 tensor / plain Act, or a split Act."""
+    L = _lib.load()
+    if not (isinstance(A, Act) and isinstance(W, Act) and A.plane and W.plane):
+        raise _lib.ZutisHipError("gemm_x3: both operands must be split pairs")
+    a, w = A.hi, W.hi
+    M = a.shape[-2] if M is None else M
+    K = a.shape[-1] if K is None else K
+    N = w.shape[-2] if N is None else N
+    lda = a.stride(-2) if lda is None else lda
+    ldw = w.stride(-2) if ldw is None else ldw
+    o, planeC = _hp(out)
+    kind = 0 if o.dtype == f32 else (2 if planeC else 1)
+    ldc = o.stride(-2) if ldc is None else ldc
+    if residual is not None:
+        assert residual.dtype == f32 and kind == 0
+        ldr = residual.stride(-2) if ldr is None else ldr
+        res_rows = res_rows or M
+    if bias is not None:
+        assert bias.dtype == f32 and bias.numel() >= N
+    args = (_p(a), lda, strideA, A.plane, _p(w), ldw, strideW, W.plane, _p(o), ldc, strideC, planeC, kind,
+            float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream())
+    _lib.check(_launch("gemm_f16x3", 2.0 * M * N * K * batch, lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
+    return out
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residual=None, res_rows: int = 0,
          act: int = ACT_NONE, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, batch: int = 1,
          strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None, strideR: int = 0):
-    """out = act(A @ W^T + bias) + residual[m % res_rows].  A [M,K] f16, W [N,K] f16, out f32|f16 [M,N]."""
+    """out = act(A @ W^T + bias) + residual[m % res_rows].  A [M,K] f16, W [N,K] f16, out f32|f16 [M,N].
+    Act operands / outputs are read / written through their hi plane (plain fp16)."""
     L = _lib.load()
+    A, W, out_ret = _hp(A)[0], _hp(W)[0], out
+    if isinstance(out, Act):
+        if out.plane:
+            raise _lib.ZutisHipError("gemm: an fp16-operand GEMM cannot fill a split-pair output (its lo plane would be stale)")
+        out = out.hi
     M = A.shape[-2] if M is None else M
     K = A.shape[-1] if K is None else K
     N = W.shape[-2] if N is None else N
@@ -76,24 +152,31 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
     args = (_p(A), lda, strideA, _p(W), ldw, strideW, _p(out), ldc, strideC, int(out.dtype == f16),
             _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream())
     _lib.check(_launch("gemm_f16", 2.0 * M * N * K * batch, lambda: L.zh_gemm_f16(*args)), "zh_gemm_f16")
-    return out
+    return out_ret
 
 
 def attention(Q, K, V, O, *, batch, heads, Tq, Tk, head_dim, ldq, ldk, ldv, ldo, strideQ, strideK, strideV, strideO,
-              scale=None, causal=False):
+              scale=None, causal=False, x3=False):
+    """x3: Q and K are split-pair Acts and the scores get the three-product fp32-class form; a split O is filled as a pair."""
     L = _lib.load()
     scale = 1.0 / math.sqrt(head_dim) if scale is None else scale
+    (Q, pq), (K, pk), (V, _), (O, po) = _hp(Q), _hp(K), _hp(V), _hp(O)
+    if x3 and not (pq and pk):
+        raise _lib.ZutisHipError("attention(x3): Q and K must be split pairs")
+    if not x3:
+        pq = pk = 0
+    name = "attention_f16x3" if x3 else "attention_f16"
     if causal:
         if Tq != Tk:
             raise _lib.ZutisHipError("causal attention needs Tq == Tk")
         args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
-                batch, heads, Tq, head_dim, float(scale), _stream())
-        _lib.check(_launch("attention_f16", 2.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_causal_f16(*args)),
+                batch, heads, Tq, head_dim, float(scale), pq, pk, po, _stream())
+        _lib.check(_launch(name, 2.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_causal_f16(*args)),
                    "zh_attention_causal_f16")
         return O
     args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
-            batch, heads, Tq, Tk, head_dim, float(scale), _stream())
-    _lib.check(_launch("attention_f16", 4.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_f16(*args)),
+            batch, heads, Tq, Tk, head_dim, float(scale), pq, pk, po, _stream())
+    _lib.check(_launch(name, 4.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_f16(*args)),
                "zh_attention_f16")
     return O
 
@@ -130,10 +213,14 @@ def layernorm(x, gamma, beta, eps, rows, D, *, out_f32=None, out_f16=None, out_f
     in_group_stride = in_group_rows if in_group_stride is None else in_group_stride
     out_group_rows = rows if out_group_rows is None else out_group_rows
     out_group_stride = out_group_rows if out_group_stride is None else out_group_stride
+    (out_f16, p1), (out_f16_plus, p2) = _hp(out_f16), _hp(out_f16_plus)
+    if out_f16 is not None and out_f16_plus is not None and p1 != p2:
+        raise _lib.ZutisHipError("layernorm: both fp16 outputs must be split pairs of the same shape, or both plain")
+    lo_plane = p1 or p2
     _lib.check(L.zh_layernorm_f32(_p(x), in_group_rows, in_group_stride, in_offset,
                                   out_group_rows, out_group_stride, out_offset, _p(gamma), _p(beta), float(eps),
                                   _p(out_f32), _p(out_f16), _p(out_f16_plus), _p(out_f32_plus), _p(add), add_rows,
-                                  rows, D, _stream()), "zh_layernorm_f32")
+                                  rows, D, lo_plane, _stream()), "zh_layernorm_f32")
 
 
 def assemble_tokens_ln(patch_emb, cls, pos, gamma, beta, eps, out, B, T, D):
@@ -144,7 +231,8 @@ def assemble_tokens_ln(patch_emb, cls, pos, gamma, beta, eps, out, B, T, D):
 
 def l2norm_rows(x, rows, D, out_f32=None, out_f16=None, eps=0.0):
     L = _lib.load()
-    _lib.check(L.zh_l2norm_rows(_p(x), _p(out_f32), _p(out_f16), float(eps), rows, D, _stream()), "zh_l2norm_rows")
+    out_f16, lo = _hp(out_f16)
+    _lib.check(L.zh_l2norm_rows(_p(x), _p(out_f32), _p(out_f16), float(eps), rows, D, lo, _stream()), "zh_l2norm_rows")
 
 
 def global_ln_l2_workspace_size(B, M, Cc) -> int:
@@ -156,15 +244,17 @@ def global_ln_l2(x, B, M, Cc, out_f32=None, out_f16=None, eps=1e-5, l2_eps=1e-7,
     need = global_ln_l2_workspace_size(B, M, Cc)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    out_f16, lo = _hp(out_f16)
     _lib.check(L.zh_global_ln_l2(_p(x), _p(out_f32), _p(out_f16), float(eps), float(l2_eps), B, M, Cc, _p(workspace),
-                                 workspace.numel() * workspace.element_size(), _stream()), "zh_global_ln_l2")
+                                 workspace.numel() * workspace.element_size(), lo, _stream()), "zh_global_ln_l2")
 
 
 def im2col(x, out, patch, Kpad, pad_to_patch=False):
     L = _lib.load()
     B, Cin, H, W = x.shape
     _chk(x, f32, "im2col x")
-    _lib.check(L.zh_im2col_f16(_p(x), _p(out), B, Cin, H, W, patch, Kpad, int(pad_to_patch), _stream()), "zh_im2col_f16")
+    out, lo = _hp(out)
+    _lib.check(L.zh_im2col_f16(_p(x), _p(out), B, Cin, H, W, patch, Kpad, int(pad_to_patch), lo, _stream()), "zh_im2col_f16")
 
 
 def posembed_bicubic(pos, out, grid, h, w, D, scale_h, scale_w, has_cls=True):
@@ -175,7 +265,8 @@ def posembed_bicubic(pos, out, grid, h, w, D, scale_h, scale_w, has_cls=True):
 
 def upsample2x_cl(x, B, h, w, D, out_f32=None, out_f16=None):
     L = _lib.load()
-    _lib.check(L.zh_upsample2x_bilinear_cl(_p(x), _p(out_f32), _p(out_f16), B, h, w, D, _stream()), "zh_upsample2x_bilinear_cl")
+    out_f16, lo = _hp(out_f16)
+    _lib.check(L.zh_upsample2x_bilinear_cl(_p(x), _p(out_f32), _p(out_f16), B, h, w, D, lo, _stream()), "zh_upsample2x_bilinear_cl")
 
 
 def sine_pe(out, h, w, D, temperature=10000.0):
@@ -185,7 +276,8 @@ def sine_pe(out, h, w, D, temperature=10000.0):
 
 def add_rowperiodic_f16(a, add, out, rows, D, add_rows):
     L = _lib.load()
-    _lib.check(L.zh_add_rowperiodic_f16(_p(a), _p(add), _p(out), rows, D, add_rows, _stream()), "zh_add_rowperiodic_f16")
+    (a, la), (out, lo) = _hp(a), _hp(out)
+    _lib.check(L.zh_add_rowperiodic_f16(_p(a), _p(add), _p(out), rows, D, add_rows, la, lo, _stream()), "zh_add_rowperiodic_f16")
 
 
 def fill_f32(x, value=0.0):
@@ -196,7 +288,8 @@ def fill_f32(x, value=0.0):
 
 def cast_f16(x, out, rows, D, add=None, add_rows=0):
     L = _lib.load()
-    _lib.check(L.zh_cast_f32_f16(_p(x), _p(add), add_rows, _p(out), rows, D, _stream()), "zh_cast_f32_f16")
+    out, lo = _hp(out)
+    _lib.check(L.zh_cast_f32_f16(_p(x), _p(add), add_rows, _p(out), rows, D, lo, _stream()), "zh_cast_f32_f16")
 
 
 def lin_scale(in_size: int, out_size: int) -> float:
