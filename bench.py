@@ -270,7 +270,8 @@ def main():
         torch.cuda.synchronize()
         ops.PROFILER = None
         stats = {k: (len(v), sum(w for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
-        nl, fl, tt = stats["gemm_f16"]
+        g1, g3 = stats.get("gemm_f16", (0, 0.0, 0.0)), stats.get("gemm_f16x3", (0, 0.0, 0.0))
+        nl, fl, tt = g1[0] + g3[0], g1[1] + 3.0 * g3[1], g1[2] + g3[2]      # MFMA work: an x3 product issues three MFMAs
         ach = fl / tt / 1e12
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")     # separate rocprofv3 --pmc passes of this command

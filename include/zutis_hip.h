@@ -212,8 +212,11 @@ int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8,
 
 /* Retrieval (datasets/index_dataset.py:163-167): per row of scores [rows, N] (row stride ld) the k largest entries, score
  * descending, ties by ascending index — replaces torch.argsort(descending=True)[:n_images] per category.
- * idx_out int64 [rows,k]; val_out f32 [rows,k] or NULL.  k <= 1024. */
-int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, long long* idx_out, float* val_out, zh_stream_t stream);
+ * idx_out int64 [rows,k]; val_out f32 [rows,k] or NULL.  k <= 1024.  The index reported for column i is
+ * idx_map[row*ld + i] when idx_map != NULL (merging candidate lists that carry global image indices), else i + idx_add
+ * (chunk offset); ties are broken by ascending column.  Output rows have stride out_ld >= k. */
+int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, const long long* idx_map, long long idx_add,
+                 long long* idx_out, float* val_out, long out_ld, zh_stream_t stream);
 
 /* Device-side run extraction for COCO RLE + boxes + areas of selected masks (masks u8 [n,H,W] row-major; sel int32
  * [n_sel] mask indices): positions int32 [n_sel, max_runs] = column-major pixel indices where the value changes;

@@ -354,3 +354,11 @@ def retrieve_topk(text: np.ndarray, image: np.ndarray, k: int):
     sim = text.astype(np.float32) @ image.astype(np.float32).T
     idx = np.stack([np.lexsort((np.arange(sim.shape[1]), -row))[:k] for row in sim])
     return idx, np.take_along_axis(sim, idx, axis=1)
+
+
+def merge_topk(cand_idx: np.ndarray, cand_val: np.ndarray, k: int):
+    """Merge of per-chunk / per-rank candidate lists (new code: the reference is single-GPU and argsorts everything at once,
+    datasets/index_dataset.py:163-167): the k best of each row by (score descending, column ascending); returns the
+    candidates' global indices and scores.  Padding columns carry index -1 and score -inf."""
+    order = np.stack([np.lexsort((np.arange(cand_val.shape[1]), -row))[:k] for row in cand_val])
+    return np.take_along_axis(cand_idx, order, axis=1), np.take_along_axis(cand_val, order, axis=1)

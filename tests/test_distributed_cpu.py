@@ -43,15 +43,23 @@ def _worker(rank, world, port, n_images, q):
         text = torch.randn((4, 16), generator=g)
         images = torch.randn((n_images + 4, 16), generator=g)
         images[5] = images[2]                                            # exact score tie across shards: smaller index first
-        def cpu_topk(t, im, k):
+        def cpu_topk(t, im, k, index_offset=0):
             i, v = O.retrieve_topk(t.numpy(), im.numpy(), k)
+            return torch.from_numpy(i) + index_offset, torch.from_numpy(v)
+
+        def cpu_merge(ci, cv, k):                                        # the product's merge is the zh_topk_rows kernel
+            i, v = O.merge_topk(ci.numpy(), cv.numpy(), k)
             return torch.from_numpy(i), torch.from_numpy(v)
-        retrieval.retrieve_topk = cpu_topk
+        retrieval.retrieve_topk, retrieval.merge_topk = cpu_topk, cpu_merge
         lo2, hi2 = zd.shard_range(images.shape[0], rank, world)
         k = 6                                                            # > the smaller shard: exercises the -1 / -inf padding
         idx, val = retrieval.retrieve_topk_sharded(text, images[lo2:hi2], lo2, k)
         ri, rv = cpu_topk(text, images, k)
         assert torch.equal(idx, ri) and torch.allclose(val, rv)
+        # k larger than the GLOBAL image count is clamped exactly as the unsharded path clamps it (no -1 rows leak out)
+        idx, val = retrieval.retrieve_topk_sharded(text, images[lo2:hi2], lo2, images.shape[0] + 5)
+        ri, rv = cpu_topk(text, images, images.shape[0])
+        assert idx.shape == ri.shape and torch.equal(idx, ri) and int(idx.min()) >= 0
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

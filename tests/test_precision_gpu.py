@@ -79,7 +79,9 @@ def test_gemm_x3_epilogues_and_outputs(dev, act):
         assert torch.allclose(o16.hi.float().cpu().double(), y, atol=4e-3, rtol=1e-3)
         osp = Act.empty((M, N), True, dev)
         ops.gemm_x3(Ad, Wd, osp, bias=bias.to(dev), act=act)
-        assert torch.equal(osp.hi, o16.hi)                               # the hi plane IS the plain fp16 tensor
+        # the hi plane IS the plain fp16 tensor (the two instantiations may contract the activation differently: <= 1 ulp)
+        d = (osp.hi.float() - o16.hi.float()).abs()
+        assert float((d / o16.hi.float().abs().clamp_min(6e-5)).max()) <= 2.0 ** -10 and float((d > 0).float().mean()) < 0.01
         both = osp.t[0].float() + osp.t[1].float()
         tol = 2e-6 if act != 4 else 2e-5                                 # erff on the device vs torch's erf
         assert float((both.cpu().double() - y).abs().max()) < tol * max(1.0, float(y.abs().max()))

@@ -3,6 +3,10 @@
 // row does an exact radix SELECT of the k-th largest (score, index) pair — 8 histogram passes over the row, no sort of N
 // elements — then compacts the k survivors and bitonic-sorts only those in LDS.  Ordering: score descending, ties by
 // ascending index (torch.argsort(descending=True) leaves tie order unspecified).  HBM-bound: 9 reads of the row.
+// Reported index of column i: idx_map ? idx_map[row*ld + i] : i + idx_add — chunk offsets and the merge of per-chunk /
+// per-rank candidates (whose columns carry global image indices) need no separate gather.  Ties are always broken by
+// ascending COLUMN, so candidate lists must be laid out in ascending-index order of equal scores (chunk-major / rank-major
+// concatenations of sorted lists are).  Outputs are rows of stride out_ld (a column block of a wider candidate table).
 #include "common.h"
 
 typedef unsigned long long u64;
@@ -15,7 +19,8 @@ __device__ __forceinline__ u64 topk_key(float v, unsigned idx) {
 
 #define TOPK_MAXK 1024
 
-__global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, long ld, long N, int k, long long* idx_out, float* val_out) {
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, long ld, long N, int k, const long long* idx_map,
+                                                        long long idx_add, long long* idx_out, float* val_out, long out_ld) {
   __shared__ unsigned hist[256];
   __shared__ u64 sel[TOPK_MAXK];
   __shared__ u64 s_prefix;
@@ -75,17 +80,18 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, lon
   for (int i = tid; i < k; i += 256) {
     const u64 key = sel[i];
     const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-    idx_out[(long)blockIdx.x * k + i] = (long long)idx;
-    if (val_out) val_out[(long)blockIdx.x * k + i] = row[idx];
+    idx_out[(long)blockIdx.x * out_ld + i] = idx_map ? idx_map[(long)blockIdx.x * ld + idx] : (long long)idx + idx_add;
+    if (val_out) val_out[(long)blockIdx.x * out_ld + i] = row[idx];
   }
 }
 
-extern "C" int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, long long* idx_out, float* val_out,
-                            hipStream_t stream) {
-  ZH_CHECK_ARG(scores && idx_out && rows > 0 && N > 0 && k > 0, "zh_topk_rows: bad arguments");
+extern "C" int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, const long long* idx_map, long long idx_add,
+                            long long* idx_out, float* val_out, long out_ld, hipStream_t stream) {
+  ZH_CHECK_ARG(scores && idx_out && rows > 0 && N > 0 && k > 0 && out_ld >= k, "zh_topk_rows: bad arguments");
   ZH_CHECK_ARG(k <= TOPK_MAXK && k <= N, "zh_topk_rows: k=%d must be <= min(%d, N)", k, TOPK_MAXK);
   ZH_CHECK_ARG(N < 4294967295L && ld >= N, "zh_topk_rows: N must fit 32 bits and ld >= N");
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, stream, scores, ld, N, k, idx_out, val_out);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, stream, scores, ld, N, k, idx_map, idx_add, idx_out, val_out,
+                     out_ld);
   ZH_CHECK_LAUNCH("zh_topk_rows");
   return ZH_OK;
 }

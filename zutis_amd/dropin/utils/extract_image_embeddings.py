@@ -21,13 +21,22 @@ _MEAN = np.array((0.48145466, 0.4578275, 0.40821073), np.float32)
 _STD = np.array((0.26862954, 0.26130258, 0.27577711), np.float32)
 
 
+def resize_crop_box(w: int, h: int, n_px: int):
+    """CLIP's `_transform` (third-party clip, used at utils/extract_image_embeddings.py:43,98-103) =
+    torchvision Resize(n_px, BICUBIC) + CenterCrop(n_px), with torchvision's integer conventions: the shorter side becomes
+    n_px and the longer one int(n_px * long / short) (truncation); the crop offset is int(round((side - n_px) / 2.0))
+    (Python's round-half-to-even).  Returns ((new_w, new_h), (left, top))."""
+    if w <= h:
+        nw, nh = n_px, int(n_px * h / w)
+    else:
+        nw, nh = int(n_px * w / h), n_px
+    return (nw, nh), (int(round((nw - n_px) / 2.0)), int(round((nh - n_px) / 2.0)))
+
+
 def _preprocess(p_image: str, n_px: int) -> np.ndarray:
     im = Image.open(p_image).convert("RGB")
-    w, h = im.size
-    s = n_px / min(w, h)
-    im = im.resize((max(n_px, round(w * s)), max(n_px, round(h * s))), Image.BICUBIC)
-    w, h = im.size
-    left, top = (w - n_px) // 2, (h - n_px) // 2
+    (nw, nh), (left, top) = resize_crop_box(*im.size, n_px)
+    im = im.resize((nw, nh), Image.BICUBIC)
     a = np.asarray(im.crop((left, top, left + n_px, top + n_px)), np.float32) / 255.0
     return ((a - _MEAN) / _STD).transpose(2, 0, 1)
 

@@ -98,7 +98,8 @@ class _EngineBase:
         self._pack()
         e = copy.copy(self)
         e._bufs, e._buf_gen = {}, 0
-        e._geo = dict(self._geo)
+        # input-independent tables are shared; captured graphs are not (they replay into the parent's buffers and stream)
+        e._geo = {k: v for k, v in self._geo.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
         e._pt16_of = e._text16_of = None       # provenance of the f16 copies held in the (new, empty) buffer cache
         return e
 
@@ -428,6 +429,8 @@ class ZutisEngine(_EngineBase):
         self._pack()
         key = ("graph", tuple(x.shape))
         g = self._geo.get(key)
+        if g is not None and g["weights"] != self._packed_key:
+            g = None                                 # parameters changed since capture: the graph holds the old packed weights
         if g is None:
             static_x = x.clone()
             s = torch.cuda.Stream()
@@ -439,7 +442,12 @@ class ZutisEngine(_EngineBase):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.forward(static_x)
-            g = {"x": static_x, "graph": graph, "out": out}
+            # The graph bakes in raw pointers to this shape's scratch buffers, geometry tables and packed weights.  _buf()
+            # drops a name's buffers when another shape arrives and _geo is a bounded cache, so the graph keeps its own
+            # references: shape A, then B, then A again replays A into memory that is still A's.
+            g = {"x": static_x, "graph": graph, "out": out, "weights": self._packed_key,
+                 "keep": (dict(self._bufs), {k: v for k, v in self._geo.items() if not (isinstance(k, tuple) and k and k[0] == "graph")},
+                          self._w)}
             self._geo_put(key, g)
         g["x"].copy_(x)
         g["graph"].replay()
@@ -464,13 +472,16 @@ class ZutisEngine(_EngineBase):
             labels = None if text32 is None else self.predict_semantic(out["patch_tokens"], text32, size)
         if self._buf_gen != gen:
             raise ZutisHipError("build_plan: buffers were re-allocated while recording")
-        return {"x": static_x, "out": out, "labels": labels, "text": text32, "plan": rec.build(), "gen": gen}
+        return {"x": static_x, "out": out, "labels": labels, "text": text32, "plan": rec.build(), "gen": gen,
+                "weights": self._packed_key}
 
     def run_plan(self, p, x: Optional[torch.Tensor] = None):
         """Replay a plan from build_plan() on the current stream.  Outputs are the plan's static tensors (overwritten by
         the next replay: clone what must survive)."""
         if self._buf_gen != p["gen"]:
             raise ZutisHipError("run_plan: the engine's buffers changed since the plan was built")
+        if self._version_key() != p["weights"]:
+            raise ZutisHipError("run_plan: parameters changed since the plan was built (it holds the old packed weights): rebuild it")
         if x is not None:
             p["x"].copy_(x)
         p["plan"].run(torch.cuda.current_stream().cuda_stream)

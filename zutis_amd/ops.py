@@ -45,6 +45,9 @@ def _p(t: Optional[torch.Tensor]):
         return None
     if not t.is_cuda:
         raise _lib.ZutisHipError("zutis_amd ops need GPU tensors (no CPU fallback)")
+    if _raw_device is not None and t.device.index != _raw_device():
+        raise _lib.ZutisHipError(f"tensor on cuda:{t.device.index} but the current device (whose stream is used) is "
+                                 f"cuda:{_raw_device()}: wrap the call in torch.cuda.device(...)")
     if _lib.RECORDER is not None:
         _lib.RECORDER.keepalive.append(t)        # a launch plan owns every tensor whose address it recorded
     return t.data_ptr()
@@ -407,15 +410,24 @@ def resize_nearest_u8(x_u8, H, W):
     return out
 
 
-def topk_rows(scores, k, N=None, with_values=False):
-    """scores f32 [R, ld] on the GPU -> int64 [R,k] indices of the k largest of the first N columns (score desc, index asc)."""
+def topk_rows(scores, k, N=None, with_values=False, idx_map=None, idx_add=0, out_idx=None, out_val=None):
+    """scores f32 [R, ld] on the GPU -> int64 [R,k] indices of the k largest of the first N columns (score desc, column asc).
+    Reported index of column i = idx_map[r, i] (int64 [R, ld]) if given, else i + idx_add.  out_idx / out_val may be column
+    blocks [R, k] of wider row-major tables (same row stride for both)."""
     L = _lib.load()
     _chk(scores, f32, "topk scores")
     R, ld = scores.shape
     N = ld if N is None else N
-    idx = torch.empty((R, k), dtype=torch.int64, device=scores.device)
-    val = torch.empty((R, k), dtype=f32, device=scores.device) if with_values else None
-    _lib.check(L.zh_topk_rows(_p(scores), ld, R, N, k, _p(idx), _p(val), _stream()), "zh_topk_rows")
+    if idx_map is not None:
+        _chk(idx_map, torch.int64, "topk idx_map")
+        if tuple(idx_map.shape) != (R, ld):
+            raise _lib.ZutisHipError("topk_rows: idx_map must have the shape of scores")
+    idx = torch.empty((R, k), dtype=torch.int64, device=scores.device) if out_idx is None else out_idx
+    val = (torch.empty((R, k), dtype=f32, device=scores.device) if out_val is None else out_val) if with_values else None
+    if idx.dtype != torch.int64 or idx.stride(1) != 1 or (val is not None and (val.dtype != f32 or val.stride() != idx.stride())):
+        raise _lib.ZutisHipError("topk_rows: outputs must be int64 / f32 row-major blocks with equal row strides")
+    _lib.check(L.zh_topk_rows(_p(scores), ld, R, N, k, _p(idx_map), int(idx_add), _p(idx), _p(val), idx.stride(0), _stream()),
+               "zh_topk_rows")
     return (idx, val) if with_values else idx
 
 
