@@ -36,6 +36,14 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PRECISION_DTYPE = {"fast": "f16", "exact": "f16x3", "f16": "f16"}
+PRECISION_TEXT = {
+    "fast": "fp16 MFMA operands / fp32 accumulate in the transformer bodies, fp32 residual stream + LayerNorm + softmax; the "
+            "output-facing contractions (ffn1, ffn2, mask einsum, text-space projection, class logits) in the f16x3 mode",
+    "exact": "every contraction in the reference-equivalent f16x3 mode: operands as fp16 split pairs (hi + lo, 22 bits), three MFMA "
+             "products per accumulator in fp32, split-pair attention scores; fp32 residual stream + LayerNorm + softmax",
+    "f16": "fp16 MFMA operands / fp32 accumulate everywhere (round-1 behaviour)",
+}
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 FLOPS_PER_IMAGE_C2 = 124.4e9 + 0.146e9  # forward + semantic predict
 
@@ -123,11 +131,13 @@ def main():
     ap.add_argument("--precision", default="fast", choices=["fast", "exact", "f16"],
                     help="engine precision (zutis_amd/engine.py): fast = fp16 MFMA operands in the transformer bodies + the fp32-class "
                          "x3 mode on the output-facing contractions (passes tests/test_precision_gpu.py at 1e-3); exact = x3 everywhere")
+    ap.add_argument("--no-second-precision", action="store_true", help="skip the secondary timed run at the other precision (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--torch-gpu-baseline", action="store_true",
+    ap.add_argument("--no-torch-gpu-baseline", action="store_true")
+    ap.add_argument("--torch-gpu-baseline", action="store_true", default=True,
                     help="also time the oracle (= the reference's op sequence) with stock PyTorch-ROCm fp32 eager ops on this GPU "
                          "(SURVEY 8d: the 'reference single-GPU PyTorch' the north-star's >= 10x target is quoted against)")
-    ap.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="images in the CPU-baseline sample (timed three times)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch intra-op threads of the CPU baseline (16 was the fastest of 8..128 on the 2x64-core GPU box)")
     args = ap.parse_args()
@@ -161,93 +171,74 @@ def main():
     cfg = detgen.VIT_B16
     B, S, n = args.batch, args.size, args.classes
     P = {k: torch.from_numpy(v).to(dev) for k, v in detgen.zutis_state_dict(cfg).items()}
-    eng = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=args.precision)
     text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
     # rank r owns global images [r*B, (r+1)*B): contiguous shards so a gather reproduces reference order
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     x = torch.randn((B, 3, S, S), generator=g).to(dev)
     hw2 = (2 * ((S - cfg.patch) // cfg.patch + 1)) ** 2
-    gathered = [torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) for _ in range(2)] if dist_on else None
-    pending = [None]
-
-    def step(i: int):
-        out = eng.forward(x)
-        lo = eng.semantic_logits_lowres(out["patch_tokens"], text)
-        labels = torch.empty((B, S, S), dtype=torch.int64, device=dev)
-        ops.upsample_argmax(lo, labels, B, n, lo.shape[2], lo.shape[3], S, S)
-        if dist_on:
-            if pending[0] is not None:
-                pending[0].wait()
-            _, pending[0] = zd.all_gather_logits(lo.view(B, n, hw2), out=gathered[i & 1], async_op=True)
-        return labels
-
-    # ---- lanes: one engine (its own activation buffers), launch plan, stream and gather buffer per step in flight
     n_lanes = max(1, args.inflight)
-    lanes = []
-    if n_lanes > 1:
+
+    def timed_run(precision: str, steps: int, warmup: int):
+        """Builds the engine for `precision`, one lane (engine fork + launch plan + stream + gather buffer) per step in
+        flight, and times `steps` steps through zutis_amd.distributed.StepPipeline.  Returns (engine, seconds)."""
+        eng = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
+        lanes = []
         for li in range(n_lanes):
             e = eng if li == 0 else eng.fork()       # own activation buffers, shared packed weights
-            e.forward(x)                                   # eager warm-up: packs weights, sizes the buffer cache
-            with zplan.Recorder() as rec:
+            e.forward(x)                             # eager warm-up: packs weights, sizes the buffer cache
+            plan = None
+
+            def one_step(e=e):
                 out = e.forward(x)
                 lo = e.semantic_logits_lowres(out["patch_tokens"], text)
                 labels = torch.empty((B, S, S), dtype=torch.int64, device=dev)
                 ops.upsample_argmax(lo, labels, B, n, lo.shape[2], lo.shape[3], S, S)
-            lanes.append({"eng": e, "plan": rec.build(), "lo": lo, "labels": labels, "stream": torch.cuda.Stream(device=dev),
-                          "gathered": torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) if dist_on else None,
-                          "pending": None})
+                return lo, labels
+            if n_lanes > 1:
+                with zplan.Recorder() as rec:
+                    lo, labels = one_step()
+                plan = rec.build()
+            else:
+                lo, labels = one_step()
+            lanes.append(zd.Lane(lo.view(B, n, hw2), gathered=torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) if dist_on else None,
+                                 stream=torch.cuda.Stream(device=dev) if n_lanes > 1 else None,
+                                 state={"eng": e, "plan": plan, "labels": labels, "step": one_step}))
         torch.cuda.synchronize()
-        zplan.run_many([ln["plan"] for ln in lanes], [ln["stream"].cuda_stream for ln in lanes])   # prime every lane once (setup,
-        torch.cuda.synchronize()                                                                    # like the eager warm-up above)
 
-    def run_steps(first: int, count: int):
-        """`count` consecutive steps; with lanes, groups of `n_lanes` steps are enqueued interleaved, one stream each."""
-        if not lanes:
-            for i in range(first, first + count):
-                step(i)
-            return
-        done = 0
-        while done < count:
-            grp = lanes[:min(n_lanes, count - done)]
-            if dist_on:
-                for ln in grp:                              # the lane's previous gather must have read `lo` before it is rewritten
-                    if ln["pending"] is not None:
-                        with torch.cuda.stream(ln["stream"]):
-                            ln["pending"].wait()
-                        ln["pending"] = None
-            zplan.run_many([ln["plan"] for ln in grp], [ln["stream"].cuda_stream for ln in grp])
-            if dist_on:
+        def launch(grp, ids):
+            if n_lanes > 1:      # consecutive steps replayed interleaved, one stream each, from one C loop
+                zplan.run_many([ln.state["plan"] for ln in grp], [ln.stream.cuda_stream for ln in grp])
+            else:                # plain eager loop on the current stream (payload tensor is re-bound: eager steps allocate)
                 for ln in grp:
-                    with torch.cuda.stream(ln["stream"]):
-                        _, ln["pending"] = zd.all_gather_logits(ln["lo"].view(B, n, hw2), out=ln["gathered"], async_op=True)
-            done += len(grp)
-
-    def drain():
+                    lo, ln.state["labels"] = ln.state["step"]()
+                    ln.payload = lo.view(B, n, hw2)
+        pipe = zd.StepPipeline(lanes, launch, gather=dist_on)
+        pipe.run(max(warmup, n_lanes))
+        pipe.drain()
         if dist_on:
-            if pending[0] is not None:
-                pending[0].wait()
-                pending[0] = None
-            for ln in lanes:
-                if ln["pending"] is not None:
-                    ln["pending"].wait()
-                    ln["pending"] = None
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe.run(steps)
+        pipe.drain()
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return eng, dt
 
-    run_steps(0, args.warmup)
-    drain()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(0, args.steps)
-    drain()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    eng, elapsed = timed_run(args.precision, args.steps, args.warmup)
+    # second line (N = 1 only, bounded): the same workload with every contraction in the reference-equivalent x3 mode
+    other = None
+    if world == 1 and not args.no_second_precision:
+        oprec = "exact" if args.precision != "exact" else "fast"
+        osteps = max(3, args.steps // 2)
+        oeng, odt = timed_run(oprec, osteps, max(1, args.warmup // 2))
+        other = {"precision": oprec, "eng": oeng, "value": round(B * osteps / odt, 2), "ms_per_step": round(odt / osteps * 1e3, 3), "steps": osteps}
 
     # ---- roofline of the dominant kernel: HIP events (torch current stream == launch stream) around every launch
     prof = {}
@@ -271,14 +262,16 @@ def main():
         ops.PROFILER = None
         stats = {k: (len(v), sum(w for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
         g1, g3 = stats.get("gemm_f16", (0, 0.0, 0.0)), stats.get("gemm_f16x3", (0, 0.0, 0.0))
-        nl, fl, tt = g1[0] + g3[0], g1[1] + 3.0 * g3[1], g1[2] + g3[2]      # MFMA work: an x3 product issues three MFMAs
+        dom = "gemm_f16" if g1[2] >= g3[2] else "gemm_f16x3"               # the kernel family with the larger GPU time
+        nl, fl, tt = stats[dom]                                               # ALGORITHMIC flops (2*M*N*K) of its launches
         ach = fl / tt / 1e12
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")     # separate rocprofv3 --pmc passes of this command
         if os.path.exists(pmc) and B == 32 and S == 336:
             traffic = json.load(open(pmc))["gemm_f16_kernel_all_variants"]["hbm_bytes_per_launch"]
             traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction)"
-        roof = {"bound": "mfma", "kernel": "gemm_f16_kernel", "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
+        roof = {"bound": "mfma", "kernel": "gemm_f16_kernel" + ("<SPLIT=1> (zh_gemm_f16x3)" if dom == "gemm_f16x3" else " (zh_gemm_f16)"),
+                "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "flops_per_launch": round(fl / nl),
                 "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
@@ -286,10 +279,18 @@ def main():
                                "overlapped); rocprofv3 --stats of `bench.py --inflight 1` = profiles/r01_bench_kernel_stats.csv, "
                                "of the default run with steps in flight = profiles/r01_bench_inflight_kernel_stats.csv",
                 "gemm_share_of_step": round(tt / (elapsed / args.steps), 3)}
-        if "attention_f16" in stats:
-            na, fa, ta = stats["attention_f16"]
-            roof["attention_tflops"] = round(fa / ta / 1e12, 1)
-            roof["attention_share_of_step"] = round(ta / (elapsed / args.steps), 3)
+        oth = "gemm_f16x3" if dom == "gemm_f16" else "gemm_f16"
+        if oth in stats:                                                      # the other GEMM family of this precision mode
+            no, fo, to = stats[oth]
+            roof["other_gemm"] = {"kernel": oth, "launches_per_step": no, "algorithmic_tflops": round(fo / to / 1e12, 1),
+                                  "share_of_step": round(to / (elapsed / args.steps), 3)}
+        if g3[0]:
+            roof["x3_note"] = "zh_gemm_f16x3 issues three MFMAs per algorithmic product: its MFMA-pipe rate is 3x its algorithmic TFLOP/s"
+        for an in ("attention_f16", "attention_f16x3"):
+            if an in stats:
+                na, fa, ta = stats[an]
+                roof[an + "_tflops"] = round(fa / ta / 1e12, 1)
+                roof[an + "_share_of_step"] = round(ta / (elapsed / args.steps), 3)
 
     # ---- CPU baseline: the oracle (CPU port of the reference path) on a bounded sample, rank 0 at N=1 only
     cpu = None
@@ -307,24 +308,34 @@ def main():
                 o = O.zutis_forward(Pc, xi, cfg.patch, cfg.dec_heads)
                 return o, O.predict_semantic(o["patch_tokens"], tc, size=(S, S))
         cpu_pass(xs[:1])                                  # warm-up
-        t1 = time.perf_counter()
-        chunks = [cpu_pass(xs[i:i + 8]) for i in range(0, ns, 8)]
-        dt = time.perf_counter() - t1
+        times, chunks = [], None
+        for _ in range(3):                                # median of three passes over the sample
+            t1 = time.perf_counter()
+            chunks = [cpu_pass(xs[i:i + 8]) for i in range(0, ns, 8)]
+            times.append(time.perf_counter() - t1)
+        dt = sorted(times)[1]
         o_ref = {"patch_tokens": torch.cat([c[0]["patch_tokens"] for c in chunks])}
         lab_ref = np.concatenate([c[1] for c in chunks])
         cpu = {"value": round(ns / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"{ns} of the {B} step images in chunks of 8, oracle forward + semantic predict after a 1-image warm-up, "
-                         f"{dt:.1f}s; host has {os.cpu_count()} hardware threads"}
+               "sample": f"{ns} of the {B} step images in chunks of 8, oracle forward + semantic predict, median of 3 passes "
+                         f"({', '.join('%.1f' % t for t in times)} s) after a 1-image warm-up; host has {os.cpu_count()} hardware "
+                         f"threads, {torch.get_num_threads()} torch threads was the fastest setting of 8..128 on this host class"}
         lo_ref = O.semantic_logits_lowres(o_ref["patch_tokens"], tc).numpy()
-        out = eng.forward(x[:ns])
-        lo = eng.semantic_logits_lowres(out["patch_tokens"], text).cpu().numpy()
-        lab = eng.predict_semantic(out["patch_tokens"], text, (S, S)).cpu().numpy()
-        hist = O.confusion_hist(lab_ref, lab, n)
-        parity = {"logit_max_abs_err": float(np.abs(lo - lo_ref).max()), "label_agreement": float((lab == lab_ref).mean()),
-                  "miou_vs_oracle_labels": float(O.scores_from_hist(hist)[0]["Mean IoU"]), "tolerance": 1e-3}
+
+        def parity_of(e):
+            out = e.forward(x[:ns])
+            lo = e.semantic_logits_lowres(out["patch_tokens"], text).cpu().numpy()
+            lab = e.predict_semantic(out["patch_tokens"], text, (S, S)).cpu().numpy()
+            hist = O.confusion_hist(lab_ref, lab, n)
+            return {"logit_max_abs_err": float(np.abs(lo - lo_ref).max()), "label_agreement": float((lab == lab_ref).mean()),
+                    "miou_vs_oracle_labels": float(O.scores_from_hist(hist)[0]["Mean IoU"]), "tolerance": 1e-3,
+                    "against": "fp32 oracle (CPU restatement of the reference path) on the same %d images" % ns}
+        parity = parity_of(eng)
+        if other is not None:
+            other["parity"] = parity_of(other["eng"])
 
     torch_gpu = None
-    if rank == 0 and world == 1 and args.torch_gpu_baseline:
+    if rank == 0 and world == 1 and args.torch_gpu_baseline and not args.no_torch_gpu_baseline:
         import torch.nn.functional as F
         from oracle import zutis_ref as O
         Pg = {k: v for k, v in P.items()}                 # fp32 parameters already on the device
@@ -352,7 +363,10 @@ def main():
             "metric": f"images/sec, COCO2017-val-shaped ViT-B/16 dense semantic segmentation @{S}px (ZUTIS forward + semantic predict)",
             "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
+            "precision": {"mode": args.precision, "what": PRECISION_TEXT[args.precision],
+                          "stress_test": "tests/test_precision_gpu.py::test_stress_model_c2 (x100 outlier residual channels, sharpened "
+                                         "attention, generic fp32 weights): fast <= 2.5e-4 logits / 1e-3 masks, exact <= 2e-5 / 2e-4 vs the fp32 oracle"},
             "config": {"workload": f"{'C2' if (S, n) == (336, 81) else 'C4' if (S, n) == (518, 920) else 'custom'}: ViT-B/16 CLIP encoder + ZUTIS head, {B}x3x{S}x{S} per GPU, {n} classes, "
                                    f"predict(semantic,size=({S},{S}))", "global_batch": world * B, "image_size": S,
                        "n_classes": n, "parallelism": f"dp{world}", "accumulate": "f32", "residual_stream": "f32",
@@ -364,6 +378,12 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             **({"torch_gpu_baseline": torch_gpu} if torch_gpu else {}),
         }
+        if other is not None:       # the same workload at the other precision (same steps-in-flight setup, fewer steps)
+            line["second_precision"] = {"mode": other["precision"], "dtype": PRECISION_DTYPE[other["precision"]],
+                                        "what": PRECISION_TEXT[other["precision"]], "value": other["value"], "unit": "images/s",
+                                        "ms_per_step": other["ms_per_step"], "steps": other["steps"], "parity": other.get("parity")}
+        if torch_gpu:
+            line["vs_torch_gpu_fp32_eager"] = round(line["value"] / torch_gpu["value"], 2)
     if dist_on:
         dist.destroy_process_group()      # first: RCCL prints its version banner on stdout when the communicator goes away
     if rank == 0:

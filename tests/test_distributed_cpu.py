@@ -60,6 +60,27 @@ def _worker(rank, world, port, n_images, q):
         idx, val = retrieval.retrieve_topk_sharded(text, images[lo2:hi2], lo2, images.shape[0] + 5)
         ri, rv = cpu_topk(text, images, images.shape[0])
         assert idx.shape == ri.shape and torch.equal(idx, ri) and int(idx.min()) >= 0
+        # evaluation pipeline (bench.py's scheduling): 3 lanes, 7 steps (ragged final group of 1), async gathers retired one
+        # round later; every gathered buffer must hold both ranks' payloads of ITS step, in rank order
+        seen = []
+
+        def launch(grp, ids):
+            for ln, i in zip(grp, ids):
+                ln.payload.copy_(torch.full((2, 3), float(100 * i), dtype=torch.float32) + rank)
+
+        def consume(ln, step):
+            exp = torch.cat([torch.full((2, 3), float(100 * step + r)) for r in range(world)])
+            assert torch.equal(ln.gathered, exp), (step, ln.gathered)
+            seen.append(step)
+        lanes = [zd.Lane(torch.zeros((2, 3)), gathered=torch.empty((2 * world, 3))) for _ in range(3)]
+        pipe = zd.StepPipeline(lanes, launch, gather=True, consume=consume)
+        pipe.run(3)                                                      # warm-up group
+        pipe.run(7)
+        pipe.drain()
+        assert sorted(seen) == list(range(10)) and pipe.next_step == 10
+        nog = zd.StepPipeline([zd.Lane(torch.zeros(1)) for _ in range(2)], lambda g_, ids: seen.extend(-i - 1 for i in ids), gather=False)
+        nog.run(5); nog.drain()
+        assert [s for s in seen if s < 0] == [-1, -2, -3, -4, -5]
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

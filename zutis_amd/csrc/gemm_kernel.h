@@ -335,7 +335,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     // slab holds fp32 and each lane writes 8 B to the hi plane and 8 B to the lo plane).
     constexpr int ESZ = OUT_F16 ? 2 : 4;
     constexpr int RS = TN * 16 * ESZ + 16;                  // slab row stride (bytes)
-    constexpr int PR = (OUT_F16 ? 64 : 32) < TM * 16 ? (OUT_F16 ? 64 : 32) : TM * 16;   // rows per pass
+    constexpr int PR0 = (OUT_F16 ? 64 : 32) < TM * 16 ? (OUT_F16 ? 64 : 32) : TM * 16;
+    constexpr int PR = (TM * 16) % PR0 == 0 ? PR0 : (TM * 16 <= 48 ? TM * 16 : 16);       // rows per pass (divides the wave tile)
     constexpr int MTP = PR / 16;
     constexpr int CPRW = TN * 16 * ESZ / 16;                // 16-B chunks per row
     constexpr int NIT = PR * CPRW / 64;

@@ -65,14 +65,19 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // the LDS-staged epilogue reads the slab in 16-byte chunks: f32 / split rows need N % 4 == 0 (vec_ok), f16 rows N % 8 == 0
   const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&
                        (out_kind == 1 ? (N % 8 == 0) : true) && (out_kind != 2 || (ldc % 8 == 0 && planeC % 8 == 0 && N % 8 == 0));
-  // 256 x 128 (8 waves, 144 KiB ring, one block per CU) when it fills the chip at least ~1.5 times, else 128 x 64 (4 waves, two per CU)
-  const long big_tiles = (long)zh_cdiv(M, 256) * zh_cdiv(N, 128) * batch;
+  // 256 x 128 or 192 x 128 (8 waves, 144 / 120 KiB ring, one block per CU; the 192-row tile quantises N = 768 GEMMs into
+  // 1.73 rounds of the chip instead of 1.31) or 128 x 64 (4 waves, two blocks per CU) for small problems
+  const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
+  const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
+  const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
+  int pick = (c64 < c256 && c64 < c192) ? 64 : (c192 < c256 ? 192 : 256);
   const int forced = gemm_dev_overrides().tile;
-  const bool big = forced ? (forced == 256) : big_tiles >= 384;
+  if (forced == 64 || forced == 192 || forced == 256) pick = forced;
   bool ok;
   if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
   else if (!wide_ok) ok = launch_x3<2, 2, 4, 2, 3, 1>(p, batch, out_kind, stream);
-  else if (big) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
+  else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
+  else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16x3");

@@ -45,3 +45,62 @@ def all_reduce_confusion(hist: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the per-rank int64 n x n confusion matrices (utils/running_score.py:11-20 accumulates them serially)."""
     dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
     return hist
+
+
+class Lane:
+    """One evaluation step in flight: `payload` is the tensor the step's kernels write and the collective reads (low-res class
+    logits), `gathered` the all-gather destination, `stream` the HIP stream its work is enqueued on (None on CPU), `state`
+    whatever the launcher needs (engine, launch plan, outputs)."""
+    __slots__ = ("payload", "gathered", "stream", "state", "pending", "step")
+
+    def __init__(self, payload, gathered=None, stream=None, state=None):
+        self.payload, self.gathered, self.stream, self.state = payload, gathered, stream, state
+        self.pending, self.step = None, -1
+
+
+class StepPipeline:
+    """Scheduling of an evaluation loop with `len(lanes)` independent steps in flight (bench.py, config 2 / 4 at N GPUs).
+
+    Steps are processed in groups of up to n_lanes: `launch(group, step_ids)` enqueues the compute of the group's lanes
+    (interleaved on their streams — zutis_amd.plan.run_many on the GPU), then every lane issues an ASYNC all-gather of its
+    payload on its own stream, so the collective of step i overlaps the compute of the steps behind it.  A lane's payload and
+    gather buffer are reused every n_lanes steps: before the lane is launched again its previous gather is waited for (on the
+    lane's stream: the wait orders the stream, not the host) and `consume(lane, step_id)` — if given — sees the gathered
+    result of that earlier step.  The final group may be ragged (count % n_lanes lanes)."""
+
+    def __init__(self, lanes, launch, gather: bool, group=None, consume=None):
+        self.lanes, self.launch, self.gather, self.group, self.consume = list(lanes), launch, gather, group, consume
+        self.next_step = 0
+
+    def _on_stream(self, lane):
+        import contextlib
+        return torch.cuda.stream(lane.stream) if lane.stream is not None else contextlib.nullcontext()
+
+    def _retire(self, lane):
+        if lane.pending is not None:
+            with self._on_stream(lane):
+                lane.pending.wait()
+            lane.pending = None
+            if self.consume is not None:
+                self.consume(lane, lane.step)
+
+    def run(self, count: int):
+        done = 0
+        while done < count:
+            grp = self.lanes[:min(len(self.lanes), count - done)]
+            ids = list(range(self.next_step, self.next_step + len(grp)))
+            if self.gather:
+                for ln in grp:                 # the lane's previous gather must have read `payload` before it is rewritten
+                    self._retire(ln)
+            self.launch(grp, ids)
+            for ln, i in zip(grp, ids):
+                ln.step = i
+                if self.gather:
+                    with self._on_stream(ln):
+                        ln.gathered, ln.pending = all_gather_logits(ln.payload, out=ln.gathered, async_op=True, group=self.group)
+            done += len(grp)
+            self.next_step += len(grp)
+
+    def drain(self):
+        for ln in self.lanes:
+            self._retire(ln)
