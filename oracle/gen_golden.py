@@ -258,6 +258,90 @@ def gen_text():
     print("text.npz", {k: v.shape for k, v in d.items()})
 
 
+def gen_c3():
+    """Config 3 at its own shape (coco20k_eval.py:241-268): ViT-B/16, batch 1, native-resolution COCO-like inputs, forward +
+    predict(mask_type="instance", size=image size, nms_type="hard").  Stores the per-prediction integers / scores / boxes,
+    the masks bit-packed, and sub-sampled forward tensors."""
+    cfg = detgen.VIT_B16
+    net = build_reference_zutis(cfg, 81)
+    d = {}
+    for (H, W) in ((480, 640), (427, 640)):
+        tag = f"{H}x{W}"
+        x = torch.from_numpy(detgen.images(1, H, W, seed=21))
+        with torch.no_grad():
+            out = net(x)
+            preds = net.predict(out, mask_type="instance", size=(H, W), image_ids=[7], nms_type="hard")
+            logits_lo = net.predict(out, mask_type="semantic", size=None, return_logits=True)
+        d[f"{tag}_mask_proposals_last_sub"] = out["mask_proposals"].numpy()[:, -1, :, ::3, ::3]
+        d[f"{tag}_patch_tokens_sub"] = out["patch_tokens"].numpy()[:, ::3, ::3, ::4]
+        d[f"{tag}_logits_lo_sub"] = logits_lo.numpy()[:, :, ::2, ::2]
+        d[f"{tag}_n"] = len(preds)
+        if preds:
+            d[f"{tag}_masks"] = np.packbits(np.stack([p["segmentation"]["mask"] for p in preds]).astype(bool), axis=-1)
+            d[f"{tag}_score"] = np.array([p["score"] for p in preds], np.float64)
+            d[f"{tag}_cat"] = np.array([p["category_id"] for p in preds], np.int64)
+            d[f"{tag}_bbox"] = np.array([p["bbox"] for p in preds], np.float64)
+            d[f"{tag}_area"] = np.array([int(p["segmentation"]["mask"].sum()) for p in preds], np.int64)
+        with torch.no_grad():     # every candidate (no NMS): per-query class / score / area / box at the native resolution
+            allp = net.predict(out, mask_type="instance", size=(H, W), image_ids=[7], nms_type=None)
+        d[f"{tag}_all_n"] = len(allp)
+        d[f"{tag}_all_score"] = np.array([p["score"] for p in allp], np.float64)
+        d[f"{tag}_all_cat"] = np.array([p["category_id"] for p in allp], np.int64)
+        d[f"{tag}_all_bbox"] = np.array([p["bbox"] for p in allp], np.float64)
+        d[f"{tag}_all_area"] = np.array([int(p["segmentation"]["mask"].sum()) for p in allp], np.int64)
+        print("c3", tag, "preds", len(preds), "cats", sorted(set(p["category_id"] for p in preds)), "no-NMS candidates", len(allp))
+    np.savez_compressed(os.path.join(GOLD, "c3_vitb16.npz"), **d)
+
+
+A4_CFG = detgen.A4_TINY
+
+
+def gen_a4():
+    """build_model / convert_weights (clip_arch.py:566-627) through the real ZUTIS constructor (zutis.py:35-55): `clip.load`
+    hands back a CLIP carrying GENERIC fp32 weights (detgen.clip_full_state_dict); the constructor re-builds the model from
+    its state_dict, which rounds conv / Linear / attention / proj weights (and Linear biases) through fp16 and leaves
+    LayerNorm / class / positional embeddings in fp32, then casts back to fp32.  Stores the inferred architecture, per-key
+    fingerprints of the resulting encoder parameters and the forward outputs on a fixed input."""
+    cfg = A4_CFG
+    install_stubs(cfg)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for m in [k for k in sys.modules if k.startswith("networks") or k.startswith("utils")]:
+        del sys.modules[m]
+    import clip as clip_stub
+    from networks.clip_arch import CLIP
+    csd = {k: torch.from_numpy(v) for k, v in detgen.clip_full_state_dict(cfg).items()}
+
+    def load(name, device=None):
+        m = CLIP(embed_dim=cfg.embed_dim, image_resolution=cfg.patch * cfg.grid, vision_layers=cfg.layers, vision_width=cfg.width,
+                 vision_patch_size=cfg.patch, context_length=8, vocab_size=64, transformer_width=64, transformer_heads=1,
+                 transformer_layers=1).float()
+        missing, unexpected = m.load_state_dict(csd, strict=False)
+        assert not unexpected and set(missing) <= {"logit_scale"}, (missing, unexpected)
+        return m.eval(), None
+    clip_stub.load = load
+    from networks.zutis import ZUTIS
+    net = ZUTIS(categories=[f"c{i}" for i in range(7)], clip_arch="ViT-B/16", n_queries=cfg.n_queries,
+                n_decoder_layers=cfg.dec_layers, n_heads=cfg.dec_heads, device=torch.device("cpu"))
+    head = {k: torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items() if not k.startswith("encoder.")}
+    missing, unexpected = net.load_state_dict(head, strict=False)
+    assert not unexpected and all(k.startswith("encoder.") for k in missing)
+    net.text_embeddings = torch.from_numpy(detgen.text_embeddings(7, cfg.embed_dim))
+    net.eval().requires_grad_(False)
+    enc = net.encoder
+    d = {"arch": np.array([enc.width, enc.transformer.layers, enc.conv1.kernel_size[0], enc.input_resolution, enc.output_dim])}
+    for k, v in enc.state_dict().items():
+        a = v.numpy().astype(np.float64).reshape(-1)
+        d["fp_" + k] = np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[:8], [float(v.dtype == torch.float32)]])
+    x = torch.from_numpy(detgen.images(2, 80, 112))
+    with torch.no_grad():
+        tok, h, w = enc(x)
+        out = net(x)
+    d["enc_tokens"], d["mask_proposals"], d["patch_tokens"] = tok.numpy(), out["mask_proposals"].numpy(), out["patch_tokens"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "a4_build_model.npz"), **d)
+    print("a4", d["arch"], {k: v.shape for k, v in d.items() if not k.startswith("fp_")}, len([k for k in d if k.startswith("fp_")]), "keys")
+
+
 class _FakeCuda:
     """`clip.tokenize(texts).cuda()` in the reference loop: hand the CPU tensor back."""
     def __init__(self, t):
@@ -277,6 +361,12 @@ if __name__ == "__main__":
     if "--text-only" in sys.argv:
         gen_text()
         sys.exit(0)
+    if "--c3-only" in sys.argv:
+        gen_c3()
+        sys.exit(0)
+    if "--a4-only" in sys.argv:
+        gen_a4()
+        sys.exit(0)
     if "--selfmask-only" in sys.argv:
         gen_selfmask()
         sys.exit(0)
@@ -287,3 +377,5 @@ if __name__ == "__main__":
     gen_e2e("tiny", detgen.TINY, b=2, H=80, W=112, n_cat=7, size=(80, 112), full=True)
     gen_e2e("vitb16_336", detgen.VIT_B16, b=1, H=336, W=336, n_cat=81, size=(336, 336), full=False)
     gen_e2e("vitb32_224", detgen.VIT_B32, b=1, H=224, W=224, n_cat=81, size=(224, 224), full=False)
+    gen_c3()
+    gen_a4()

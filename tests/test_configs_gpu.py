@@ -1,0 +1,154 @@
+"""-m gpu: the configurations BASELINE.json names beyond C1 / C2, at their own shapes.
+
+  C3  ViT-B/16, batch 1, native-resolution COCO-like inputs, instance predict with hard NMS (coco20k_eval.py:241-268)
+      against outputs of the real reference (tests/golden/c3_vitb16.npz, oracle/gen_golden.py::gen_c3).
+  A4  build_model / convert_weights through the constructor (clip_arch.py:566-627, zutis.py:35-55): drop-in module built from
+      a generic-fp32 CLIP state_dict against the reference built from the same (tests/golden/a4_build_model.npz).
+  C5  full-depth CLIP ViT-L/14@336 encode_image (24 layers) against the oracle, and the extract_image_embeddings drop-in
+      (files -> dict -> pickle round trip, utils/extract_image_embeddings.py:21-86).
+"""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DROPIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin")
+
+
+def _dropin():
+    if DROPIN not in sys.path:
+        sys.path.insert(0, DROPIN)
+
+
+@pytest.mark.parametrize("precision,t_tok,t_mask,t_score,t_area", [("exact", 2e-5, 2e-4, 1e-4, 8), ("fast", 2.5e-4, 1e-3, 2e-3, 80)])
+@pytest.mark.parametrize("H,W", [(480, 640), (427, 640)])
+def test_c3_native_resolution_instance_predict(dev, golden_dir, H, W, precision, t_tok, t_mask, t_score, t_area):
+    from zutis_amd import detgen, rle
+    _dropin()
+    from networks.zutis import ZUTIS
+    cfg = detgen.VIT_B16
+    g = np.load(f"{golden_dir}/c3_vitb16.npz")
+    tag = f"{H}x{W}"
+    net = ZUTIS(categories=[f"c{i}" for i in range(81)], clip_arch="ViT-B/16", device=dev,
+                text_embeddings=torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim)))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items()}, strict=True)
+    net = net.to(dev).eval().requires_grad_(False)
+    net.precision = precision
+    x = torch.from_numpy(detgen.images(1, H, W, seed=21)).to(dev)
+    out = net(x)
+    mp, pt = out["mask_proposals"].cpu().numpy(), out["patch_tokens"].cpu().numpy()
+    assert np.abs(mp[:, -1, :, ::3, ::3] - g[f"{tag}_mask_proposals_last_sub"]).max() < t_mask
+    assert np.abs(pt[:, ::3, ::3, ::4] - g[f"{tag}_patch_tokens_sub"]).max() < t_tok
+    lo = net.predict(out, mask_type="semantic", size=None, return_logits=True).cpu().numpy()
+    assert np.abs(lo[:, :, ::2, ::2] - g[f"{tag}_logits_lo_sub"]).max() < t_tok
+    # every candidate, no NMS: class ids identical, scores / areas / boxes within what one threshold-crossing pixel can move
+    allp = net.predict(out, mask_type="instance", size=(H, W), image_ids=[7], nms_type=None)
+    assert len(allp) == int(g[f"{tag}_all_n"])
+    assert [p["category_id"] for p in allp] == list(g[f"{tag}_all_cat"])
+    assert np.abs(np.array([p["score"] for p in allp]) - g[f"{tag}_all_score"]).max() < t_score
+    areas = np.array([int(rle.decode(p["segmentation"]).sum()) for p in allp])
+    assert np.abs(areas - g[f"{tag}_all_area"]).max() <= t_area
+    assert np.abs(np.array([p["bbox"] for p in allp]) - g[f"{tag}_all_bbox"]).max() <= 2.0
+    # hard NMS, the evaluation's setting
+    preds = net.predict(out, mask_type="instance", size=(H, W), image_ids=[7], nms_type="hard")
+    assert len(preds) == int(g[f"{tag}_n"])
+    ref_masks = np.unpackbits(g[f"{tag}_masks"], axis=-1)[..., :W].astype(bool)
+    for j, p in enumerate(preds):
+        assert p["category_id"] == g[f"{tag}_cat"][j] and p["image_id"] == 7 and tuple(p["image_size"]) == (H, W)
+        assert abs(p["score"] - g[f"{tag}_score"][j]) < t_score
+        m = rle.decode(p["segmentation"]).astype(bool)
+        assert (m != ref_masks[j]).sum() <= t_area
+
+
+def test_a4_build_model_through_constructor(dev, golden_dir):
+    """Drop-in built from a generic fp32 CLIP state_dict: inferred architecture, fp16-rounded encoder parameters and forward
+    outputs equal those of the reference constructor (which calls build_model -> convert_weights -> .float())."""
+    from zutis_amd import detgen
+    _dropin()
+    from networks.zutis import ZUTIS
+    cfg = detgen.A4_TINY
+    g = np.load(f"{golden_dir}/a4_build_model.npz")
+    csd = {k: torch.from_numpy(v) for k, v in detgen.clip_full_state_dict(cfg).items()}
+    net = ZUTIS(categories=[f"c{i}" for i in range(7)], clip_arch="ViT-B/16", n_queries=cfg.n_queries, n_decoder_layers=cfg.dec_layers,
+                n_heads=cfg.dec_heads, device=dev, text_embeddings=torch.from_numpy(detgen.text_embeddings(7, cfg.embed_dim)),
+                clip_state_dict=csd)
+    head = {k: torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items() if not k.startswith("encoder.")}
+    missing, unexpected = net.load_state_dict(head, strict=False)
+    assert not unexpected and all(k.startswith("encoder.") for k in missing)
+    net = net.to(dev).eval().requires_grad_(False)
+    net.precision = "exact"
+    x = torch.from_numpy(detgen.images(2, 80, 112)).to(dev)
+    tok, h, w = net.forward_transformer_encoder(x)
+    out = net(x)
+    assert np.abs(tok.cpu().numpy() - g["enc_tokens"]).max() < 5e-5
+    assert np.abs(out["mask_proposals"].cpu().numpy() - g["mask_proposals"]).max() < 2e-4
+    assert np.abs(out["patch_tokens"].cpu().numpy() - g["patch_tokens"]).max() < 2e-5
+    # without the fp16 rounding of convert_weights the same inputs give visibly different tokens (the test has teeth)
+    net2 = ZUTIS(categories=[f"c{i}" for i in range(7)], clip_arch="ViT-B/16", n_queries=cfg.n_queries, n_decoder_layers=cfg.dec_layers,
+                 n_heads=cfg.dec_heads, device=dev, text_embeddings=torch.from_numpy(detgen.text_embeddings(7, cfg.embed_dim)),
+                 vision_config=(cfg.width, cfg.layers, cfg.patch, cfg.grid, cfg.embed_dim))
+    net2.load_state_dict({**head, **{"encoder." + k[len("visual."):]: v for k, v in csd.items() if k.startswith("visual.")}}, strict=True)
+    net2 = net2.to(dev).eval().requires_grad_(False)
+    net2.precision = "exact"
+    tok2, _, _ = net2.forward_transformer_encoder(x)
+    assert np.abs(tok2.cpu().numpy() - g["enc_tokens"]).max() > 2e-4
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fast", 1e-3)])
+def test_c5_vit_l14_336_full_depth(dev, precision, tol):
+    """CLIP ViT-L/14@336 `encode_image`, all 24 layers (D = 1024, 16 heads, T = 577, conv K = 588 padded to 640), batch 2,
+    against the oracle's restatement of the original CLIP forward (clip_arch.py:413-431,531-532; parity unpinned by the
+    reference: third-party `clip` is absent)."""
+    from zutis_amd import detgen
+    from zutis_amd.engine import ClipImageEncoder
+    from oracle import zutis_ref as O
+    cfg = detgen.ZutisConfig(width=1024, layers=24, patch=14, grid=24, embed_dim=768)
+    sd = {k: v for k, v in detgen.zutis_state_dict(cfg, seed=5).items() if k.startswith("encoder.")}
+    x = torch.from_numpy(detgen.images(2, 336, 336, seed=5))
+    with torch.no_grad():
+        ref = O.clip_encode_image(O.to_torch_params(sd), x, cfg.patch).numpy()
+    enc = ClipImageEncoder({k.replace("encoder.", "visual."): torch.from_numpy(v).to(dev) for k, v in sd.items()}, cfg.patch,
+                           precision=precision)
+    got = enc.encode_image(x.to(dev)).cpu().numpy()
+    assert got.shape == (2, 768) and np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
+    err = float(np.abs(got - ref).max())
+    print(f"ViT-L/14@336 24 layers [{precision}]: max |err| {err:.2e} on unit-norm embeddings")
+    assert err < tol
+
+
+def test_extract_image_embeddings_dropin_files_and_pickle(dev, tmp_path):
+    """utils/extract_image_embeddings.py:21-86 call surface: image files in, {basename: FloatTensor[E]} out, the periodic
+    pickle holds the same dict; pre-processing follows torchvision's Resize/CenterCrop integer conventions."""
+    from PIL import Image
+    from zutis_amd import detgen
+    from oracle import zutis_ref as O
+    _dropin()
+    from utils.extract_image_embeddings import extract_image_embeddings, resize_crop_box, _preprocess
+    cfg = detgen.ZutisConfig(width=128, layers=2, patch=14, grid=3, embed_dim=64)       # 42 px tower
+    sd = {k.replace("encoder.", "visual."): torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items() if k.startswith("encoder.")}
+    rng = np.random.default_rng(0)
+    paths = []
+    for i, (w, h) in enumerate([(64, 43), (50, 75), (42, 42), (91, 60), (47, 53)]):
+        p = tmp_path / f"img_{i}.png"
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+    fp = str(tmp_path / "emb.pkl")
+    out = extract_image_embeddings(paths, model_name="ViT-B/16", fp=fp, device=dev, batch_size=2, state_dict=sd, precision="exact")
+    assert sorted(out) == sorted(os.path.basename(p) for p in paths)
+    xs = torch.from_numpy(np.stack([_preprocess(p, 42) for p in paths]))
+    with torch.no_grad():
+        ref = O.clip_encode_image(O.to_torch_params({k.replace("visual.", "encoder."): v for k, v in sd.items()}), xs, cfg.patch).numpy()
+    for p, r in zip(paths, ref):
+        e = out[os.path.basename(p)]
+        assert isinstance(e, torch.Tensor) and e.dtype == torch.float32 and e.device.type == "cpu" and e.shape == (64,)
+        assert np.abs(e.numpy() - r).max() < 2e-5
+    disk = pickle.load(open(fp, "rb"))                                       # the wire format index_dataset.py:142,157 reads
+    assert sorted(disk) == sorted(out) and all(torch.equal(disk[k], out[k]) for k in out)
+    assert resize_crop_box(640, 427, 224) == ((335, 224), (56, 0))          # torchvision: int(224*640/427) = 335, round(55.5) = 56
+    assert resize_crop_box(427, 640, 224) == ((224, 335), (0, 56))
+    assert resize_crop_box(500, 375, 336) == ((448, 336), (56, 0))

@@ -6,24 +6,30 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 1e-3   # north_star: fp32 logits within 1e-3
-MASK_TOL = 2e-3    # sigmoid mask proposals (fp16 MFMA operands, fp32 accumulate)
+# north_star: fp32 logits within 1e-3.  Tolerances per engine precision (zutis_amd/engine.py): the default "fast" engine is
+# held to a quarter of that on logits / unit-norm tokens and to 1e-3 on the sigmoid mask proposals; "exact" (every
+# contraction in the reference-equivalent x3 mode) to fp32-reordering-class errors.
+LOGIT_TOL = 2.5e-4
+MASK_TOL = 1e-3
+TOLS = {"fast": (LOGIT_TOL, MASK_TOL, 0.995), "exact": (2e-5, 2e-4, 0.9995)}
 
 
-def _engine(cfg, dev):
+def _engine(cfg, dev, precision="fast"):
     from zutis_amd import detgen
     from zutis_amd.engine import ZutisEngine
     P = {k: torch.from_numpy(v).to(dev) for k, v in detgen.zutis_state_dict(cfg).items()}
-    return ZutisEngine(P, cfg.patch, cfg.dec_heads)
+    return ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
 
 
+@pytest.mark.parametrize("precision", ["fast", "exact"])
 @pytest.mark.parametrize("tag,cfgname", [("tiny", "TINY"), ("vitb32_224", "VIT_B32"), ("vitb16_336", "VIT_B16")])
-def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname):
+def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname, precision):
     from zutis_amd import detgen
     cfg = getattr(detgen, cfgname)
     g = np.load(f"{golden_dir}/e2e_{tag}.npz")
     b, H, W, n = int(g["b"]), int(g["H"]), int(g["W"]), int(g["n_cat"])
-    eng = _engine(cfg, dev)
+    eng = _engine(cfg, dev, precision)
+    LOGIT_TOL, MASK_TOL, MIN_AGREE = TOLS[precision]
     x = torch.from_numpy(detgen.images(b, H, W)).to(dev)
     text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
     out = eng.forward(x)
@@ -32,7 +38,7 @@ def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname):
     assert err < LOGIT_TOL, err
     labels = eng.predict_semantic(out["patch_tokens"], text, tuple(g["size"])).cpu().numpy()
     agree = (labels == g["labels"]).mean()
-    assert agree > 0.995, agree
+    assert agree > MIN_AGREE, agree
     mp, pt = out["mask_proposals"].cpu().numpy(), out["patch_tokens"].cpu().numpy()
     assert mp.min() >= 0 and mp.max() <= 1
     if "mask_proposals" in g:
@@ -43,7 +49,7 @@ def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname):
     else:
         assert np.abs(mp[:, :, ::9, ::3, ::3] - g["mask_proposals_sub"]).max() < MASK_TOL
         assert np.abs(pt[:, ::3, ::3, ::4] - g["patch_tokens_sub"]).max() < LOGIT_TOL
-    print(f"{tag}: logits maxerr {err:.2e}, label agreement {agree:.5f}")
+    print(f"{tag}[{precision}]: logits maxerr {err:.2e}, label agreement {agree:.5f}")
 
 
 def test_engine_vs_oracle_ragged_batch(dev):
@@ -99,7 +105,8 @@ def _dropin_zutis(cfg, dev, n_cat):
     return net.to(dev).eval()
 
 
-def test_dropin_module_matches_reference_golden(dev, golden_dir):
+@pytest.mark.parametrize("precision,t_score,t_pix", [("fast", 2e-2, 1e-2), ("exact", 2e-3, 5e-4)])
+def test_dropin_module_matches_reference_golden(dev, golden_dir, precision, t_score, t_pix):
     """The reference's call surface (ZUTIS.forward / .predict semantic + instance, all NMS types) on the HIP path,
     against the reference's own outputs for the tiny config."""
     from zutis_amd import detgen
@@ -107,6 +114,8 @@ def test_dropin_module_matches_reference_golden(dev, golden_dir):
     g = np.load(f"{golden_dir}/e2e_tiny.npz")
     b, H, W, n = int(g["b"]), int(g["H"]), int(g["W"]), int(g["n_cat"])
     net = _dropin_zutis(cfg, dev, n)
+    net.precision = precision
+    LOGIT_TOL = TOLS[precision][0]
     assert len(net.state_dict()) == len(detgen.zutis_param_shapes(cfg))
     x = torch.from_numpy(detgen.images(b, H, W)).to(dev)
     with pytest.raises(NotImplementedError):
@@ -126,11 +135,11 @@ def test_dropin_module_matches_reference_golden(dev, golden_dir):
         from zutis_amd import rle
         for j, p in enumerate(preds):
             assert p["image_id"] == g[f"inst_{key}_img"][j] and p["category_id"] == g[f"inst_{key}_cat"][j]
-            # score = mean(p inside p>0.5) * class prob: one low-res pixel crossing 0.5 (fp16-MFMA noise ~3e-4) moves it by
-            # ~1/mask_size; the kernel itself is checked to 1e-6 on identical inputs in test_instance_kernels_vs_oracle_exact_inputs
-            assert abs(p["score"] - g[f"inst_{key}_score"][j]) < 2e-2
+            # score = mean(p inside p>0.5) * class prob: one low-res pixel crossing 0.5 moves it by ~1/mask_size (a 10x14 mask
+            # here); the kernel itself is checked to 1e-6 on identical inputs in test_instance_kernels_vs_oracle_exact_inputs
+            assert abs(p["score"] - g[f"inst_{key}_score"][j]) < t_score
             m = rle.decode(p["segmentation"]).astype(bool)
-            assert (m != ref_masks[j]).mean() < 1e-2          # masks come from fp16-MFMA proposals thresholded at 0.5
+            assert (m != ref_masks[j]).mean() <= t_pix        # proposals thresholded at 0.5
             assert np.abs(np.array(p["bbox"]) - g[f"inst_{key}_bbox"][j]).max() <= 1.0
             assert tuple(p["image_size"]) == (H, W)
 
@@ -159,12 +168,13 @@ def test_instance_kernels_vs_oracle_exact_inputs(dev, golden_dir):
             assert iou[i, j] == O.compute_iou(up[0, i], up[0, j])
 
 
-def test_selfmask_engine_vs_reference_golden(dev, golden_dir):
+@pytest.mark.parametrize("precision,t_obj,t_mask,t_dts", [("fast", 2e-3, 5e-3, 5e-3), ("exact", 5e-5, 2e-4, 2e-4)])
+def test_selfmask_engine_vs_reference_golden(dev, golden_dir, precision, t_obj, t_mask, t_dts):
     """SelfMask (DINO ViT-S/8 + decoder + objectness) on the HIP path against the reference's outputs."""
     from zutis_amd import detgen
     from zutis_amd.engine import SelfMaskEngine
     g = np.load(f"{golden_dir}/selfmask.npz")
-    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()})
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()}, precision=precision)
     for tag in ("small", "full"):
         b, H, W = (int(v) for v in g[f"{tag}_shape"])
         x = torch.from_numpy(detgen.images(b, H, W, seed=11)).to(dev)
@@ -172,13 +182,15 @@ def test_selfmask_engine_vs_reference_golden(dev, golden_dir):
         mp = out["mask_pred"].cpu().numpy()
         if tag == "full":
             mp = mp[:, :, :, ::2, ::2]
-        assert np.abs(out["objectness"].cpu().numpy() - g[f"{tag}_objectness"]).max() < 2e-3
-        assert np.abs(mp - g[f"{tag}_mask_pred"]).max() < 2e-2      # un-normalised queries: |logit| ~ 30, fp16 operands => 1e-3 relative on the logit
+        e_obj = np.abs(out["objectness"].cpu().numpy() - g[f"{tag}_objectness"]).max()
+        e_mask = np.abs(mp - g[f"{tag}_mask_pred"]).max()     # un-normalised queries: |logit| ~ 30
+        print(f"selfmask {tag}[{precision}]: objectness {e_obj:.2e} mask_pred {e_mask:.2e}")
+        assert e_obj < t_obj and e_mask < t_mask
         inf = eng.forward(x, inference=True)
         ref = np.unpackbits(g[f"{tag}_dts"], axis=-1)[..., :W].astype(bool)
         got = inf["dts"].cpu().numpy().astype(bool)
         assert got.shape == (b, H, W)
-        assert (got != ref).mean() < 5e-3, (got != ref).mean()
+        assert (got != ref).mean() <= t_dts, (got != ref).mean()
 
 
 def test_selfmask_dropin_module(dev, golden_dir):
@@ -280,6 +292,36 @@ def test_forward_graphed_matches_eager(dev):
             assert torch.equal(a["mask_proposals"], b["mask_proposals"]) and torch.equal(a["patch_tokens"], b["patch_tokens"])
 
 
+def test_forward_graphed_shape_a_b_a_and_fork(dev):
+    """A graph bakes in pointers to its shape's scratch buffers.  The engine's buffer cache drops a name's buffers when
+    another shape arrives, so shape A, then B, then A again must not replay A into freed memory: between the two A
+    replays a pile of fresh tensors is allocated (they would land in the freed blocks) and must survive untouched.
+    fork() must not inherit the parent's captured graphs."""
+    from zutis_amd import detgen
+    cfg = detgen.TINY
+    eng = _engine(cfg, dev)
+    xa = torch.from_numpy(detgen.images(1, 80, 112, seed=3)).to(dev)
+    xb = torch.from_numpy(detgen.images(1, 96, 64, seed=4)).to(dev)
+    ref_a = {k: v.clone() for k, v in eng.forward(xa).items()}
+    ref_b = {k: v.clone() for k, v in eng.forward(xb).items()}
+    ga = eng.forward_graphed(xa)
+    assert torch.equal(ga["patch_tokens"], ref_a["patch_tokens"])
+    gb = eng.forward_graphed(xb)                         # evicts shape A's buffers from the cache
+    assert torch.equal(gb["patch_tokens"], ref_b["patch_tokens"])
+    canaries = [torch.full((1 << 16,), float(i), device=dev) for i in range(64)]   # occupy whatever was freed
+    ga2 = eng.forward_graphed(xa)
+    torch.cuda.synchronize()
+    assert torch.equal(ga2["patch_tokens"], ref_a["patch_tokens"]) and torch.equal(ga2["mask_proposals"], ref_a["mask_proposals"])
+    assert all(bool((c == float(i)).all()) for i, c in enumerate(canaries))
+    f = eng.fork()
+    assert not any(isinstance(k, tuple) and k and k[0] == "graph" for k in f._geo)
+    assert torch.equal(f.forward(xa)["patch_tokens"], ref_a["patch_tokens"])
+    # a parameter update invalidates the captured graph (it holds the old packed weights)
+    with torch.no_grad():
+        eng.params["encoder.proj"].mul_(-1.0)
+    assert not torch.equal(eng.forward_graphed(xa)["patch_tokens"], ref_a["patch_tokens"])
+
+
 def test_batch_invariance_full_size(dev):
     """Size-independent property at the BASELINE geometry (ViT-B/16 @336): images are independent, so image i's outputs
     are BITWISE the same whether it is evaluated alone or inside a batch (every reduction runs over K / keys / one image
@@ -300,6 +342,19 @@ def test_batch_invariance_full_size(dev):
     pt = full["patch_tokens"]
     assert (pt.norm(dim=-1) - 1).abs().max().item() < 1e-5
     assert 0 <= full["mask_proposals"].min().item() and full["mask_proposals"].max().item() <= 1
+
+
+def test_launch_plan_refuses_stale_weights(dev):
+    from zutis_amd import detgen, _lib
+    cfg = detgen.TINY
+    eng = _engine(cfg, dev)
+    text = torch.from_numpy(detgen.text_embeddings(5, cfg.embed_dim)).to(dev)
+    p = eng.build_plan((1, 3, 64, 64), text, (64, 64))
+    eng.run_plan(p, torch.from_numpy(detgen.images(1, 64, 64)).to(dev))
+    with torch.no_grad():
+        eng.params["encoder.proj"].mul_(-1.0)
+    with pytest.raises(_lib.ZutisHipError, match="parameters changed"):
+        eng.run_plan(p)
 
 
 def test_launch_plan_replay_matches_eager(dev):

@@ -159,3 +159,64 @@ def test_text_oracle_matches_reference(golden_dir, tag, cfgname, n):
             pe = O.prompt_ensemble(P, toks).numpy()
         assert np.abs(pe - g["tiny_prompt_ensemble"]).max() < 1e-6
         assert np.abs(np.linalg.norm(pe, axis=1) - 1).max() < 1e-6
+
+
+def test_a4_build_model_convert_weights_vs_reference(golden_dir):
+    """build_model / convert_weights (clip_arch.py:566-627) as executed by the reference constructor: architecture inferred
+    from the state_dict keys, conv / Linear / attention / proj values rounded through fp16, LayerNorm + class / positional
+    embeddings untouched.  The drop-in's restatement (convert_weight_like_reference + its key-based inference) must
+    reproduce the reference's resulting encoder parameters bit for bit, and the oracle forward on them its tokens."""
+    import os, sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    from networks.zutis import ZUTIS
+    cfg = detgen.A4_TINY
+    g = np.load(f"{golden_dir}/a4_build_model.npz")
+    csd = {k: torch.from_numpy(v) for k, v in detgen.clip_full_state_dict(cfg).items()}
+    net = ZUTIS(categories=[f"c{i}" for i in range(7)], clip_arch="ViT-B/16", n_queries=cfg.n_queries, n_decoder_layers=cfg.dec_layers,
+                n_heads=cfg.dec_heads, device=torch.device("cpu"), text_embeddings=torch.from_numpy(detgen.text_embeddings(7, cfg.embed_dim)),
+                clip_state_dict=csd)
+    enc = net.encoder
+    assert [enc.width, enc.transformer.layers, enc.patch_size, enc.input_resolution, enc.output_dim] == list(g["arch"])
+    sd = enc.state_dict()
+    assert sorted("fp_" + k for k in sd) == sorted(k for k in g.files if k.startswith("fp_"))
+    n_rounded = 0
+    for k, v in sd.items():
+        a = v.numpy().astype(np.float64).reshape(-1)
+        fp = np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[:8], [1.0]])
+        assert np.array_equal(fp, g["fp_" + k]), k
+        n_rounded += int(not torch.equal(v, csd["visual." + k].float()))
+    assert n_rounded == 2 + 8 * cfg.layers            # conv1, proj, and per block 4 weights + 4 biases; LN / embeddings untouched
+    P = {"encoder." + k: v for k, v in sd.items()}
+    P.update({k: torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items() if not k.startswith("encoder.")})
+    x = torch.from_numpy(detgen.images(2, 80, 112))
+    with torch.no_grad():
+        tok, _, _ = O.clip_vit_forward(P, x, cfg.patch)
+        out = O.zutis_forward(P, x, cfg.patch, cfg.dec_heads)
+    assert np.abs(tok.numpy() - g["enc_tokens"]).max() < 2e-5
+    assert np.abs(out["mask_proposals"].numpy() - g["mask_proposals"]).max() < 2e-6
+    assert np.abs(out["patch_tokens"].numpy() - g["patch_tokens"]).max() < 2e-6
+
+
+def test_c3_oracle_matches_reference_at_native_resolution(golden_dir):
+    """Config 3's shape (ViT-B/16, 480x640, batch 1): oracle forward + instance scoring vs the reference's outputs."""
+    cfg = detgen.VIT_B16
+    g = np.load(f"{golden_dir}/c3_vitb16.npz")
+    H, W = 480, 640
+    P = O.to_torch_params(detgen.zutis_state_dict(cfg))
+    x = torch.from_numpy(detgen.images(1, H, W, seed=21))
+    text = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim))
+    with torch.no_grad():
+        out = O.zutis_forward(P, x, cfg.patch, cfg.dec_heads)
+    mp, pt = out["mask_proposals"].numpy(), out["patch_tokens"].numpy()
+    assert np.abs(mp[:, -1, :, ::3, ::3] - g["480x640_mask_proposals_last_sub"]).max() < 5e-6
+    assert np.abs(pt[:, ::3, ::3, ::4] - g["480x640_patch_tokens_sub"]).max() < 2e-6
+    binary, cats, scores = O.instance_scores(out["mask_proposals"], out["patch_tokens"], text)
+    keep = cats[0] != 0
+    assert list(cats[0][keep]) == list(g["480x640_all_cat"])
+    assert np.abs(scores[0][keep] - g["480x640_all_score"]).max() < 1e-5
+    up = R.bilinear_nchw(mp[:, -1], H, W) > 0.5
+    assert np.abs(up[0][keep].reshape(keep.sum(), -1).sum(1) - g["480x640_all_area"]).max() <= 2
+    sel = O.mask_nms(up[0], scores[0], cats[0], "hard")
+    assert len(sel) == int(g["480x640_n"]) and [c for c, _, _ in sel] == list(g["480x640_cat"])

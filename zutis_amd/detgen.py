@@ -79,6 +79,10 @@ TINY = ZutisConfig(width=192, layers=2, patch=16, grid=4, embed_dim=64, n_querie
                    dec_layers=2, dec_heads=2, dec_ff=2048, ffn_hidden=256)
 
 
+# config of the build_model / convert_weights fixture (tests/golden/a4_build_model.npz): dh = 64 in encoder and decoder
+A4_TINY = ZutisConfig(width=128, layers=2, patch=16, grid=4, embed_dim=64, n_queries=5, dec_layers=2, dec_heads=2)
+
+
 def zutis_param_shapes(cfg: ZutisConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], float, float]]":
     """name -> (shape, std, mean) in reference state_dict order-insensitive form."""
     D, L = cfg.width, cfg.layers
@@ -267,6 +271,20 @@ def clip_text_param_shapes(cfg: ClipTextConfig):
 
 def clip_text_state_dict(cfg: ClipTextConfig, seed: int = 2468):
     return OrderedDict((k, det_normal("text." + k, shp, std, mean, seed)) for k, (shp, std, mean) in clip_text_param_shapes(cfg).items())
+
+
+def clip_full_state_dict(cfg: ZutisConfig, seed: int = 97) -> "OrderedDict[str, np.ndarray]":
+    """A complete CLIP state_dict in the third-party package's key layout (visual.* + text tower) carrying GENERIC fp32
+    values (not fp16-representable): the input of build_model / convert_weights (clip_arch.py:566-627).  The text tower is
+    minimal (ctx 8, vocab 64, width 64, 1 layer) — only its key set matters to build_model's architecture inference."""
+    sd = OrderedDict()
+    for k, (shp, std, mean) in zutis_param_shapes(cfg).items():
+        if k.startswith("encoder."):
+            sd["visual." + k[len("encoder."):]] = det_normal("clipfull." + k, shp, std, mean, seed)
+    tc = ClipTextConfig(context_length=8, vocab_size=64, width=64, layers=1, embed_dim=cfg.embed_dim)
+    for k, (shp, std, mean) in clip_text_param_shapes(tc).items():
+        sd[k] = det_normal("clipfull.text." + k, shp, std, mean, seed)
+    return sd
 
 
 def text_tokens(n: int, cfg: ClipTextConfig, seed: int = 11) -> np.ndarray:

@@ -95,10 +95,14 @@ class SelfMask(nn.Module):
         self.use_binary_classifier = use_binary_classifier
         self.scale_factor = scale_factor
         self._engine = None
+        self.precision: str = "fast"             # "fast" | "exact" | "f16" (zutis_amd.engine)
 
     def _get_engine(self) -> SelfMaskEngine:
+        if self._engine is not None and self._engine.precision != self.precision:
+            self._engine = None
         if self._engine is None:
-            self._engine = SelfMaskEngine(dict(self.named_parameters()), self.encoder.patch_size, self.encoder.n_heads)
+            self._engine = SelfMaskEngine(dict(self.named_parameters()), self.encoder.patch_size, self.encoder.n_heads,
+                                          precision=self.precision)
         return self._engine
 
     def _apply(self, fn, *args, **kwargs):

@@ -41,6 +41,18 @@ _VIT_ARCHS = {
 }
 
 
+def convert_weight_like_reference(key: str, value: torch.Tensor) -> torch.Tensor:
+    """What the reference constructor does to one CLIP parameter: `build_model` loads the state_dict into a model whose
+    conv / Linear weights AND biases, attention in_proj weight / bias and `proj` / `text_projection` were converted to fp16
+    (convert_weights, clip_arch.py:566-587, applied before load_state_dict at :625-626), so those values are rounded to fp16;
+    LayerNorm parameters, class_embedding and positional_embedding stay fp32.  `.float()` follows (zutis.py:55)."""
+    v = value.detach().float()
+    name = key.rsplit(".", 1)[-1]
+    is_ln = ".ln_" in "." + key          # ln_pre / ln_post / ln_1 / ln_2 (LayerNorm is not in convert_weights' list)
+    rounded = (not is_ln) and (name in ("weight", "bias", "in_proj_weight", "in_proj_bias", "proj", "text_projection"))
+    return v.half().float() if rounded else v
+
+
 class MLP(nn.Module):
     """Parameter container with the reference's keys `layers.{i}.weight/bias` (networks/zutis.py:535-549)."""
 
@@ -174,7 +186,7 @@ class ZUTIS(nn.Module):
             width, layers, patch, grid, embed = _VIT_ARCHS[arch]
         self.encoder = VisionTransformer(patch * grid, patch, width, layers, width // 64, embed)
         if sd is not None:                                                                 # clip_arch.py:620-627 + zutis.py:55
-            vis = {k[len("visual."):]: v.float() for k, v in sd.items() if k.startswith("visual.")}
+            vis = {k[len("visual."):]: convert_weight_like_reference(k, v) for k, v in sd.items() if k.startswith("visual.")}
             self.encoder.load_state_dict(vis, strict=True)
         self.encoder.requires_grad_(True)
 
@@ -190,12 +202,17 @@ class ZUTIS(nn.Module):
         self.clip_arch: str = clip_arch
         self.encoder_type: str = encoder_type
         self._engine: Optional[ZutisEngine] = None
+        # "fast" | "exact" | "f16" (zutis_amd.engine): exact = every contraction in the reference-equivalent f16x3 mode
+        self.precision: str = "fast"
         self.use_hip_graph: bool = False       # opt-in: forward() of batches <= 4 replays a hipGraph captured per input shape
 
     # ------------------------------------------------------------------ plumbing
     def _get_engine(self) -> ZutisEngine:
+        if self._engine is not None and self._engine.precision != self.precision:
+            self._engine = None                  # precision switched after construction
         if self._engine is None:
-            self._engine = ZutisEngine(dict(self.named_parameters()), self.encoder.patch_size, self.n_heads)
+            self._engine = ZutisEngine(dict(self.named_parameters()), self.encoder.patch_size, self.n_heads,
+                                       precision=self.precision)
         return self._engine
 
     def _apply(self, fn, *args, **kwargs):

@@ -51,6 +51,7 @@ def extract_image_embeddings(
         n_workers: int = 16,
         *,
         state_dict: Optional[dict] = None,
+        precision: str = "fast",
 ) -> Dict[str, torch.Tensor]:
     if "ViT" not in model_name:
         raise NotImplementedError(f"{model_name}: only the CLIP-ViT towers are on the MI355X hot path")
@@ -60,7 +61,7 @@ def extract_image_embeddings(
         state_dict = model.state_dict()
     vis = {k: v.float().to(device) for k, v in state_dict.items() if k.startswith("visual.")}
     patch = vis["visual.conv1.weight"].shape[-1]
-    enc = ClipImageEncoder(vis, patch, prefix="visual.")
+    enc = ClipImageEncoder(vis, patch, prefix="visual.", precision=precision)
     n_px = patch * enc.grid
     out: Dict[str, torch.Tensor] = {}
     for i in range(0, len(p_images), batch_size):
