@@ -68,21 +68,21 @@ int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void
 
 /* Flash attention: O = softmax(scale * Q K^T) V per (image, head); Q [Tq, heads*dh] rows with stride ldq, etc.
  * f16 in/out, fp32 softmax/accumulate; head_dim in {64, 96}.
- * planeQ / planeK != 0 (both or neither): Q and K are split pairs and the scores are Kh.Qh + Kl.Qh + Kh.Ql (fp32-class
- * exponents; P.V stays fp16 x fp16).  planeO != 0: O is written as a split pair.
+ * planeQ / planeK / planeV != 0 (all or none): Q, K, V are split pairs; scores are Kh.Qh + Kl.Qh + Kh.Ql and the
+ * probabilities are split in registers, O += Vh.Ph + Vl.Ph + Vh.Pl (fp32-class).  planeO != 0: O is written as a split pair.
  * Replaces nn.MultiheadAttention core at clip_arch.py:314-316, transformer.py:272-286,
  * selfmask/vision_transformer.py:110-133 (which materialises [B,heads,T,T]). */
 int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                      const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                      int batch, int heads, int Tq, int Tk, int head_dim, float scale,
-                     long planeQ, long planeK, long planeO, zh_stream_t stream);
+                     long planeQ, long planeK, long planeV, long planeO, zh_stream_t stream);
 
 /* The same under CLIP's causal mask (build_attention_mask, clip_arch.py:525-531: -inf above the diagonal), Tq = Tk = T:
  * the text tower's resblocks (clip_arch.py:534-541). */
 int zh_attention_causal_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                             const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                             int batch, int heads, int T, int head_dim, float scale,
-                            long planeQ, long planeK, long planeO, zh_stream_t stream);
+                            long planeQ, long planeK, long planeV, long planeO, zh_stream_t stream);
 
 /* Text tower glue.  x = token_embedding(text) + positional_embedding (clip_arch.py:535-537): tokens int64 [n,ctx],
  * table f32 [vocab,D], pos f32 [ctx,D] -> out f32 [n*ctx, D]. */
@@ -217,6 +217,15 @@ int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8,
  * (chunk offset); ties are broken by ascending column.  Output rows have stride out_ld >= k. */
 int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, const long long* idx_map, long long idx_add,
                  long long* idx_out, float* val_out, long out_ld, zh_stream_t stream);
+
+/* Greedy per-category mask NMS on the device: networks/zutis.py:211-299 (copy: coco20k_eval.py:54-136).  inter / uni int32
+ * [B,Q,Q] from zh_mask_iou_counts (IoU = inter / (uni + 1e-7) in float64 = utils/iou.py:30-32), scores f32 [B,Q], category_ids
+ * int64 [B,Q].  nms_type 0 hard | 1 linear | 2 gaussian; the reference's constants are nms_threshold 0.3, sigma 0.5,
+ * score_threshold 0.001.  Output per image, in the reference's emission order (category ascending, 0 skipped, then selection
+ * order; empty masks skipped): out_index int32 [B,Q], out_score f64 [B,Q], out_category int64 [B,Q], out_count int32 [B]. */
+int zh_mask_nms(const int* inter, const int* uni, const float* scores, const long long* category_ids, int B, int Q,
+                int nms_type, double nms_threshold, double sigma, double score_threshold,
+                int* out_index, double* out_score, long long* out_category, int* out_count, zh_stream_t stream);
 
 /* Device-side run extraction for COCO RLE + boxes + areas of selected masks (masks u8 [n,H,W] row-major; sel int32
  * [n_sel] mask indices): positions int32 [n_sel, max_runs] = column-major pixel indices where the value changes;

@@ -391,3 +391,57 @@ def test_retrieval_shard_merge_equals_unsharded(dev):
         cand_i.append(pi); cand_v.append(pv)
     mi, mv = retrieval.merge_topk(torch.cat(cand_i, 1), torch.cat(cand_v, 1), k)
     assert torch.equal(mi, ref_i) and torch.equal(mv, ref_v)
+
+
+def test_device_rle_matches_hand_derived_vectors(dev, golden_dir):
+    """Device run extraction (zh_mask_runs) + string packing reproduce the hand-derived COCO RLE vectors."""
+    import json
+    from zutis_amd.engine import ZutisEngine
+    vecs = json.load(open(f"{golden_dir}/rle_vectors.json"))["vectors"]
+    for v in vecs:
+        h, w = v["size"]
+        flat = np.zeros(h * w, np.uint8)
+        pos, val = 0, 0
+        for r in v["runs_colmajor"]:
+            flat[pos:pos + r] = val; pos += r; val ^= 1
+        m = flat.reshape((h, w), order="F")
+        rles, boxes, areas = ZutisEngine.encode_masks(None, torch.from_numpy(np.ascontiguousarray(m[None])).to(dev), np.array([0], np.int32))
+        assert rles[0]["counts"] == v["counts"].encode("ascii") and rles[0]["size"] == v["size"], v["name"]
+        assert areas[0] == int(m.sum())
+
+
+@pytest.mark.parametrize("nms_type", ["hard", "linear", "gaussian"])
+def test_device_mask_nms_matches_reference_control_flow(dev, nms_type):
+    """zh_mask_nms (one workgroup per image) against the oracle's restatement of ZUTIS.non_maximum_suppression
+    (zutis.py:211-299) on random overlapping masks: same (category, query) emission order; scores equal (hard: exactly —
+    only x1 / x0 products; linear / gaussian: float64 arithmetic, 1e-12)."""
+    from zutis_amd import ops
+    from zutis_amd.engine import ZutisEngine
+    from oracle import zutis_ref as O
+    rng = np.random.default_rng(5)
+    B, Q, H, W = 3, 100, 48, 64
+    masks = np.zeros((B, Q, H, W), np.uint8)
+    for b in range(B):
+        for q in range(Q):
+            if q % 17 == 3:
+                continue                                              # empty masks: never emitted
+            y0, x0 = rng.integers(0, H - 8), rng.integers(0, W - 8)
+            hh, ww = rng.integers(4, 24), rng.integers(4, 32)
+            masks[b, q, y0:y0 + hh, x0:x0 + ww] = 1
+        masks[b, 10] = masks[b, 11]                                   # identical masks: IoU exactly 1
+    scores = rng.random((B, Q)).astype(np.float32) * 0.9 + 0.05
+    scores[:, 20] = 0.0009                                            # below the keep threshold once multiplied
+    cats = rng.integers(0, 6, (B, Q)).astype(np.int64)                # class 0 = background: skipped
+    cats[1] = 2                                                       # one image with a single crowded class
+    eng_kept = ZutisEngine.instance_nms(None, torch.from_numpy(masks).to(dev), torch.from_numpy(scores).to(dev),
+                                        torch.from_numpy(cats).to(dev), nms_type)
+    ref = []
+    for b in range(B):
+        ref += [(b, c, q, s) for (c, q, s) in O.mask_nms(masks[b].astype(bool), scores[b], cats[b], nms_type)]
+    assert [(b, c, q) for b, c, q, _ in eng_kept] == [(b, c, q) for b, c, q, _ in ref]
+    got_s, ref_s = np.array([s for *_, s in eng_kept]), np.array([s for *_, s in ref])
+    if nms_type == "hard":
+        assert np.array_equal(got_s, ref_s)
+    else:
+        assert np.abs(got_s - ref_s).max() < 1e-12
+    assert len(eng_kept) > 20

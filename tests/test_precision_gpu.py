@@ -180,19 +180,19 @@ def test_split_producers_write_hi_plus_lo(dev):
 
 @pytest.mark.parametrize("dh,heads,Tq,Tk,causal", [(64, 3, 442, 442, False), (96, 2, 100, 1764, False), (64, 2, 77, 77, True), (64, 1, 130, 700, False)])
 def test_attention_x3_scores(dev, dh, heads, Tq, Tk, causal):
-    """Split-pair scores: large, sharply peaked logits (|s| up to ~60) where fp16 operand rounding moves the softmax by ~1e-2
-    but the x3 form stays at the fp16-P/V floor."""
+    """Split-pair attention: large, sharply peaked logits (|s| up to ~60) where fp16 operand rounding moves the softmax by
+    ~1e-2; the x3 form (split scores AND split P.V) stays at fp32-class error against float64."""
     from zutis_amd import ops
     from zutis_amd.ops import Act
     B, D = 2, heads * dh
     q, k, v = _randn((B * Tq, D), 1, 2.5), _randn((B * Tk, D), 2, 2.5), _randn((B * Tk, D), 3)
     qd, kd = q.view(B, Tq, heads, dh).transpose(1, 2).double(), k.view(B, Tk, heads, dh).transpose(1, 2).double()
-    vd = v.to(f16).view(B, Tk, heads, dh).transpose(1, 2).double()
+    vd = v.view(B, Tk, heads, dh).transpose(1, 2).double()
     s = qd @ kd.transpose(-1, -2) / math.sqrt(dh)
     if causal:
         s = s + torch.full((Tq, Tk), float("-inf"), dtype=f64).triu_(1)
     ref = (torch.softmax(s, -1) @ vd).transpose(1, 2).reshape(B * Tq, D)
-    Q, K, V = _split_act(q, dev), _split_act(k, dev), Act(v.to(f16).to(dev)[None].contiguous())
+    Q, K, V = _split_act(q, dev), _split_act(k, dev), _split_act(v, dev)
     kw = dict(batch=B, heads=heads, Tq=Tq, Tk=Tk, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=Tq * D, strideK=Tk * D,
               strideV=Tk * D, strideO=Tq * D, causal=causal)
     O3, O1 = Act.empty((B * Tq, D), True, dev), Act.empty((B * Tq, D), False, dev)
@@ -200,7 +200,7 @@ def test_attention_x3_scores(dev, dh, heads, Tq, Tk, causal):
     ops.attention(Q, K, V, O1, x3=False, **kw)
     e3 = float(((O3.t[0].float() + O3.t[1].float()).cpu().double() - ref).abs().max())
     e1 = float((O1.hi.float().cpu().double() - ref).abs().max())
-    assert e3 < 2e-3 and e3 * 4 < e1, (e3, e1)
+    assert e3 < 2e-5 and e3 * 100 < e1, (e3, e1)
 
 
 # ------------------------------------------------------------------------------------------- whole-model stress test

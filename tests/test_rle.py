@@ -41,3 +41,43 @@ def test_c_helper_matches_python_restatement():
         assert rle.encode(m)["counts"] == rle.encode_py(m)["counts"]
     big = np.zeros((300, 300), bool); big[5:290, 7] = True; big[0:3, 200] = True
     assert rle.encode(big)["counts"] == rle.encode_py(big)["counts"]
+
+
+def _mask_from_runs(size, runs):
+    h, w = size
+    flat = np.zeros(h * w, np.uint8)
+    pos, val = 0, 0
+    for r in runs:
+        flat[pos:pos + r] = val
+        pos += r
+        val ^= 1
+    assert pos == h * w
+    return flat.reshape((h, w), order="F")
+
+
+def test_rle_hand_derived_format_vectors(golden_dir):
+    """RLE byte strings pinned to vectors derived BY HAND from the published COCO format (pycocotools maskApi.c rleToString;
+    the package is absent), tests/golden/rle_vectors.json.  Worked examples (c = x & 31; x >>= 5; more = bit4(c) ? x != -1 :
+    x != 0; char = (c | 32*more) + 48; counts i > 2 stored minus counts[i-2]):
+      9            -> c=9, x=0, stop                      -> '9'
+      40           -> c=8, x=1, more -> 8|32=40 -> 'X'; then c=1 -> '1'            -> "X1"
+      1 - 2 = -1   -> c=31, x=-1, bit4 set and x == -1 -> stop -> 31+48 -> 'O'
+      1000         -> c=8,x=31 -> 'X'; c=31,x=0, bit4 set, 0 != -1 -> more -> 63+48 -> 'o'; c=0 -> '0'   -> "Xo0"
+      3 - 1000     -> -997: c=27,x=-32 -> 27|32 -> 'k'; c=0,x=-1, more (x != 0) -> 'P'; c=31,x=-1 stop -> 'O' -> "kPO"
+      2000 - 5     -> 1995: c=11,x=62 -> '['; c=30,x=1, bit4 set, more -> 'n'; c=1 -> '1'   -> "[n1"
+      31           -> c=31,x=0, bit4 set and 0 != -1 -> more -> 'o'; then '0' (a positive value whose top group has bit 4 set
+                      needs one more all-zero group so that the decoder does not sign-extend it)
+      16           -> c=16 -> same guard -> "`0"
+    """
+    import json
+    vecs = json.load(open(f"{golden_dir}/rle_vectors.json"))["vectors"]
+    assert len(vecs) >= 7
+    for v in vecs:
+        m = _mask_from_runs(v["size"], v["runs_colmajor"])
+        want = v["counts"].encode("ascii")
+        assert rle._counts(m).tolist() == v["runs_colmajor"], v["name"]
+        assert rle.encode_py(m)["counts"] == want, v["name"]                 # NumPy/Python restatement
+        assert rle.encode(m)["counts"] == want, v["name"]                    # C helper in libzutis_hip.so
+        assert rle.encode(m)["size"] == v["size"]
+        assert np.array_equal(rle.decode({"size": v["size"], "counts": want}), m), v["name"]
+        assert rle._from_string(want) == v["runs_colmajor"], v["name"]

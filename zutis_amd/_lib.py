@@ -31,8 +31,8 @@ _SIGS = {
     "zh_last_error": (C.c_char_p, []),
     "zh_gemm_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "zh_gemm_f16x3": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _f, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
-    "zh_attention_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _l, _l, _l, _vp]),
-    "zh_attention_causal_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _f, _l, _l, _l, _vp]),
+    "zh_attention_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _l, _l, _l, _l, _vp]),
+    "zh_attention_causal_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _f, _l, _l, _l, _l, _vp]),
     "zh_embed_tokens_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "zh_eot_rows_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "zh_group_mean_l2norm": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -68,6 +68,7 @@ _SIGS = {
     "zh_plan_run": (_i, [_vp, _i, _vp]),
     "zh_plan_run_multi": (_i, [_vp, _vp, _vp, _i]),
     "zh_plan_run2": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "zh_mask_nms": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),
     "zh_mask_iou_workspace_size": (_sz, [_i, _l]),
     "zh_mask_iou_counts": (_i, [_vp, _i, _l, _vp, _vp, _vp, _sz, _vp]),
 }

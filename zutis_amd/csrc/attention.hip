@@ -25,7 +25,7 @@ struct AttnArgs {
   int Tq, Tk, H;
   float scale_log2;
   int causal;       // keys > query masked (CLIP text tower, clip_arch.py:525-531)
-  long planeQ, planeK, planeO;   // X3 kernels: lo planes of the split-pair Q / K inputs; planeO != 0: O is written as a split pair
+  long planeQ, planeK, planeV, planeO;   // X3 kernels: lo planes of the split-pair Q / K / V inputs; planeO != 0: O is written as a split pair
 };
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -34,12 +34,13 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 #define KT 64
 #define VS 96
 
-// X3 = 1 (reference-equivalent scores): Q and K arrive as split pairs (hi = f16(x), lo = f16(x - hi)) and
+// X3 = 1 (the reference-equivalent mode): Q, K and V arrive as split pairs (hi = f16(x), lo = f16(x - hi)):
 // S = Kh.Qh + Kl.Qh + Kh.Ql in fp32 — the softmax exponent sees fp32-class scores, which is where fp16 operand rounding is
-// amplified (|s| * 2^-11 absolute).  P.V stays fp16 x fp16: P in [0,1] and V carry independent relative roundings that the
-// weighted average does not amplify.
+// amplified (|s| * 2^-11 absolute) — and the probabilities are split in registers, O += Vh.Ph + Vl.Ph + Vh.Pl, so short
+// key sets (decoder self-attention over 100 queries, small images) are not left with the 2^-11 rounding of single P / V
+// values.  One block per CU (the lo planes of K and V double the LDS tiles).
 template <int DH, int NWAVE, int X3>
-__global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnArgs p) {
   constexpr int NT = 64 * NWAVE;
   constexpr int KS = DH + 8;          // K row stride (halves)
   constexpr int NKS = DH / 16;        // k-steps of QK^T
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) half_t sKb[2][KT * KS];   // double-buffered: one barrier per key tile
   __shared__ __attribute__((aligned(16))) half_t sKl[X3 ? 2 : 1][X3 ? KT * KS : 8];   // lo plane of K (X3)
   __shared__ __attribute__((aligned(16))) half_t sVb[2][KT * VS];
+  __shared__ __attribute__((aligned(16))) half_t sVl[X3 ? 2 : 1][X3 ? KT * VS : 8];   // lo plane of V (X3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.y, img = blockIdx.z;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
   float m_run = -INFINITY, l_run = 0.f;
 
   // cooperative tile loads: chunk c -> (row = c / CPR, col chunk = c % CPR)
-  half8_t kreg[NLD], vreg[NLD], klreg[X3 ? NLD : 1];
+  half8_t kreg[NLD], vreg[NLD], klreg[X3 ? NLD : 1], vlreg[X3 ? NLD : 1];
   auto load_tile = [&](int kbase) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -93,11 +95,14 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
       if (key < p.Tk) {
         kreg[i] = *(const half8_t*)(K + (long)key * p.ldk + cc * 8);
         vreg[i] = *(const half8_t*)(V + (long)key * p.ldv + cc * 8);
-        if (X3) klreg[i] = *(const half8_t*)(K + p.planeK + (long)key * p.ldk + cc * 8);
+        if (X3) {
+          klreg[i] = *(const half8_t*)(K + p.planeK + (long)key * p.ldk + cc * 8);
+          vlreg[i] = *(const half8_t*)(V + p.planeV + (long)key * p.ldv + cc * 8);
+        }
       } else {
         kreg[i] = (half8_t)(half_t)0;
         vreg[i] = (half8_t)(half_t)0;
-        if (X3) klreg[i] = (half8_t)(half_t)0;
+        if (X3) { klreg[i] = (half8_t)(half_t)0; vlreg[i] = (half8_t)(half_t)0; }
       }
     }
   };
@@ -108,7 +113,10 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
       const int row = c / CPR, cc = c - row * CPR;
       *(half8_t*)(sKb[buf] + row * KS + cc * 8) = kreg[i];
       *(half8_t*)(sVb[buf] + row * VS + cc * 8) = vreg[i];
-      if (X3) *(half8_t*)(sKl[buf] + row * KS + cc * 8) = klreg[i];
+      if (X3) {
+        *(half8_t*)(sKl[buf] + row * KS + cc * 8) = klreg[i];
+        *(half8_t*)(sVl[buf] + row * VS + cc * 8) = vlreg[i];
+      }
     }
   };
 
@@ -175,14 +183,16 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
-    half8_t pf[2][2];
+    half8_t pf[2][2], pl[X3 ? 2 : 1][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
         psum += e;
-        pf[u][r >> 3][r & 7] = (half_t)e;
+        const half_t eh = (half_t)e;
+        pf[u][r >> 3][r & 7] = eh;
+        if (X3) pl[u][r >> 3][r & 7] = (half_t)(e - (float)eh);
       }
     l_run = l_run * alpha + psum;
     if (__any(alpha != 1.0f)) {
@@ -206,6 +216,16 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
           __builtin_memcpy(&vf, &lo, 8);
           __builtin_memcpy(((char*)&vf) + 8, &hi, 8);
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][ks], oacc[d], 0, 0, 0);
+          if (X3) {
+            const half_t* vq = sVl[t & 1] + (32 * u + 16 * ks + tr_row) * VS + tr_col;
+            fp16x4 llo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(vq + 32 * d));
+            fp16x4 lhi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(vq + 32 * d + 4 * VS));
+            half8_t vl;
+            __builtin_memcpy(&vl, &llo, 8);
+            __builtin_memcpy(((char*)&vl) + 8, &lhi, 8);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[u][ks], oacc[d], 0, 0, 0);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl[u][ks], oacc[d], 0, 0, 0);
+          }
         }
       }
     }
@@ -233,17 +253,18 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attn_f16_kernel(AttnArgs p) {
 static int attention_launch(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                             const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                             int batch, int heads, int Tq, int Tk, int head_dim, float scale, int causal,
-                            long planeQ, long planeK, long planeO, hipStream_t stream) {
+                            long planeQ, long planeK, long planeV, long planeO, hipStream_t stream) {
   ZH_CHECK_ARG(Q && K && V && O, "zh_attention_f16: null operand");
   ZH_CHECK_ARG(batch > 0 && heads > 0 && Tq > 0 && Tk > 0, "zh_attention_f16: bad shape");
   ZH_CHECK_ARG(head_dim == 64 || head_dim == 96, "zh_attention_f16: head_dim %d not in {64, 96}", head_dim);
   ZH_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && strideQ % 8 == 0 && strideK % 8 == 0 &&
-                   strideV % 8 == 0 && strideO % 4 == 0 && planeQ % 8 == 0 && planeK % 8 == 0 && planeO % 4 == 0,
+                   strideV % 8 == 0 && strideO % 4 == 0 && planeQ % 8 == 0 && planeK % 8 == 0 && planeV % 8 == 0 && planeO % 4 == 0,
                "zh_attention_f16: row/batch/plane strides must keep 16-byte (Q,K,V) / 8-byte (O) alignment");
   ZH_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 && ((uintptr_t)O & 7) == 0,
                "zh_attention_f16: misaligned pointer");
   ZH_CHECK_ARG(heads < 65536 && batch < 65536, "zh_attention_f16: heads/batch exceed grid limits");
-  ZH_CHECK_ARG((planeQ != 0) == (planeK != 0), "zh_attention_f16: split-pair scores need the lo planes of both Q and K");
+  ZH_CHECK_ARG((planeQ != 0) == (planeK != 0) && (planeQ != 0) == (planeV != 0),
+               "zh_attention_f16: the split-pair mode needs the lo planes of Q, K and V (all three or none)");
   AttnArgs p;
   p.Q = (const half_t*)Q; p.ldq = ldq; p.sQ = strideQ;
   p.K = (const half_t*)K; p.ldk = ldk; p.sK = strideK;
@@ -252,7 +273,7 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   p.Tq = Tq; p.Tk = Tk; p.H = heads;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.causal = causal;
-  p.planeQ = planeQ; p.planeK = planeK; p.planeO = planeO;
+  p.planeQ = planeQ; p.planeK = planeK; p.planeV = planeV; p.planeO = planeO;
   // 128-query (4-wave) blocks: each K/V tile is shared four ways.  A 64-query (2-wave) variant was measured slower on
   // every shape of the model (encoder 301 vs 423 TF, cross-attention 230 vs 397 TF) and was dropped.
   dim3 grid(zh_cdiv(Tq, 128), heads, batch);
@@ -271,15 +292,15 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
 extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                                 const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                                 int batch, int heads, int Tq, int Tk, int head_dim, float scale,
-                                long planeQ, long planeK, long planeO, hipStream_t stream) {
+                                long planeQ, long planeK, long planeV, long planeO, hipStream_t stream) {
   return attention_launch(Q, ldq, strideQ, K, ldk, strideK, V, ldv, strideV, O, ldo, strideO, batch, heads, Tq, Tk, head_dim,
-                          scale, 0, planeQ, planeK, planeO, stream);
+                          scale, 0, planeQ, planeK, planeV, planeO, stream);
 }
 
 extern "C" int zh_attention_causal_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                                        const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                                        int batch, int heads, int T, int head_dim, float scale,
-                                       long planeQ, long planeK, long planeO, hipStream_t stream) {
+                                       long planeQ, long planeK, long planeV, long planeO, hipStream_t stream) {
   return attention_launch(Q, ldq, strideQ, K, ldk, strideK, V, ldv, strideV, O, ldo, strideO, batch, heads, T, T, head_dim,
-                          scale, 1, planeQ, planeK, planeO, stream);
+                          scale, 1, planeQ, planeK, planeV, planeO, stream);
 }

@@ -280,3 +280,109 @@ extern "C" int zh_mask_runs(const unsigned char* masks, const int* sel, int n_se
   ZH_CHECK_LAUNCH("zh_mask_runs");
   return ZH_OK;
 }
+
+// ---- greedy per-category mask NMS on the device (networks/zutis.py:211-299, copy at coco20k_eval.py:54-136).
+// One workgroup per image; inputs are the exact integer intersection / union counts of zh_mask_iou_counts, so every IoU is
+// inter / (union + 1e-7) in float64 exactly as utils/iou.py:30-32 computes it on boolean masks.  Control flow of the
+// reference, restated over the Q x Q counts:
+//   for every category present, ascending, skipping 0 (background):
+//     active = queries of that category, s = their scores
+//     while active: best = argmax s (the reference takes the LAST element of an ascending np.argsort; equal maxima: the
+//                   largest query index here — numpy's choice among exact ties is unspecified); emit (best, s[best]);
+//                   for the others: s *= w(IoU(m, best)), w = hard: 0 if IoU > thr else 1; linear: (1 - IoU) if IoU > thr
+//                   else 1; gaussian: exp(-IoU^2 / sigma); drop those with s <= score_threshold
+//     emitted entries whose mask is empty are skipped (zutis.py:281-282).
+// Scores are carried in float64: the reference's float32 scores are promoted by the first float64 weight (linear / gaussian)
+// and stay float32 under hard NMS, where the only products are x1 / x0 — both representations agree exactly.
+#define NMS_MAXQ 1024
+__global__ __launch_bounds__(256) void mask_nms_kernel(const int* inter, const int* uni, const float* scores, const long long* cats,
+                                                       int Q, int nms_type, double thr, double sigma, double score_thr,
+                                                       int* out_idx, double* out_score, long long* out_cat, int* out_count) {
+  __shared__ double s_sc[NMS_MAXQ];
+  __shared__ long long s_cat[NMS_MAXQ];
+  __shared__ unsigned char s_act[NMS_MAXQ];
+  __shared__ double r_val[256];
+  __shared__ long long r_key[256];
+  __shared__ int s_best, s_n;
+  __shared__ long long s_cur;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  inter += (long)img * Q * Q; uni += (long)img * Q * Q;
+  scores += (long)img * Q; cats += (long)img * Q;
+  out_idx += (long)img * Q; out_score += (long)img * Q; out_cat += (long)img * Q;
+  for (int q = tid; q < Q; q += 256) { s_cat[q] = cats[q]; s_act[q] = 0; }
+  if (tid == 0) { s_n = 0; s_cur = 0; }        // categories <= 0 are never processed (0 = background)
+  __syncthreads();
+  for (;;) {
+    // next category: the smallest id greater than the one just processed
+    long long mine = 0x7FFFFFFFFFFFFFFFll;
+    for (int q = tid; q < Q; q += 256)
+      if (s_cat[q] > s_cur && s_cat[q] < mine) mine = s_cat[q];
+    r_key[tid] = mine;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st && r_key[tid + st] < r_key[tid]) r_key[tid] = r_key[tid + st];
+      __syncthreads();
+    }
+    const long long cur = r_key[0];
+    __syncthreads();
+    if (cur == 0x7FFFFFFFFFFFFFFFll) break;
+    if (tid == 0) s_cur = cur;
+    for (int q = tid; q < Q; q += 256) {
+      s_act[q] = s_cat[q] == cur;
+      s_sc[q] = (double)scores[q];
+    }
+    __syncthreads();
+    for (;;) {
+      // argmax over the active set; key = (score, index) so equal maxima resolve to the largest index
+      double bv = -1.0; int bi = -1;
+      for (int q = tid; q < Q; q += 256)
+        if (s_act[q] && (s_sc[q] > bv || (s_sc[q] == bv && q > bi))) { bv = s_sc[q]; bi = q; }
+      r_val[tid] = bv; r_key[tid] = bi;
+      __syncthreads();
+      for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+          const double ov = r_val[tid + st]; const long long oi = r_key[tid + st];
+          if (oi >= 0 && (r_key[tid] < 0 || ov > r_val[tid] || (ov == r_val[tid] && oi > r_key[tid]))) { r_val[tid] = ov; r_key[tid] = oi; }
+        }
+        __syncthreads();
+      }
+      const int best = (int)r_key[0];
+      const double best_s = r_val[0];
+      __syncthreads();
+      if (best < 0) break;
+      if (tid == 0) {
+        s_act[best] = 0;
+        if (inter[(long)best * Q + best] > 0) {         // area of the mask = |m & m|: empty masks are not emitted
+          const int n = s_n++;
+          out_idx[n] = best; out_score[n] = best_s; out_cat[n] = cur;
+        }
+      }
+      __syncthreads();
+      for (int q = tid; q < Q; q += 256) {
+        if (!s_act[q]) continue;
+        const double iou = (double)inter[(long)q * Q + best] / ((double)uni[(long)q * Q + best] + 1e-7);
+        double s = s_sc[q];
+        if (nms_type == 0) { if (iou > thr) s = s * 0.0; }
+        else if (nms_type == 1) { if (iou > thr) s = s * (1.0 - iou); }
+        else s = s * exp(-(iou * iou) / sigma);
+        s_sc[q] = s;
+        if (!(s > score_thr)) s_act[q] = 0;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) out_count[img] = s_n;
+}
+
+extern "C" int zh_mask_nms(const int* inter, const int* uni, const float* scores, const long long* category_ids, int B, int Q,
+                           int nms_type, double nms_threshold, double sigma, double score_threshold,
+                           int* out_index, double* out_score, long long* out_category, int* out_count, hipStream_t stream) {
+  ZH_CHECK_ARG(inter && uni && scores && category_ids && out_index && out_score && out_category && out_count,
+               "zh_mask_nms: null pointer");
+  ZH_CHECK_ARG(B > 0 && Q > 0 && Q <= NMS_MAXQ, "zh_mask_nms: need 0 < Q <= %d", NMS_MAXQ);
+  ZH_CHECK_ARG(nms_type >= 0 && nms_type <= 2, "zh_mask_nms: nms_type %d not in {0 hard, 1 linear, 2 gaussian}", nms_type);
+  hipLaunchKernelGGL(mask_nms_kernel, dim3(B), dim3(256), 0, stream, inter, uni, scores, category_ids, Q, nms_type, nms_threshold, sigma,
+                     score_threshold, out_index, out_score, out_category, out_count);
+  ZH_CHECK_LAUNCH("zh_mask_nms");
+  return ZH_OK;
+}

@@ -276,23 +276,21 @@ class ZUTIS(nn.Module):
         masks_dev, scores, category_ids = eng.instance_candidates(
             mask_proposals, dict_outputs["patch_tokens"], self.text_embeddings, threshold, temperature, size)
         B, Q, Hm, Wm = masks_dev.shape
+        category_ids_dev = category_ids
         confidence_scores: np.ndarray = scores.cpu().numpy()
         category_ids: np.ndarray = category_ids.cpu().numpy()
         if image_ids is None:
             image_ids = [0 for _ in range(B)]
 
         # The reference pulls all B x Q x H x W boolean masks to the host, then loops (zutis.py:423-469).  Here the masks
-        # stay on the GPU: IoU counts + areas come from the popcount kernel, the greedy NMS (control flow only) runs on
-        # the host over Q x Q numbers, and only the KEPT masks' run boundaries and boxes are copied back.
-        kept = []                                       # (batch index, category, query, score)
-        for bi in range(B):
-            s_img, c_img = confidence_scores[bi], category_ids[bi]
-            if nms_type is None:
-                kept += [(bi, int(c), q, float(s)) for q, (s, c) in enumerate(zip(s_img, c_img)) if c != 0]
-            else:
-                iou, areas = eng.mask_iou_matrix(masks_dev[bi], return_areas=True)
-                kept += [(bi, c, q, s) for c, q, s in
-                         self.non_maximum_suppression_indices(areas > 0, s_img, c_img, nms_type=nms_type, iou=iou)]
+        # stay on the GPU: IoU counts come from the popcount kernel, the greedy per-category NMS loop runs in one kernel
+        # launch (zh_mask_nms, one workgroup per image), and only the KEPT masks' run boundaries and boxes are copied back.
+        if nms_type is None:
+            kept = [(bi, int(c), q, float(s)) for bi in range(B)
+                    for q, (s, c) in enumerate(zip(confidence_scores[bi], category_ids[bi])) if c != 0]
+        else:
+            assert nms_type in ["hard", "linear", "gaussian"]
+            kept = eng.instance_nms(masks_dev, scores, category_ids_dev, nms_type)
         sel = np.array([bi * Q + q for bi, _, q, _ in kept], dtype=np.int32)
         rles, boxes, areas = eng.encode_masks(masks_dev.view(B * Q, Hm, Wm), sel)
         predictions: List[dict] = list()
@@ -316,9 +314,11 @@ class ZUTIS(nn.Module):
     @staticmethod
     def non_maximum_suppression_indices(binary_masks, scores, category_ids, nms_type="hard", nms_threshold=0.3,
                                         sigma=0.5, threshold=0.001, iou=None):
-        """Greedy per-category mask NMS with the reference's control flow (zutis.py:211-299), returning
-        (category, query index, score) in its emission order.  `iou` is the Q x Q matrix from the bit-packed
-        popcount kernel (exact integer counts / float64 divide = utils/iou.py on boolean masks)."""
+        """Host form of the greedy per-category mask NMS with the reference's control flow (zutis.py:211-299), returning
+        (category, query index, score) in its emission order.  predict() runs the device kernel (zh_mask_nms) instead; this
+        method is kept as the call surface for code that passes its own masks and as the host-side cross-check in the tests.
+        `iou` is the Q x Q matrix from the bit-packed popcount kernel (exact integer counts / float64 divide = utils/iou.py
+        on boolean masks)."""
         assert nms_type in ["hard", "linear", "gaussian"]
         out = []
         for c in sorted(set(int(v) for v in category_ids)):

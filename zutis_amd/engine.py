@@ -255,7 +255,7 @@ class _EngineBase:
         Ff = P_shape0(W_["dec.0.l1_w"])
         xk = xd and self._x3("dec_kv")                                                     # K lo planes feed the x3 scores
         KALL = self._abuf("KALL", (B * M, L * D), xk)
-        VALL = self._abuf("VALL", (B * M, L * D), False)
+        VALL = self._abuf("VALL", (B * M, L * D), xk)
         self._gemm("dec_kv", KIN16, W_["ca_k_w"], KALL, bias=W_["ca_k_b"])                 # all layers' K / V at once
         self._gemm("dec_kv", MEM16, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
         qpos = W_["query_embed"]
@@ -264,7 +264,7 @@ class _EngineBase:
         tgt16 = self._abuf("tgt16", (R, D), xd)
         qin16 = self._abuf("qin16", (R, D), xd)
         qk16 = self._abuf("qk16", (R, 2 * D), xd)
-        v16 = self._abuf("v16", (R, D), False)
+        v16 = self._abuf("v16", (R, D), xd)
         qc16 = self._abuf("qc16", (R, D), xd)
         o16 = self._abuf("do16", (R, D), xd)
         ff16 = self._abuf("ff16", (R, Ff), xd)
@@ -565,6 +565,24 @@ class ZutisEngine(_EngineBase):
         ih = inter.cpu().numpy()
         iou = ih / (uni.cpu().numpy() + 1e-7)
         return (iou, np.diag(ih).copy()) if return_areas else iou
+
+    def instance_nms(self, masks_u8: torch.Tensor, scores: torch.Tensor, category_ids: torch.Tensor, nms_type: str = "hard",
+                     nms_threshold: float = 0.3, sigma: float = 0.5, threshold: float = 0.001):
+        """zutis.py:211-299 for a batch, entirely on the device: masks u8 [B,Q,H,W], scores f32 [B,Q], category_ids int64 [B,Q]
+        -> list of (batch index, category, query index, score) in the reference's emission order.  Popcount IoU counts per
+        image (zh_mask_iou_counts), then one launch of the greedy per-category loop (zh_mask_nms, one workgroup per image);
+        only the kept (index, score, category) triples and their count cross PCIe."""
+        B, Q, H, W = masks_u8.shape
+        dev = masks_u8.device
+        inter = torch.empty((B, Q, Q), dtype=torch.int32, device=dev)
+        uni = torch.empty((B, Q, Q), dtype=torch.int32, device=dev)
+        m = masks_u8.contiguous()
+        for b in range(B):
+            ops.mask_iou_counts(m[b], Q, H * W, inter[b], uni[b])
+        idx, sc, cat, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma,
+                                         threshold)
+        cnt_h, idx_h, sc_h, cat_h = cnt.cpu().numpy(), idx.cpu().numpy(), sc.cpu().numpy(), cat.cpu().numpy()
+        return [(b, int(cat_h[b, j]), int(idx_h[b, j]), float(sc_h[b, j])) for b in range(B) for j in range(int(cnt_h[b]))]
 
     def encode_masks(self, masks_u8: torch.Tensor, sel: np.ndarray, max_runs: int = 8192):
         """COCO RLE dicts, xyxy boxes and areas of the masks `sel` (flat indices into [n,H,W]) without moving the masks

@@ -160,25 +160,25 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
 
 def attention(Q, K, V, O, *, batch, heads, Tq, Tk, head_dim, ldq, ldk, ldv, ldo, strideQ, strideK, strideV, strideO,
               scale=None, causal=False, x3=False):
-    """x3: Q and K are split-pair Acts and the scores get the three-product fp32-class form; a split O is filled as a pair."""
+    """x3: Q, K and V are split-pair Acts; scores and P.V get the three-product fp32-class form; a split O is filled as a pair."""
     L = _lib.load()
     scale = 1.0 / math.sqrt(head_dim) if scale is None else scale
-    (Q, pq), (K, pk), (V, _), (O, po) = _hp(Q), _hp(K), _hp(V), _hp(O)
-    if x3 and not (pq and pk):
-        raise _lib.ZutisHipError("attention(x3): Q and K must be split pairs")
+    (Q, pq), (K, pk), (V, pv), (O, po) = _hp(Q), _hp(K), _hp(V), _hp(O)
+    if x3 and not (pq and pk and pv):
+        raise _lib.ZutisHipError("attention(x3): Q, K and V must be split pairs")
     if not x3:
-        pq = pk = 0
+        pq = pk = pv = 0
     name = "attention_f16x3" if x3 else "attention_f16"
     if causal:
         if Tq != Tk:
             raise _lib.ZutisHipError("causal attention needs Tq == Tk")
         args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
-                batch, heads, Tq, head_dim, float(scale), pq, pk, po, _stream())
+                batch, heads, Tq, head_dim, float(scale), pq, pk, pv, po, _stream())
         _lib.check(_launch(name, 2.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_causal_f16(*args)),
                    "zh_attention_causal_f16")
         return O
     args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
-            batch, heads, Tq, Tk, head_dim, float(scale), pq, pk, po, _stream())
+            batch, heads, Tq, Tk, head_dim, float(scale), pq, pk, pv, po, _stream())
     _lib.check(_launch(name, 4.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_f16(*args)),
                "zh_attention_f16")
     return O
@@ -346,6 +346,29 @@ def mask_iou_counts(masks_u8, n, pixels, inter, uni):
     need = L.zh_mask_iou_workspace_size(n, pixels)
     ws = torch.empty(need, dtype=torch.uint8, device=masks_u8.device)
     _lib.check(L.zh_mask_iou_counts(_p(masks_u8), n, pixels, _p(inter), _p(uni), _p(ws), need, _stream()), "zh_mask_iou_counts")
+
+
+NMS_TYPES = {"hard": 0, "linear": 1, "gaussian": 2}
+
+
+def mask_nms(inter, uni, scores, category_ids, nms_type="hard", nms_threshold=0.3, sigma=0.5, score_threshold=0.001):
+    """Greedy per-category mask NMS on the device (zutis.py:211-299).  inter / uni int32 [B,Q,Q], scores f32 [B,Q], category_ids
+    int64 [B,Q] -> (index int32 [B,Q], score f64 [B,Q], category int64 [B,Q], count int32 [B]); the first count[b] entries of
+    row b are the kept queries in the reference's emission order."""
+    L = _lib.load()
+    B, Q = scores.shape
+    _chk(inter, torch.int32, "nms inter"); _chk(uni, torch.int32, "nms union"); _chk(scores, f32, "nms scores")
+    _chk(category_ids, torch.int64, "nms categories")
+    if nms_type not in NMS_TYPES:
+        raise AssertionError(nms_type)                     # reference: assert nms_type in ["hard", "linear", "gaussian"]
+    dev = scores.device
+    idx = torch.empty((B, Q), dtype=torch.int32, device=dev)
+    sc = torch.empty((B, Q), dtype=torch.float64, device=dev)
+    cat = torch.empty((B, Q), dtype=torch.int64, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    _lib.check(L.zh_mask_nms(_p(inter), _p(uni), _p(scores), _p(category_ids), B, Q, NMS_TYPES[nms_type], float(nms_threshold),
+                             float(sigma), float(score_threshold), _p(idx), _p(sc), _p(cat), _p(cnt), _stream()), "zh_mask_nms")
+    return idx, sc, cat, cnt
 
 
 # ---------------------------------------------------------------------------------------- bilateral solver (float64)

@@ -3,8 +3,9 @@
 The reference calls pycocotools.mask.encode(np.asfortranarray(m)) (networks/zutis.py:290,448) and
 torchvision.ops.masks_to_boxes (zutis.py:294,452).  Neither package is in this image, so their published
 algorithms are restated here (pycocotools 2.0 maskApi.c: rleEncode + rleToString; torchvision.ops.boxes.masks_to_boxes).
-PARITY UNPINNED for the RLE byte string: no pycocotools to compare with; pinned only by decode(encode(m)) == m and
-the format invariants in tests/test_rle.py.  When pycocotools IS importable, networks.zutis uses it instead.
+The RLE byte string is pinned by hand-derived vectors of the published format (tests/golden/rle_vectors.json, worked out in
+tests/test_rle.py: multi-character values, negative deltas, the sign-guard group) plus decode(encode(m)) == m; pycocotools
+itself is not available to compare with.  When pycocotools IS importable, networks.zutis uses it instead.
 """
 from __future__ import annotations
 
