@@ -168,7 +168,8 @@ def test_instance_kernels_vs_oracle_exact_inputs(dev, golden_dir):
             assert iou[i, j] == O.compute_iou(up[0, i], up[0, j])
 
 
-@pytest.mark.parametrize("precision,t_obj,t_mask,t_dts", [("fast", 2e-3, 5e-3, 5e-3), ("exact", 5e-5, 2e-4, 2e-4)])
+# fast: the DINO body runs on fp16 operands and the mask logits are un-normalised (|logit| ~ 30): 1e-3 relative on the logit
+@pytest.mark.parametrize("precision,t_obj,t_mask,t_dts", [("fast", 2e-3, 2e-2, 5e-3), ("exact", 2e-5, 4e-4, 2e-4)])
 def test_selfmask_engine_vs_reference_golden(dev, golden_dir, precision, t_obj, t_mask, t_dts):
     """SelfMask (DINO ViT-S/8 + decoder + objectness) on the HIP path against the reference's outputs."""
     from zutis_amd import detgen

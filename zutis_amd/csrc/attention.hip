@@ -190,7 +190,8 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
       for (int r = 0; r < 16; ++r) {
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
         psum += e;
-        const half_t eh = (half_t)e;
+        half_t eh = (half_t)e;
+        if (X3) asm volatile("" : "+v"(eh));      // one conversion only: see zh_store_h4 (common.h)
         pf[u][r >> 3][r & 7] = eh;
         if (X3) pl[u][r >> 3][r & 7] = (half_t)(e - (float)eh);
       }

@@ -52,8 +52,13 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // fp16 store of 4 consecutive values, optionally as a split pair for the f16x3 GEMM mode (gemm_x3.hip): hi = f16(y) at p,
 // lo = f16(y - hi) at p + lo_plane.  lo_plane == 0: hi only (the plain fp16 tensor every other consumer reads).
+// NOTE the asm barrier: without it hipcc converts y -> fp16 TWICE (v_cvt_pk_f16_f32 for the stored vector, v_cvt_f16_f32 for
+// the value subtracted below) and on gfx950 the two instructions do not agree on every input (seen on exact rounding ties,
+// ~2^-13 of all values): hi + lo was then off by one fp16 ulp.  The barrier makes `h` opaque, so lo is computed from the very
+// bits that are stored.
 __device__ __forceinline__ void zh_store_h4(half_t* p, long lo_plane, f32x4 y) {
-  const half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+  half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+  asm volatile("" : "+v"(h));
   *(half4_t*)p = h;
   if (lo_plane) {
     const half4_t l = {(half_t)(y[0] - (float)h[0]), (half_t)(y[1] - (float)h[1]), (half_t)(y[2] - (float)h[2]),
@@ -62,7 +67,8 @@ __device__ __forceinline__ void zh_store_h4(half_t* p, long lo_plane, f32x4 y) {
   }
 }
 __device__ __forceinline__ void zh_store_h1(half_t* p, long lo_plane, float y) {
-  const half_t h = (half_t)y;
+  half_t h = (half_t)y;
+  asm volatile("" : "+v"(h));
   *p = h;
   if (lo_plane) p[lo_plane] = (half_t)(y - (float)h);
 }

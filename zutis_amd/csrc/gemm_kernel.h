@@ -378,12 +378,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
           if (OUT == 1) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
           else if (OUT == 0) *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
           else {
-            half4_t hi = {(half_t)d[0], (half_t)d[1], (half_t)d[2], (half_t)d[3]};
-            half4_t lo = {(half_t)(d[0] - (float)hi[0]), (half_t)(d[1] - (float)hi[1]), (half_t)(d[2] - (float)hi[2]),
-                          (half_t)(d[3] - (float)hi[3])};
-            half_t* ch_ = (half_t*)p.C + cb + (long)m * p.ldc + n;
-            *(half4_t*)ch_ = hi;
-            *(half4_t*)(ch_ + p.planeC) = lo;
+            zh_store_h4((half_t*)p.C + cb + (long)m * p.ldc + n, p.planeC, d);
           }
         }
       }
@@ -410,12 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
           } else if (OUT == 0) {
             *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = v;
           } else {
-            half4_t hi = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            half4_t lo = {(half_t)(v[0] - (float)hi[0]), (half_t)(v[1] - (float)hi[1]), (half_t)(v[2] - (float)hi[2]),
-                          (half_t)(v[3] - (float)hi[3])};
-            half_t* ch_ = (half_t*)p.C + cb + (long)m * p.ldc + n;
-            *(half4_t*)ch_ = hi;
-            *(half4_t*)(ch_ + p.planeC) = lo;
+            zh_store_h4((half_t*)p.C + cb + (long)m * p.ldc + n, p.planeC, v);
           }
         }
       }
@@ -439,9 +429,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
             if (OUT == 1) ((half_t*)p.C)[ci] = (half_t)x;
             else if (OUT == 0) ((float*)p.C)[ci] = x;
             else {
-              const half_t hi = (half_t)x;
-              ((half_t*)p.C)[ci] = hi;
-              ((half_t*)p.C)[ci + p.planeC] = (half_t)(x - (float)hi);
+              zh_store_h1((half_t*)p.C + ci, p.planeC, x);
             }
           }
         }

@@ -40,8 +40,10 @@ __global__ __launch_bounds__(128) void im2col_kernel(const float* x, half_t* out
         const int yy = py * p + i, xx = px * p + j;     // beyond the image only with pad_to_patch (zero padding,
         if (yy < H && xx < W) v = x[(((long)b * Cin + c) * H + yy) * W + xx];   // selfmask/vision_transformer.py:260-267)
       }
-      o[e] = (half_t)v;
-      if (lo_plane) orow[lo_plane + k] = (half_t)(v - (float)o[e]);
+      half_t hv = (half_t)v;
+      asm volatile("" : "+v"(hv));                                  // one conversion only: see zh_store_h4 (common.h)
+      o[e] = hv;
+      if (lo_plane) orow[lo_plane + k] = (half_t)(v - (float)hv);
     }
     *(half8_t*)(orow + k0) = o;
   }
