@@ -84,38 +84,41 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // cooperative tile loads: chunk c -> (row = c / CPR, col chunk = c % CPR)
-  half8_t kreg[NLD], vreg[NLD], klreg[X3 ? NLD : 1], vlreg[X3 ? NLD : 1];
-  auto load_tile = [&](int kbase) {
+  // cooperative tile loads: chunk c -> (row = c / CPR, col chunk = c % CPR).  Two register sets: tile t+2 is requested
+  // while tile t is computed and tile t+1 (requested one iteration earlier) waits in the other set, so a global load has two
+  // key tiles of compute to land (one tile — ~0.5 us — did not cover the loaded L2 latency: the loop was latency-bound).
+  struct TileRegs { half8_t k[NLD], v[NLD], kl[X3 ? NLD : 1], vl[X3 ? NLD : 1]; };
+  TileRegs ra, rb;
+  auto load_tile = [&](int kbase, TileRegs& r) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
       const int row = c / CPR, cc = c - row * CPR;
       const int key = kbase + row;
       if (key < p.Tk) {
-        kreg[i] = *(const half8_t*)(K + (long)key * p.ldk + cc * 8);
-        vreg[i] = *(const half8_t*)(V + (long)key * p.ldv + cc * 8);
+        r.k[i] = *(const half8_t*)(K + (long)key * p.ldk + cc * 8);
+        r.v[i] = *(const half8_t*)(V + (long)key * p.ldv + cc * 8);
         if (X3) {
-          klreg[i] = *(const half8_t*)(K + p.planeK + (long)key * p.ldk + cc * 8);
-          vlreg[i] = *(const half8_t*)(V + p.planeV + (long)key * p.ldv + cc * 8);
+          r.kl[i] = *(const half8_t*)(K + p.planeK + (long)key * p.ldk + cc * 8);
+          r.vl[i] = *(const half8_t*)(V + p.planeV + (long)key * p.ldv + cc * 8);
         }
       } else {
-        kreg[i] = (half8_t)(half_t)0;
-        vreg[i] = (half8_t)(half_t)0;
-        if (X3) { klreg[i] = (half8_t)(half_t)0; vlreg[i] = (half8_t)(half_t)0; }
+        r.k[i] = (half8_t)(half_t)0;
+        r.v[i] = (half8_t)(half_t)0;
+        if (X3) { r.kl[i] = (half8_t)(half_t)0; r.vl[i] = (half8_t)(half_t)0; }
       }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const TileRegs& r) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
       const int row = c / CPR, cc = c - row * CPR;
-      *(half8_t*)(sKb[buf] + row * KS + cc * 8) = kreg[i];
-      *(half8_t*)(sVb[buf] + row * VS + cc * 8) = vreg[i];
+      *(half8_t*)(sKb[buf] + row * KS + cc * 8) = r.k[i];
+      *(half8_t*)(sVb[buf] + row * VS + cc * 8) = r.v[i];
       if (X3) {
-        *(half8_t*)(sKl[buf] + row * KS + cc * 8) = klreg[i];
-        *(half8_t*)(sVl[buf] + row * VS + cc * 8) = vlreg[i];
+        *(half8_t*)(sKl[buf] + row * KS + cc * 8) = r.kl[i];
+        *(half8_t*)(sVl[buf] + row * VS + cc * 8) = r.vl[i];
       }
     }
   };
@@ -132,16 +135,15 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
     ntiles = min(ntiles, qlast / KT + 1);
   }
   const int qidx = q0 + ql;
-  load_tile(0);
-  store_tile(0);
+  load_tile(0, ra);
+  store_tile(0, ra);
   __syncthreads();
+  if (ntiles > 1) load_tile(KT, ra);
 
-  for (int t = 0; t < ntiles; ++t) {
+  auto compute = [&](int t) {
     const int kbase = t * KT;
     const half_t* sK = sKb[t & 1];
     const half_t* sV = sVb[t & 1];
-    if (t + 1 < ntiles) load_tile(kbase + KT);
-
     // a wave whose 32 queries all lie beyond Tq (T = 442: two of the last block's four) only helps with the tile loads
     if (q0 < p.Tq) {
     // ---- S^T = K Q^T  (two 32-key slot tiles)
@@ -173,28 +175,38 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
           if (key >= p.Tk || (p.causal && key > qidx)) s[u][r] = -INFINITY;
         }
     }
+    {   // 32 scores per lane: four independent v_max3 chains instead of one 32-deep dependent chain
+      float m4[4] = {mx, mx, mx, mx};
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+        for (int r = 0; r < 16; r += 8) {
+          m4[0] = fmaxf(fmaxf(m4[0], s[u][r + 0]), s[u][r + 1]);
+          m4[1] = fmaxf(fmaxf(m4[1], s[u][r + 2]), s[u][r + 3]);
+          m4[2] = fmaxf(fmaxf(m4[2], s[u][r + 4]), s[u][r + 5]);
+          m4[3] = fmaxf(fmaxf(m4[3], s[u][r + 6]), s[u][r + 7]);
+        }
+      mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // running max kept in log2 units (scale_log2 > 0 commutes with max): p = 2^(s*c - m) is ONE fma + v_exp_f32
     const float m_new = fmaxf(m_run, mx * p.scale_log2);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    float psum = 0.f;
+    float ps4[4] = {0.f, 0.f, 0.f, 0.f};      // four independent partial sums (fixed order: deterministic)
     half8_t pf[2][2], pl[X3 ? 2 : 1][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
-        psum += e;
+        ps4[r & 3] += e;
         half_t eh = (half_t)e;
         if (X3) asm volatile("" : "+v"(eh));      // one conversion only: see zh_store_h4 (common.h)
         pf[u][r >> 3][r & 7] = eh;
         if (X3) pl[u][r >> 3][r & 7] = (half_t)(e - (float)eh);
       }
+    const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
     l_run = l_run * alpha + psum;
     if (__any(alpha != 1.0f)) {
 #pragma unroll
@@ -231,9 +243,20 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
       }
     }
 
-    // buffer (t+1)&1 was last read in iteration t-1; every wave passed the barrier that ended t-1 => free to overwrite
-    if (t + 1 < ntiles) store_tile((t + 1) & 1);
+  };
+
+  // buffer (t+1)&1 was last read in iteration t-1 and every wave passed the barrier that ended it => free to overwrite
+  for (int t = 0; t < ntiles; t += 2) {
+    if (t + 2 < ntiles) load_tile((t + 2) * KT, rb);
+    compute(t);
+    if (t + 1 < ntiles) store_tile(1, ra);
     __syncthreads();
+    if (t + 1 < ntiles) {
+      if (t + 3 < ntiles) load_tile((t + 3) * KT, ra);
+      compute(t + 1);
+      if (t + 2 < ntiles) store_tile(0, rb);
+      __syncthreads();
+    }
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

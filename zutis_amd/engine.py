@@ -270,31 +270,46 @@ class _EngineBase:
         ff16 = self._abuf("ff16", (R, Ff), xd)
         inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
         out32 = self._buf("dec_out32", (R, D), f32)
-        # tgt = zeros (zutis.py:164): layer 0's f16 inputs are constants of (B, weights) — zeros and f16(query_pos) — kept in
-        # their own buffers, and its first residual add (+0) is skipped, so nothing is filled or cast per forward
+        # tgt = zeros (zutis.py:164) and query_pos is a parameter, so layer 0's whole self-attention block — q/k/v projections
+        # of (0 + query_pos, 0), attention over the Q queries, out-projection, norm1 — does not depend on the image: its result
+        # (tgt after norm1 and f16(tgt + query_pos), [R, D] = the same Q rows for every image) is computed once per (batch rows,
+        # parameter version) with the same kernels and cached; layer 0 then starts at the cross-attention.
         ikey = ("dec_init", R, self._packed_key)
         init = self._geo.get(ikey)
         if init is None:
-            z = torch.zeros((R, D), dtype=f32, device=self._device())
-            init = {"tgt16": Act(torch.zeros((2 if xd else 1, R, D), dtype=f16, device=self._device())),
-                    "qin16": Act.empty((R, D), xd, self._device())}
-            ops.cast_f16(z, init["qin16"], R, D, add=qpos, add_rows=Q)
+            dev = self._device()
+            z = torch.zeros((R, D), dtype=f32, device=dev)
+            z16 = Act(torch.zeros((2 if xd else 1, R, D), dtype=f16, device=dev))
+            q0 = Act.empty((R, D), xd, dev)
+            ops.cast_f16(z, q0, R, D, add=qpos, add_rows=Q)
+            pp = "dec.0."
+            self._gemm("dec", q0, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])        # q = k = 0 + query_pos
+            self._gemm("dec", z16, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])          # v = 0 (the bias row)
+            ops.attention(qk16, qk16.view(qk16.hi[:, D:]), v16, o16, batch=B, heads=heads, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D,
+                          ldk=2 * D, ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D, x3=xd)
+            self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"])           # + tgt (= 0)
+            init = {"tgt0": torch.empty((R, D), dtype=f32, device=dev), "qin0": Act.empty((R, D), xd, dev)}
+            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=init["tgt0"], out_f16_plus=init["qin0"],
+                          add=qpos, add_rows=Q)
             self._geo_put(ikey, init)
         for l in range(L):
             pp = f"dec.{l}."
-            a_qk, a_v = (init["qin16"], init["tgt16"]) if l == 0 else (qin16, tgt16)
-            self._gemm("dec", a_qk, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])     # q = k = tgt + query_pos
-            self._gemm("dec", a_v, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])         # v = tgt
-            ops.attention(qk16, qk16.view(qk16.hi[:, D:]), v16, o16, batch=B, heads=heads, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D,
-                          ldk=2 * D, ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D, x3=xd)
-            self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=tgt if l > 0 else None)   # tgt == 0 at l == 0
-            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=tgt, out_f16_plus=qin16,
-                          add=qpos, add_rows=Q)
-            self._gemm("dec", qin16, W_[pp + "ca_q_w"], qc16, bias=W_[pp + "ca_q_b"])
+            if l == 0:
+                tgt_in, qin_in = init["tgt0"], init["qin0"]
+            else:
+                self._gemm("dec", qin16, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])     # q = k = tgt + query_pos
+                self._gemm("dec", tgt16, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])        # v = tgt
+                ops.attention(qk16, qk16.view(qk16.hi[:, D:]), v16, o16, batch=B, heads=heads, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D,
+                              ldk=2 * D, ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D, x3=xd)
+                self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=tgt)
+                ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=tgt, out_f16_plus=qin16,
+                              add=qpos, add_rows=Q)
+                tgt_in, qin_in = tgt, qin16
+            self._gemm("dec", qin_in, W_[pp + "ca_q_w"], qc16, bias=W_[pp + "ca_q_b"])
             ops.attention(qc16, KALL.view(KALL.hi[:, l * D:]), VALL.view(VALL.hi[:, l * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=M,
                           head_dim=dh, ldq=D, ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D,
                           strideO=Q * D, x3=xk)
-            self._gemm("dec", o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt)
+            self._gemm("dec", o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt_in)
             ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
             self._gemm("dec", tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
             self._gemm("dec", ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
