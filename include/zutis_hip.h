@@ -210,6 +210,18 @@ int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8,
                        double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
                        double* n_out, double* m_out, void* workspace, size_t workspace_bytes, zh_stream_t stream);
 
+/* The same for B images of one size in ONE sequence of launches (blockIdx.y = image): rgb u8 [B,H,W,3], target [B,H,W],
+ * out_soft f64 [B,H,W], stats int32 [B,2], n_out / m_out f64 [B,H*W]; workspace = B * zh_bilateral_workspace_size(...) bytes.
+ * A solve is ~110 small launches (grid build, 11 bistochastisation steps, 3 per CG iteration): batching shares them —
+ * the pseudo-label driver's batched mode (datasets/index_dataset.py:189-204 runs batch 1). */
+int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned char* target_u8, const double* target_f64, int B, int H, int W,
+                             double sigma_spatial, double sigma_luma, double sigma_chroma, double confidence, double lam,
+                             double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
+                             double* n_out, double* m_out, void* workspace, size_t workspace_bytes, zh_stream_t stream);
+
+/* output_solver > 0.5 on the device (networks/selfmask/selfmask.py:231): x f64 [n] -> out u8 {0,1} [n]. */
+int zh_threshold_f64_u8(const double* x, double threshold, unsigned char* out, long n, zh_stream_t stream);
+
 /* Retrieval (datasets/index_dataset.py:163-167): per row of scores [rows, N] (row stride ld) the k largest entries, score
  * descending, ties by ascending index — replaces torch.argsort(descending=True)[:n_images] per category.
  * idx_out int64 [rows,k]; val_out f32 [rows,k] or NULL.  k <= 1024.  The index reported for column i is

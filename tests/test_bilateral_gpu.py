@@ -143,3 +143,56 @@ def test_select_upsample_mask_kernel(dev):
     up = F.interpolate(masks[torch.arange(B), sel][:, None], scale_factor=4, mode="bilinear", align_corners=False)[:, 0, :H, :W]
     ref = (up > 0.5).to(torch.uint8)
     assert (out.cpu() != ref).float().mean().item() < 2e-4          # fp32 rounding at the 0.5 threshold only
+
+
+def test_solver_batched_equals_per_image_bitwise(dev):
+    """zh_bilateral_solve_batch (blockIdx.y = image, per-image workspace slices) == B separate solves, bit for bit; images
+    with different vertex counts share the launches.  Also: two runs of the same batch are bitwise identical (the splat is
+    integer atomics + ordered float sums — nothing depends on atomic order)."""
+    from zutis_amd import ops, detgen
+    h, w = 120, 168
+    rgbs = np.stack([detgen.selfmask_like_rgb(h, w, seed=s) for s in (3, 5, 9, 11)])
+    rgbs[3] = (detgen.det_normal("noise_rgb", (h, w, 3)) * 60 + 128).clip(0, 255).astype(np.uint8)      # many more vertices
+    yy, xx = np.mgrid[:h, :w]
+    tg = np.stack([(((yy - 60 - 5 * i) ** 2 + (xx - 80) ** 2) < (30 + 4 * i) ** 2).astype(np.uint8) for i in range(4)])
+    R, T = torch.from_numpy(rgbs).to(dev), torch.from_numpy(tg).to(dev)
+    soft_b, stats_b = ops.bilateral_solve(R, T)
+    soft_b2, _ = ops.bilateral_solve(R, T)
+    assert torch.equal(soft_b, soft_b2)
+    vs = []
+    for i in range(4):
+        s1, st1 = ops.bilateral_solve(R[i].contiguous(), T[i].contiguous())
+        assert torch.equal(s1, soft_b[i]) and torch.equal(st1, stats_b[i])
+        vs.append(int(st1[0]))
+    assert vs[3] > 2 * max(vs[:3])
+
+
+def test_solver_nonbinary_and_float_targets_ordered_splat(dev):
+    """Targets that are not {0,1}: the splat S.(t*w) is summed per vertex in ascending pixel order (SciPy's CSR row order),
+    for uint8 0..255 and for float64 targets, against the NumPy/SciPy oracle."""
+    from zutis_amd import ops, detgen
+    from oracle import bilateral_ref as B
+    h, w = 96, 128
+    rgb = detgen.selfmask_like_rgb(h, w, seed=3)
+    t8 = (np.abs(detgen.det_normal("t8", (h, w))) * 90).clip(0, 255).astype(np.uint8)
+    tf = np.abs(detgen.det_normal("tf", (h, w))).astype(np.float64) * 0.7
+    for t in (t8, tf):
+        ref_soft, _ = B.bilateral_solver_output(rgb, t)
+        soft, _ = ops.bilateral_solve(torch.from_numpy(rgb).to(dev), torch.from_numpy(t).to(dev))
+        assert np.abs(soft.cpu().numpy() - ref_soft).max() < 1e-9 * max(1.0, float(np.abs(ref_soft).max()))
+
+
+def test_pseudo_mask_batched_driver_matches_batch1(dev, tmp_path):
+    """Batched SelfMask + batched solver (generate_pseudo_masks_batched) write the same RLE JSON files as the batch-1 loop."""
+    from zutis_amd import detgen, pseudo_masks
+    from zutis_amd.engine import SelfMaskEngine
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()})
+    sizes_in = [(72, 100), (72, 100), (72, 100), (64, 64), (64, 64), (72, 100)]
+    imgs = [torch.from_numpy(detgen.images(1, h, w, seed=40 + i))[0].to(dev) for i, (h, w) in enumerate(sizes_in)]
+    sizes_out = [(2 * h + 1, 2 * w) for h, w in sizes_in]
+    pa = [str(tmp_path / "seq" / f"{i}.json") for i in range(len(imgs))]
+    pb = [str(tmp_path / "bat" / f"{i}.json") for i in range(len(imgs))]
+    pseudo_masks.generate_pseudo_masks(eng, imgs, sizes_out, pa, n_streams=1)
+    pseudo_masks.generate_pseudo_masks_batched(eng, imgs, sizes_out, pb, batch_size=4)
+    for a, b in zip(pa, pb):
+        assert open(a).read() == open(b).read()

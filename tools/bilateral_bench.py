@@ -1,19 +1,24 @@
-"""Bilateral solver: GPU (zh_bilateral_solve) vs the NumPy/SciPy oracle on a SelfMask-sized image (developer tool)."""
+"""Bilateral solver throughput at the SelfMask size (512x683), one image per call and batched (zh_bilateral_solve_batch).
+Algorithmic bytes per image: N*(3+1+8+4*4) + V*250*(25 CG + 11 bistochastisation iterations)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from zutis_amd import ops, detgen
-from oracle import bilateral_ref as B
 dev = torch.device("cuda:0")
-for (h, w) in [(512, 683), (512, 1131)]:
-    rgb = detgen.selfmask_like_rgb(h, w, seed=3)
-    yy, xx = np.mgrid[:h, :w]
-    target = (((yy - h / 2) ** 2 + (xx - w / 2) ** 2) < (0.3 * h) ** 2).astype(np.uint8)
-    r, t = torch.from_numpy(rgb).to(dev), torch.from_numpy(target).to(dev)
-    for _ in range(3): soft, stats = ops.bilateral_solve(r, t)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): soft, stats = ops.bilateral_solve(r, t)
-    torch.cuda.synchronize(); gpu = (time.perf_counter() - t0) / 20
-    t0 = time.perf_counter(); ref, _ = B.bilateral_solver_output(rgb, target); cpu = time.perf_counter() - t0
-    V, its = stats.cpu().tolist()
-    print(f"{h}x{w}: V={V} cg_iters={its} GPU {gpu*1e3:.3f} ms  oracle(CPU, incl. post-processing) {cpu*1e3:.0f} ms  max|diff| {np.abs(soft.cpu().numpy()-ref).max():.2e}")
+H, W = 512, 683
+yy, xx = np.mgrid[:H, :W]
+for B in (1, 2, 4, 8, 16, 32):
+    rgb = torch.from_numpy(np.stack([detgen.selfmask_like_rgb(H, W, seed=3 + i) for i in range(B)])).to(dev)
+    tg = torch.from_numpy(np.stack([(((yy - 250) ** 2 + (xx - 300 - 3 * i) ** 2) < 150 ** 2).astype(np.uint8) for i in range(B)])).to(dev)
+    soft, stats = ops.bilateral_solve(rgb, tg)
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ops.bilateral_solve(rgb, tg)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    V = stats[:, 0].float().mean().item()
+    byts = H * W * (3 + 1 + 8 + 16) + V * 250 * 36
+    print(f"B={B:2d}: {dt*1e3:7.3f} ms per call, {dt/B*1e3:6.3f} ms per image, V~{V:.0f}, iters {stats[:,1].tolist()[:4]}, "
+          f"algorithmic {byts/1e6:.1f} MB/image -> {byts*B/dt/1e12:.3f} TB/s", flush=True)

@@ -64,6 +64,8 @@ _SIGS = {
     "zh_bgrid_coords": (_i, [_vp, _i, _i, _d, _d, _d, _vp, _vp]),
     "zh_bilateral_workspace_size": (_sz, [_i, _i, _d, _d, _d]),
     "zh_bilateral_solve": (_i, [_vp, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "zh_bilateral_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "zh_threshold_f64_u8": (_i, [_vp, _d, _vp, _l, _vp]),
     "zh_plan_op_name": (C.c_char_p, [_i]),
     "zh_plan_run": (_i, [_vp, _i, _vp]),
     "zh_plan_run_multi": (_i, [_vp, _vp, _vp, _i]),

@@ -9,10 +9,15 @@
 // hash order (hash = x + 255 y + 255^2 l + ... sorts by (v,u,l,y,x)).  So:
 //   vertex id of a cell   = exclusive popcount-prefix of the occupancy bitmap   (== np.unique's sorted rank)
 //   neighbour of a vertex = bit test at cell +/- stride_d + the same prefix      (== searchsorted + equality test)
-// No sort, no hash table, no CSR: splat is an integer-indexed atomic add (order-independent for binary targets:
-// every addend is 0 or the same constant), blur is a 10-entry gather summed in SciPy's CSR column order.
-// The PCG loop keeps every scalar (rho, alpha, ||r||, the convergence flag) on the device: 3 launches per
-// iteration, deterministic two-level reductions, no host round trip until the result is sliced.
+// No sort, no hash table, no CSR.  Splat is deterministic and reproduces SciPy's CSR row sums bit for bit: pixel counts and
+// (for uint8 targets) target sums are INTEGER atomics; splat(w) is `confidence` added count times; splat(t*w) is the same
+// repeated add for binary targets and, for any other target, a per-vertex scan of the vertex's spatial cell in ascending
+// pixel order (a vertex's pixels all lie in one sigma_spatial x sigma_spatial block).  Blur is a 10-entry gather summed in
+// SciPy's CSR column order.  The PCG loop keeps every scalar (rho, alpha, ||r||, the convergence flag) on the device: 3
+// launches per iteration, deterministic two-level reductions over the blocks that actually hold vertices (the block count
+// is derived in-kernel from the vertex count), no host round trip until the result is sliced.
+// Batching: every kernel takes blockIdx.y = image; the B images of a call (same H x W) have their own workspace slices, so
+// the ~110 launches of a solve — launch/latency-bound for one image — are shared by the whole batch.
 #include "common.h"
 
 typedef unsigned long long u64;
@@ -67,6 +72,10 @@ extern "C" int zh_denormalize_u8(const float* x, unsigned char* rgb, int H, int 
   return ZH_OK;
 }
 
+// ---- batching: image = blockIdx.y; per-image strides of the caller's arrays and of the workspace
+struct BgBatch { size_t ws; long N; long dbg; };     // workspace bytes per image, pixels per image, doubles per image in n_out / m_out
+template <class T> __device__ __forceinline__ T* ws_img(T* p, const BgBatch& bt) { return (T*)((char*)p + (size_t)blockIdx.y * bt.ws); }
+
 // ---- K1: 5-D coordinates (bilateral_solver.py:42-50) -> dense cell id, occupancy bitmap
 __device__ __forceinline__ void yuv_bins(unsigned char R, unsigned char G, unsigned char B, double sl, double sc, int& l, int& u, int& v) {
   const double r = R, g = G, b = B;
@@ -80,15 +89,17 @@ __device__ __forceinline__ void yuv_bins(unsigned char R, unsigned char G, unsig
 }
 
 __global__ __launch_bounds__(256) void bg_cells_kernel(const unsigned char* rgb, int H, int W, double ss, double sl, double sc,
-                                                       BgDims dm, int* cell, u64* bitmap, int* coords_out) {
+                                                       BgDims dm, int* cell, u64* bitmap, int* coords_out, BgBatch bt) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long)H * W) return;
+  rgb += (size_t)blockIdx.y * bt.N * 3;
   const int y = (int)(p / W), x = (int)(p - (long)y * W);
   int l, u, v;
   yuv_bins(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2], sl, sc, l, u, v);
   const int cx = (int)((double)x / ss), cy = (int)((double)y / ss);
-  if (coords_out) { int* c = coords_out + 5 * p; c[0] = cx; c[1] = cy; c[2] = l; c[3] = u; c[4] = v; }
+  if (coords_out) { int* c = coords_out + 5 * ((size_t)blockIdx.y * bt.N + p); c[0] = cx; c[1] = cy; c[2] = l; c[3] = u; c[4] = v; }
   if (cell) {
+    cell = ws_img(cell, bt); bitmap = ws_img(bitmap, bt);
     l = min(l, dm.Nl - 1); u = min(u, dm.Nu - 1); v = min(v, dm.Nv - 1);
     const long id = ((((long)v * dm.Nu + u) * dm.Nl + l) * dm.Ny + cy) * dm.Nx + cx;
     cell[p] = (int)id;
@@ -98,7 +109,8 @@ __global__ __launch_bounds__(256) void bg_cells_kernel(const unsigned char* rgb,
 
 // ---- K2: exclusive prefix of per-word popcounts (3 passes; words <= ~1M)
 #define SCAN_PER_BLOCK 1024
-__global__ __launch_bounds__(256) void bg_scan_block_sums(const u64* bitmap, long nwords, unsigned* blocksum) {
+__global__ __launch_bounds__(256) void bg_scan_block_sums(const u64* bitmap, long nwords, unsigned* blocksum, BgBatch bt) {
+  bitmap = ws_img(bitmap, bt); blocksum = ws_img(blocksum, bt);
   const long base = (long)blockIdx.x * SCAN_PER_BLOCK;
   unsigned s = 0;
   for (int i = threadIdx.x; i < SCAN_PER_BLOCK; i += 256)
@@ -110,12 +122,33 @@ __global__ __launch_bounds__(256) void bg_scan_block_sums(const u64* bitmap, lon
   __syncthreads();
   if (threadIdx.x == 0) blocksum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void bg_scan_top(unsigned* blocksum, int nb, int* nvertices) {   // one thread: nb is a few hundred
-  unsigned acc = 0;
-  for (int i = 0; i < nb; ++i) { const unsigned t = blocksum[i]; blocksum[i] = acc; acc += t; }
-  *nvertices = (int)acc;
+__global__ __launch_bounds__(256) void bg_scan_top(unsigned* blocksum, int nb, int* nvertices, BgBatch bt) {
+  // one workgroup per image: exclusive scan of the nb (a few hundred) block sums, 256 at a time with a running carry
+  blocksum = ws_img(blocksum, bt); nvertices = ws_img(nvertices, bt);
+  __shared__ unsigned sh[256];
+  __shared__ unsigned carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 256) {
+    const int i = base + threadIdx.x;
+    const unsigned mine = i < nb ? blocksum[i] : 0;
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const unsigned t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) blocksum[i] = carry + sh[threadIdx.x] - mine;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += sh[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *nvertices = (int)carry;
 }
-__global__ __launch_bounds__(256) void bg_scan_write(const u64* bitmap, long nwords, const unsigned* blocksum, unsigned* wprefix) {
+__global__ __launch_bounds__(256) void bg_scan_write(const u64* bitmap, long nwords, const unsigned* blocksum, unsigned* wprefix, BgBatch bt) {
+  bitmap = ws_img(bitmap, bt); blocksum = ws_img(blocksum, bt); wprefix = ws_img(wprefix, bt);
   // each thread owns 4 consecutive words; block-level exclusive scan of the 256 thread sums
   const long base = (long)blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 4;
   unsigned c[4], s = 0;
@@ -135,26 +168,31 @@ __global__ __launch_bounds__(256) void bg_scan_write(const u64* bitmap, long nwo
   for (int i = 0; i < 4; ++i) { if (base + i < nwords) wprefix[base + i] = run; run += c[i]; }
 }
 
-// ---- K3: pixel -> vertex, splat of ones / confidence / target*confidence (S.dot, bilateral_solver.py:87-88)
+// ---- K3: pixel -> vertex; INTEGER splat of ones and (uint8 targets) of the target (S.dot, bilateral_solver.py:87-88)
 __global__ __launch_bounds__(256) void bg_assign_kernel(const int* cell, const u64* bitmap, const unsigned* wprefix, long N,
-                                                        const unsigned char* t_u8, const double* t_f64, double conf,
-                                                        int* pix2v, double* cnt, double* wsplat, double* bsplat) {
+                                                        const unsigned char* t_u8, int* pix2v, unsigned* cnt_i, unsigned* tsum_i,
+                                                        unsigned* nonbinary, BgBatch bt) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= N) return;
+  cell = ws_img(cell, bt); bitmap = ws_img(bitmap, bt); wprefix = ws_img(wprefix, bt); pix2v = ws_img(pix2v, bt);
+  cnt_i = ws_img(cnt_i, bt); tsum_i = ws_img(tsum_i, bt); nonbinary = ws_img(nonbinary, bt);
   const int id = cell[p];
   const u64 w = bitmap[id >> 6];
   const int v = (int)(wprefix[id >> 6] + __popcll(w & ((1ull << (id & 63)) - 1ull)));
   pix2v[p] = v;
-  const double t = t_u8 ? (double)t_u8[p] : t_f64[p];
-  atomicAdd(&cnt[v], 1.0);
-  atomicAdd(&wsplat[v], conf);
-  atomicAdd(&bsplat[v], t * conf);
+  atomicAdd(&cnt_i[v], 1u);
+  if (t_u8) {
+    const unsigned t = t_u8[(size_t)blockIdx.y * bt.N + p];
+    if (t) atomicAdd(&tsum_i[v], t);
+    if (t > 1) atomicOr(nonbinary, 1u);
+  }
 }
 
 // ---- K4/K5: vertex -> cell, neighbour table (get_valid_idx, bilateral_solver.py:29-37,69-81)
-__global__ __launch_bounds__(256) void bg_vertices_kernel(const u64* bitmap, const unsigned* wprefix, long nwords, int* vcell) {
+__global__ __launch_bounds__(256) void bg_vertices_kernel(const u64* bitmap, const unsigned* wprefix, long nwords, int* vcell, BgBatch bt) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   if (w >= nwords) return;
+  bitmap = ws_img(bitmap, bt); wprefix = ws_img(wprefix, bt); vcell = ws_img(vcell, bt);
   u64 bits = bitmap[w];
   unsigned v = wprefix[w];
   while (bits) {
@@ -164,7 +202,8 @@ __global__ __launch_bounds__(256) void bg_vertices_kernel(const u64* bitmap, con
   }
 }
 __global__ __launch_bounds__(256) void bg_neighbors_kernel(const int* vcell, const u64* bitmap, const unsigned* wprefix, const int* nv,
-                                                           BgDims dm, int* nbr) {
+                                                           BgDims dm, int* nbr, BgBatch bt) {
+  vcell = ws_img(vcell, bt); bitmap = ws_img(bitmap, bt); wprefix = ws_img(wprefix, bt); nv = ws_img(nv, bt); nbr = ws_img(nbr, bt);
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= *nv) return;
   const long id = vcell[v];
@@ -190,14 +229,53 @@ __global__ __launch_bounds__(256) void bg_neighbors_kernel(const int* vcell, con
     }
 }
 
+// ---- splat finalisation, one thread per vertex: the float64 sums SciPy's CSR matvec forms, in its order.
+//   cnt    = S.1            (exact integer)
+//   wsplat = S.(conf * 1)   = conf added cnt times
+//   bsplat = S.(t * conf)   = binary targets: conf added (number of ones) times (x + 0.0 == x);
+//                             otherwise the vertex's spatial cell is scanned in ascending pixel order
+__global__ __launch_bounds__(256) void bg_splat_final_kernel(const unsigned* cnt_i, const unsigned* tsum_i, const unsigned* nonbinary,
+                                                             const int* pix2v, const int* vcell, const int* nv, const unsigned char* t_u8,
+                                                             const double* t_f64, int H, int W, double ss, BgDims dm, double conf,
+                                                             double* cnt, double* wsplat, double* bsplat, BgBatch bt) {
+  cnt_i = ws_img(cnt_i, bt); tsum_i = ws_img(tsum_i, bt); nonbinary = ws_img(nonbinary, bt); pix2v = ws_img(pix2v, bt);
+  vcell = ws_img(vcell, bt); nv = ws_img(nv, bt); cnt = ws_img(cnt, bt); wsplat = ws_img(wsplat, bt); bsplat = ws_img(bsplat, bt);
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= *nv) return;
+  const unsigned k = cnt_i[v];
+  cnt[v] = (double)k;
+  double sw = 0.0;
+  for (unsigned i = 0; i < k; ++i) sw = sw + conf;
+  wsplat[v] = sw;
+  double sb = 0.0;
+  if (t_u8 && *nonbinary == 0) {
+    const unsigned ones = tsum_i[v];
+    for (unsigned i = 0; i < ones; ++i) sb = sb + conf;
+  } else {
+    const long id = vcell[v];
+    const int cx = (int)(id % dm.Nx), cy = (int)((id / dm.Nx) % dm.Ny);
+    const int x0 = max(0, (int)((double)cx * ss) - 1), x1 = min(W - 1, (int)((double)(cx + 1) * ss) + 1);
+    const int y0 = max(0, (int)((double)cy * ss) - 1), y1 = min(H - 1, (int)((double)(cy + 1) * ss) + 1);
+    const size_t ib = (size_t)blockIdx.y * bt.N;
+    for (int y = y0; y <= y1; ++y)
+      for (int x = x0; x <= x1; ++x) {
+        const long p = (long)y * W + x;
+        if (pix2v[p] == v) sb = sb + (t_u8 ? (double)t_u8[ib + p] : t_f64[ib + p]) * conf;
+      }
+  }
+  bsplat[v] = sb;
+}
+
 // ---- bistochastisation (bilateral_solver.py:107-118)
-__global__ __launch_bounds__(256) void bg_bisto_step(const double* n_in, const double* m0, const int* nbr, const int* nv, double* n_out) {
+__global__ __launch_bounds__(256) void bg_bisto_step(const double* n_in, const double* m0, const int* nbr, const int* nv, double* n_out, BgBatch bt) {
+  n_in = ws_img(n_in, bt); m0 = ws_img(m0, bt); nbr = ws_img(nbr, bt); nv = ws_img(nv, bt); n_out = ws_img(n_out, bt);
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= *nv) return;
   const double nvv = n_in[v];
   n_out[v] = sqrt(nvv * m0[v] / blur_gather(n_in, nbr + v * 10, nvv));
 }
-__global__ __launch_bounds__(256) void bg_bisto_final(const double* n, const int* nbr, const int* nv, double* m) {
+__global__ __launch_bounds__(256) void bg_bisto_final(const double* n, const int* nbr, const int* nv, double* m, BgBatch bt) {
+  n = ws_img(n, bt); nbr = ws_img(nbr, bt); nv = ws_img(nv, bt); m = ws_img(m, bt);
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= *nv) return;
   m[v] = n[v] * blur_gather(n, nbr + v * 10, n[v]);
@@ -207,10 +285,19 @@ __global__ __launch_bounds__(256) void bg_bisto_final(const double* n, const int
 struct CgPtrs {
   const double *n, *m, *wsplat, *b; const int* nbr; const int* nv;
   double *minv, *x, *r, *z, *p, *q;
-  double *part_rz, *part_rr, *part_pq;   // per-block partial sums [nblocks]; three arrays => no cross-block WAR
+  double *part_rz, *part_rr, *part_pq;   // per-block partial sums; three arrays => no cross-block WAR
   double* sc;                            // scalars: [0],[1] rho ping-pong, [2] atol, [3] converged flag, [4] iterations
-  double lam, a_diag_min, rtol; int nblocks;
+  double lam, a_diag_min, rtol;
 };
+__device__ __forceinline__ CgPtrs cg_img(CgPtrs c, const BgBatch& bt) {
+  c.n = ws_img(c.n, bt); c.m = ws_img(c.m, bt); c.wsplat = ws_img(c.wsplat, bt); c.b = ws_img(c.b, bt); c.nbr = ws_img(c.nbr, bt);
+  c.nv = ws_img(c.nv, bt); c.minv = ws_img(c.minv, bt); c.x = ws_img(c.x, bt); c.r = ws_img(c.r, bt); c.z = ws_img(c.z, bt);
+  c.p = ws_img(c.p, bt); c.q = ws_img(c.q, bt); c.part_rz = ws_img(c.part_rz, bt); c.part_rr = ws_img(c.part_rr, bt);
+  c.part_pq = ws_img(c.part_pq, bt); c.sc = ws_img(c.sc, bt);
+  return c;
+}
+// blocks that hold vertices: the launch grid is sized for the worst case (one vertex per pixel); everything past this exits
+__device__ __forceinline__ int cg_active_blocks(const CgPtrs& c) { return (*c.nv + 255) >> 8; }
 
 __device__ __forceinline__ double matvec_row(const CgPtrs& c, const double* y, int v) {
   // A y = lam * (m*y - n * blur(n .* y)) + wsplat*y
@@ -232,16 +319,20 @@ __device__ __forceinline__ double sum_partials(const double* part, int nb, doubl
   return block_sum(s, red);
 }
 
-__global__ __launch_bounds__(256) void bg_fill_kernel(double* x, double val, const int* nv) {
+__global__ __launch_bounds__(256) void bg_fill_kernel(double* x, double val, const int* nv, BgBatch bt) {
+  x = ws_img(x, bt); nv = ws_img(nv, bt);
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v < *nv) x[v] = val;
 }
-__global__ __launch_bounds__(256) void cg_y0_kernel(CgPtrs c) {          // flat initialisation y0 = splat(xw) / splat(w)
+__global__ __launch_bounds__(256) void cg_y0_kernel(CgPtrs c0, BgBatch bt) {          // flat initialisation y0 = splat(xw) / splat(w)
+  const CgPtrs c = cg_img(c0, bt);
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v < *c.nv) c.x[v] = c.b[v] / c.wsplat[v];
 }
-__global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c) {
+__global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c0, BgBatch bt) {
   __shared__ double red[4];
+  const CgPtrs c = cg_img(c0, bt);
+  if ((int)blockIdx.x >= cg_active_blocks(c)) return;
   const int v = blockIdx.x * 256 + threadIdx.x;
   double rz = 0.0, rr = 0.0, bb = 0.0;
   if (v < *c.nv) {
@@ -257,17 +348,21 @@ __global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c) {
   const double s1 = block_sum(rz, red), s2 = block_sum(rr, red), s3 = block_sum(bb, red);
   if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = s1; c.part_rr[blockIdx.x] = s2; c.part_pq[blockIdx.x] = s3; }
 }
-__global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c) {        // one block: atol = rtol * ||b||
+__global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c0, BgBatch bt) {        // one block per image: atol = rtol * ||b||
   __shared__ double red[4];
-  const double bb = sum_partials(c.part_pq, c.nblocks, red);
+  const CgPtrs c = cg_img(c0, bt);
+  const double bb = sum_partials(c.part_pq, cg_active_blocks(c), red);
   if (threadIdx.x == 0) { c.sc[2] = c.rtol * sqrt(bb); c.sc[3] = 0.0; c.sc[4] = 0.0; }
 }
-__global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c, int it) {
+__global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c0, int it, BgBatch bt) {
   __shared__ double red[4];
+  const CgPtrs c = cg_img(c0, bt);
+  const int nb = cg_active_blocks(c);
+  if ((int)blockIdx.x >= nb) return;
   // every block re-derives the convergence decision from the same partials (deterministic) -> no intra-kernel flag race;
   // once converged the partials are frozen, so the decision repeats for all later iterations
-  const double rho = sum_partials(c.part_rz, c.nblocks, red);
-  const double rr = sum_partials(c.part_rr, c.nblocks, red);
+  const double rho = sum_partials(c.part_rz, nb, red);
+  const double rr = sum_partials(c.part_rr, nb, red);
   if (sqrt(rr) < c.sc[2]) {                                               // ||r|| < atol at the top of iteration `it`
     if (blockIdx.x == 0 && threadIdx.x == 0 && c.sc[3] == 0.0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
     return;
@@ -276,8 +371,10 @@ __global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c, int it) {
   if (v < *c.nv) c.p[v] = it == 0 ? c.z[v] : c.z[v] + (rho / c.sc[(it - 1) & 1]) * c.p[v];
   if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;
 }
-__global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c) {
+__global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c0, BgBatch bt) {
   __shared__ double red[4];
+  const CgPtrs c = cg_img(c0, bt);
+  if ((int)blockIdx.x >= cg_active_blocks(c)) return;
   if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
   const int v = blockIdx.x * 256 + threadIdx.x;
   double pq = 0.0;
@@ -285,10 +382,13 @@ __global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c) {
   const double s = block_sum(pq, red);
   if (threadIdx.x == 0) c.part_pq[blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c, int it) {
+__global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBatch bt) {
   __shared__ double red[4];
+  const CgPtrs c = cg_img(c0, bt);
+  const int nb = cg_active_blocks(c);
+  if ((int)blockIdx.x >= nb) return;
   if (c.sc[3] != 0.0) return;
-  const double pq = sum_partials(c.part_pq, c.nblocks, red);
+  const double pq = sum_partials(c.part_pq, nb, red);
   const double alpha = c.sc[it & 1] / pq;
   const int v = blockIdx.x * 256 + threadIdx.x;
   double rz = 0.0, rr = 0.0;
@@ -303,14 +403,26 @@ __global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c, int it) {
   const double s1 = block_sum(rz, red), s2 = block_sum(rr, red);
   if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = s1; c.part_rr[blockIdx.x] = s2; }
 }
-__global__ void cg_finish_kernel(CgPtrs c, int maxiter, int* stats) {
-  if (c.sc[3] == 0.0) c.sc[4] = (double)maxiter;
-  if (stats) { stats[0] = *c.nv; stats[1] = (int)c.sc[4]; }
+__global__ void cg_finish_kernel(CgPtrs c0, int maxiter, int* stats, const double* n_src, const double* m_src, double* n_out, double* m_out,
+                                 BgBatch bt) {
+  const CgPtrs c = cg_img(c0, bt);
+  if (threadIdx.x == 0) {
+    if (c.sc[3] == 0.0) c.sc[4] = (double)maxiter;
+    if (stats) { stats[2 * blockIdx.y] = *c.nv; stats[2 * blockIdx.y + 1] = (int)c.sc[4]; }
+  }
+  if (n_out || m_out) {                                                       // debug copies of the bistochastisation vectors
+    n_src = ws_img(n_src, bt); m_src = ws_img(m_src, bt);
+    for (int v = threadIdx.x; v < *c.nv; v += blockDim.x) {
+      if (n_out) n_out[(size_t)blockIdx.y * bt.dbg + v] = n_src[v];
+      if (m_out) m_out[(size_t)blockIdx.y * bt.dbg + v] = m_src[v];
+    }
+  }
 }
 
-__global__ __launch_bounds__(256) void bg_slice_kernel(const double* y, const int* pix2v, long N, double* out) {   // S^T y
+__global__ __launch_bounds__(256) void bg_slice_kernel(const double* y, const int* pix2v, long N, double* out, BgBatch bt) {   // S^T y
+  y = ws_img(y, bt); pix2v = ws_img(pix2v, bt);
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p < N) out[p] = y[pix2v[p]];
+  if (p < N) out[(size_t)blockIdx.y * bt.N + p] = y[pix2v[p]];
 }
 
 // ---- host orchestration -----------------------------------------------------------------------------------------
@@ -324,7 +436,7 @@ static BgDims bg_dims(int H, int W, double ss, double sl, double sc) {
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BgLayout {
-  size_t bitmap, wprefix, blocksum, cell, pix2v, vcell, nbr, dbl, part, sc, nv, total;
+  size_t bitmap, wprefix, blocksum, cell, pix2v, vcell, nbr, ints, dbl, part, sc, nv, total;
   long nwords; int nscan; long Vmax; int nblocks;
 };
 static BgLayout bg_layout(int H, int W, const BgDims& d) {
@@ -342,11 +454,12 @@ static BgLayout bg_layout(int H, int W, const BgDims& d) {
   L.pix2v = o; o += al((size_t)N * 4);
   L.vcell = o; o += al((size_t)L.Vmax * 4);
   L.nbr = o; o += al((size_t)L.Vmax * 40);
+  L.ints = o; o += al((size_t)L.Vmax * 4) * 2 + 256;  // cnt_i, tsum_i, nonbinary flag
   L.dbl = o; o += al((size_t)L.Vmax * 8) * 13;      // cnt, wsplat, bsplat, nA, nB, m, minv, x, r, z, p, q, spare
   L.part = o; o += al((size_t)L.nblocks * 8 * 3);
   L.sc = o; o += 256;
   L.nv = o; o += 256;
-  L.total = o;
+  L.total = al(o);
   return L;
 }
 
@@ -361,31 +474,34 @@ extern "C" int zh_bgrid_coords(const unsigned char* rgb, int H, int W, double si
                                int* coords, hipStream_t stream) {
   ZH_CHECK_ARG(rgb && coords && H > 0 && W > 0, "zh_bgrid_coords: bad arguments");
   BgDims d = bg_dims(H, W, sigma_spatial, sigma_luma, sigma_chroma);
+  const BgBatch bt{0, (long)H * W, 0};
   hipLaunchKernelGGL(bg_cells_kernel, dim3(zh_cdiv((long)H * W, 256)), dim3(256), 0, stream, rgb, H, W, sigma_spatial, sigma_luma,
-                     sigma_chroma, d, (int*)nullptr, (u64*)nullptr, coords);
+                     sigma_chroma, d, (int*)nullptr, (u64*)nullptr, coords, bt);
   ZH_CHECK_LAUNCH("zh_bgrid_coords");
   return ZH_OK;
 }
 
-// Whole solver for one image and one channel.  target: u8 [H,W] (target_u8) or f64 [H,W] (target_f64), exactly one non-NULL.
-// out_soft f64 [H,W].  stats (device, may be NULL): int32 [2] = {nvertices, cg iterations}.  Optional debug outputs
-// (device, may be NULL): n_out / m_out f64 [>= nvertices].
-extern "C" int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8, const double* target_f64, int H, int W,
-                                  double sigma_spatial, double sigma_luma, double sigma_chroma, double confidence, double lam,
-                                  double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
-                                  double* n_out, double* m_out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  ZH_CHECK_ARG(rgb && out_soft && H > 0 && W > 0, "zh_bilateral_solve: bad arguments");
+// Whole solver for a batch of B images of one size, one channel each.  rgb u8 [B,H,W,3]; target u8 [B,H,W] (target_u8) or f64
+// [B,H,W] (target_f64), exactly one non-NULL; out_soft f64 [B,H,W].  stats (device, may be NULL): int32 [B,2] = {nvertices,
+// cg iterations}.  Optional debug outputs (device, may be NULL): n_out / m_out f64 [B, H*W] (first nvertices entries of
+// each row).  workspace: B * zh_bilateral_workspace_size(H, W, ...) bytes.
+extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned char* target_u8, const double* target_f64, int B, int H,
+                                        int W, double sigma_spatial, double sigma_luma, double sigma_chroma, double confidence,
+                                        double lam, double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
+                                        double* n_out, double* m_out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  ZH_CHECK_ARG(rgb && out_soft && B > 0 && B < 65536 && H > 0 && W > 0, "zh_bilateral_solve: bad arguments");
   ZH_CHECK_ARG((target_u8 != nullptr) != (target_f64 != nullptr), "zh_bilateral_solve: pass exactly one of target_u8 / target_f64");
   ZH_CHECK_ARG(sigma_spatial > 0 && sigma_luma > 0 && sigma_chroma > 0 && cg_maxiter >= 0, "zh_bilateral_solve: bad parameters");
   const BgDims d = bg_dims(H, W, sigma_spatial, sigma_luma, sigma_chroma);
   ZH_CHECK_ARG(d.cells < (1L << 31), "zh_bilateral_solve: lattice too large (%ld cells)", d.cells);
   const BgLayout L = bg_layout(H, W, d);
-  if (!workspace || workspace_bytes < L.total) {
-    zh_set_error("zh_bilateral_solve: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+  if (!workspace || workspace_bytes < L.total * (size_t)B) {
+    zh_set_error("zh_bilateral_solve: workspace too small (%zu < %zu)", workspace_bytes, L.total * (size_t)B);
     return ZH_ERR_WORKSPACE;
   }
   char* ws = (char*)workspace;
   const long N = (long)H * W;
+  const BgBatch bt{L.total, N, N};
   u64* bitmap = (u64*)(ws + L.bitmap);
   unsigned* wprefix = (unsigned*)(ws + L.wprefix);
   unsigned* blocksum = (unsigned*)(ws + L.blocksum);
@@ -393,6 +509,10 @@ extern "C" int zh_bilateral_solve(const unsigned char* rgb, const unsigned char*
   int* pix2v = (int*)(ws + L.pix2v);
   int* vcell = (int*)(ws + L.vcell);
   int* nbr = (int*)(ws + L.nbr);
+  const size_t istride = al((size_t)L.Vmax * 4);
+  unsigned* cnt_i = (unsigned*)(ws + L.ints);
+  unsigned* tsum_i = (unsigned*)(ws + L.ints + istride);
+  unsigned* nonbin = (unsigned*)(ws + L.ints + 2 * istride);
   const size_t dstride = al((size_t)L.Vmax * 8);
   double* D[13];
   for (int i = 0; i < 13; ++i) D[i] = (double*)(ws + L.dbl + dstride * i);
@@ -401,43 +521,67 @@ extern "C" int zh_bilateral_solve(const unsigned char* rgb, const unsigned char*
   double* sc = (double*)(ws + L.sc);
   int* nv = (int*)(ws + L.nv);
 
-  (void)hipMemsetAsync(bitmap, 0, (size_t)L.nwords * 8, stream);
-  (void)hipMemsetAsync(ws + L.dbl, 0, dstride * 3, stream);                    // cnt, wsplat, bsplat
-  (void)hipMemsetAsync(sc, 0, 256, stream);
-  const dim3 blk(256), gN(zh_cdiv(N, 256)), gV(L.nblocks);
-  hipLaunchKernelGGL(bg_cells_kernel, gN, blk, 0, stream, rgb, H, W, sigma_spatial, sigma_luma, sigma_chroma, d, cell, bitmap, (int*)nullptr);
-  hipLaunchKernelGGL(bg_scan_block_sums, dim3(L.nscan), blk, 0, stream, bitmap, L.nwords, blocksum);
-  hipLaunchKernelGGL(bg_scan_top, dim3(1), dim3(1), 0, stream, blocksum, L.nscan, nv);
-  hipLaunchKernelGGL(bg_scan_write, dim3(L.nscan), blk, 0, stream, bitmap, L.nwords, blocksum, wprefix);
-  hipLaunchKernelGGL(bg_assign_kernel, gN, blk, 0, stream, cell, bitmap, wprefix, N, target_u8, target_f64, confidence, pix2v, cnt, wsplat, bsplat);
-  hipLaunchKernelGGL(bg_vertices_kernel, dim3(zh_cdiv(L.nwords, 256)), blk, 0, stream, bitmap, wprefix, L.nwords, vcell);
-  hipLaunchKernelGGL(bg_neighbors_kernel, gV, blk, 0, stream, vcell, bitmap, wprefix, nv, d, nbr);
+  for (int b = 0; b < B; ++b) {                                                  // bitmaps, integer splats, scalars
+    char* wb = ws + (size_t)b * L.total;
+    (void)hipMemsetAsync(wb + L.bitmap, 0, (size_t)L.nwords * 8, stream);
+    (void)hipMemsetAsync(wb + L.ints, 0, 2 * istride + 256, stream);
+    (void)hipMemsetAsync(wb + L.sc, 0, 256, stream);
+  }
+  const dim3 blk(256), gN(zh_cdiv(N, 256), B), gV(L.nblocks, B), g1(1, B);
+  hipLaunchKernelGGL(bg_cells_kernel, gN, blk, 0, stream, rgb, H, W, sigma_spatial, sigma_luma, sigma_chroma, d, cell, bitmap, (int*)nullptr, bt);
+  hipLaunchKernelGGL(bg_scan_block_sums, dim3(L.nscan, B), blk, 0, stream, bitmap, L.nwords, blocksum, bt);
+  hipLaunchKernelGGL(bg_scan_top, g1, blk, 0, stream, blocksum, L.nscan, nv, bt);
+  hipLaunchKernelGGL(bg_scan_write, dim3(L.nscan, B), blk, 0, stream, bitmap, L.nwords, blocksum, wprefix, bt);
+  hipLaunchKernelGGL(bg_assign_kernel, gN, blk, 0, stream, cell, bitmap, wprefix, N, target_u8, pix2v, cnt_i, tsum_i, nonbin, bt);
+  hipLaunchKernelGGL(bg_vertices_kernel, dim3(zh_cdiv(L.nwords, 256), B), blk, 0, stream, bitmap, wprefix, L.nwords, vcell, bt);
+  hipLaunchKernelGGL(bg_neighbors_kernel, gV, blk, 0, stream, vcell, bitmap, wprefix, nv, d, nbr, bt);
+  hipLaunchKernelGGL(bg_splat_final_kernel, gV, blk, 0, stream, cnt_i, tsum_i, nonbin, pix2v, vcell, nv, target_u8, target_f64, H, W,
+                     sigma_spatial, d, confidence, cnt, wsplat, bsplat, bt);
   // bistochastise: n = 1; 10x n = sqrt(n*m0/blur(n)); m = n*blur(n)
-  hipLaunchKernelGGL(bg_fill_kernel, gV, blk, 0, stream, nA, 1.0, nv);
+  hipLaunchKernelGGL(bg_fill_kernel, gV, blk, 0, stream, nA, 1.0, nv, bt);
   double *ncur = nA, *nnext = nB;
   for (int i = 0; i < 10; ++i) {
-    hipLaunchKernelGGL(bg_bisto_step, gV, blk, 0, stream, ncur, cnt, nbr, nv, nnext);
+    hipLaunchKernelGGL(bg_bisto_step, gV, blk, 0, stream, ncur, cnt, nbr, nv, nnext, bt);
     double* t = ncur; ncur = nnext; nnext = t;
   }
-  hipLaunchKernelGGL(bg_bisto_final, gV, blk, 0, stream, ncur, nbr, nv, m);
-  if (n_out) (void)hipMemcpyAsync(n_out, ncur, (size_t)L.Vmax * 8, hipMemcpyDeviceToDevice, stream);   // room for H*W doubles
-  if (m_out) (void)hipMemcpyAsync(m_out, m, (size_t)L.Vmax * 8, hipMemcpyDeviceToDevice, stream);
+  hipLaunchKernelGGL(bg_bisto_final, gV, blk, 0, stream, ncur, nbr, nv, m, bt);
   // PCG
   CgPtrs c;
   c.n = ncur; c.m = m; c.wsplat = wsplat; c.b = bsplat; c.nbr = nbr; c.nv = nv;
   c.minv = D[6]; c.x = D[7]; c.r = D[8]; c.z = D[9]; c.p = D[10]; c.q = D[11];
   c.part_rz = part; c.part_rr = part + (size_t)L.nblocks; c.part_pq = part + 2 * (size_t)L.nblocks; c.sc = sc;
-  c.lam = lam; c.a_diag_min = a_diag_min; c.rtol = cg_tol; c.nblocks = L.nblocks;
-  hipLaunchKernelGGL(cg_y0_kernel, gV, blk, 0, stream, c);
-  hipLaunchKernelGGL(cg_init_kernel, gV, blk, 0, stream, c);
-  hipLaunchKernelGGL(cg_atol_kernel, dim3(1), blk, 0, stream, c);
+  c.lam = lam; c.a_diag_min = a_diag_min; c.rtol = cg_tol;
+  hipLaunchKernelGGL(cg_y0_kernel, gV, blk, 0, stream, c, bt);
+  hipLaunchKernelGGL(cg_init_kernel, gV, blk, 0, stream, c, bt);
+  hipLaunchKernelGGL(cg_atol_kernel, g1, blk, 0, stream, c, bt);
   for (int it = 0; it < cg_maxiter; ++it) {
-    hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it);
-    hipLaunchKernelGGL(cg_matvec_kernel, gV, blk, 0, stream, c);
-    hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it);
+    hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it, bt);
+    hipLaunchKernelGGL(cg_matvec_kernel, gV, blk, 0, stream, c, bt);
+    hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it, bt);
   }
-  hipLaunchKernelGGL(bg_slice_kernel, gN, blk, 0, stream, c.x, pix2v, N, out_soft);
-  hipLaunchKernelGGL(cg_finish_kernel, dim3(1), dim3(1), 0, stream, c, cg_maxiter, stats);
+  hipLaunchKernelGGL(bg_slice_kernel, gN, blk, 0, stream, c.x, pix2v, N, out_soft, bt);
+  hipLaunchKernelGGL(cg_finish_kernel, g1, blk, 0, stream, c, cg_maxiter, stats, ncur, m, n_out, m_out, bt);
   ZH_CHECK_LAUNCH("zh_bilateral_solve");
+  return ZH_OK;
+}
+
+// One image (the reference's call, utils/bilateral_solver.py:152-195): the batch entry with B = 1.
+extern "C" int zh_bilateral_solve(const unsigned char* rgb, const unsigned char* target_u8, const double* target_f64, int H, int W,
+                                  double sigma_spatial, double sigma_luma, double sigma_chroma, double confidence, double lam,
+                                  double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
+                                  double* n_out, double* m_out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return zh_bilateral_solve_batch(rgb, target_u8, target_f64, 1, H, W, sigma_spatial, sigma_luma, sigma_chroma, confidence, lam, a_diag_min,
+                                  cg_tol, cg_maxiter, out_soft, stats, n_out, m_out, workspace, workspace_bytes, stream);
+}
+
+// ---- output_solver > 0.5 (selfmask.py:231, bilateral_solver.py:185) on the device: f64 -> u8 {0,1}
+__global__ __launch_bounds__(256) void threshold_f64_kernel(const double* x, double thr, unsigned char* out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = x[i] > thr ? 1 : 0;
+}
+extern "C" int zh_threshold_f64_u8(const double* x, double threshold, unsigned char* out, long n, hipStream_t stream) {
+  ZH_CHECK_ARG(x && out && n > 0, "zh_threshold_f64_u8: bad arguments");
+  hipLaunchKernelGGL(threshold_f64_kernel, dim3(zh_cdiv(n, 256)), dim3(256), 0, stream, x, threshold, out, n);
+  ZH_CHECK_LAUNCH("zh_threshold_f64_u8");
   return ZH_OK;
 }

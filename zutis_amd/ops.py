@@ -397,23 +397,40 @@ def bgrid_coords(rgb_u8, sigma_spatial=16, sigma_luma=16, sigma_chroma=8):
 def bilateral_solve(rgb_u8, target, sigma_spatial=16, sigma_luma=16, sigma_chroma=8, confidence=0.999, lam=256.0,
                     a_diag_min=1e-5, cg_tol=1e-5, cg_maxiter=25, debug=False):
     """rgb u8 [H,W,3] + target u8|f64 [H,W] (device) -> soft f64 [H,W] (device), stats int32 [2] (device)
-    [, n, m f64 [H*W] when debug]."""
+    [, n, m f64 [H*W] when debug].  A batch ([B,H,W,3] + [B,H,W]) returns [B,H,W], [B,2] (, [B,H*W] x 2): one sequence of
+    launches for all B images."""
     L = _lib.load()
-    H, W, _ = rgb_u8.shape
-    _chk(rgb_u8, torch.uint8, "rgb")
-    assert target.shape == (H, W) and target.is_contiguous() and target.dtype in (torch.uint8, torch.float64)
-    need = L.zh_bilateral_workspace_size(H, W, float(sigma_spatial), float(sigma_luma), float(sigma_chroma))
-    ws = torch.empty(need, dtype=torch.uint8, device=rgb_u8.device)
-    out = torch.empty((H, W), dtype=torch.float64, device=rgb_u8.device)
-    stats = torch.zeros((2,), dtype=torch.int32, device=rgb_u8.device)
-    n = torch.zeros((H * W,), dtype=torch.float64, device=rgb_u8.device) if debug else None
-    m = torch.zeros((H * W,), dtype=torch.float64, device=rgb_u8.device) if debug else None
-    t8 = target if target.dtype == torch.uint8 else None
-    t64 = target if target.dtype == torch.float64 else None
-    _lib.check(L.zh_bilateral_solve(_p(rgb_u8), _p(t8), _p(t64), H, W, float(sigma_spatial), float(sigma_luma), float(sigma_chroma),
-                                    float(confidence), float(lam), float(a_diag_min), float(cg_tol), int(cg_maxiter), _p(out),
-                                    _p(stats), _p(n), _p(m), _p(ws), need, _stream()), "zh_bilateral_solve")
+    batched = rgb_u8.dim() == 4
+    r4 = rgb_u8 if batched else rgb_u8[None]
+    t3 = target if batched else target[None]
+    B, H, W, _ = r4.shape
+    _chk(r4, torch.uint8, "rgb")
+    assert t3.shape == (B, H, W) and t3.is_contiguous() and t3.dtype in (torch.uint8, torch.float64)
+    need = B * L.zh_bilateral_workspace_size(H, W, float(sigma_spatial), float(sigma_luma), float(sigma_chroma))
+    dev = r4.device
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = torch.empty((B, H, W), dtype=torch.float64, device=dev)
+    stats = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    n = torch.zeros((B, H * W), dtype=torch.float64, device=dev) if debug else None
+    m = torch.zeros((B, H * W), dtype=torch.float64, device=dev) if debug else None
+    t8 = t3 if t3.dtype == torch.uint8 else None
+    t64 = t3 if t3.dtype == torch.float64 else None
+    _lib.check(L.zh_bilateral_solve_batch(_p(r4), _p(t8), _p(t64), B, H, W, float(sigma_spatial), float(sigma_luma), float(sigma_chroma),
+                                          float(confidence), float(lam), float(a_diag_min), float(cg_tol), int(cg_maxiter), _p(out),
+                                          _p(stats), _p(n), _p(m), _p(ws), need, _stream()), "zh_bilateral_solve_batch")
+    if not batched:
+        out, stats = out[0], stats[0]
+        n, m = (n[0], m[0]) if debug else (None, None)
     return (out, stats, n, m) if debug else (out, stats)
+
+
+def threshold_f64_u8(x, threshold=0.5):
+    """x f64 (device, contiguous) -> u8 {0,1} of the same shape: x > threshold."""
+    L = _lib.load()
+    _chk(x, torch.float64, "threshold x")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _lib.check(L.zh_threshold_f64_u8(_p(x), float(threshold), _p(out), x.numel(), _stream()), "zh_threshold_f64_u8")
+    return out
 
 
 def select_upsample_mask(obj, masks, out_u8, index, B, Q, h, w, H, W, scale_h, scale_w, threshold=0.5):

@@ -27,7 +27,7 @@ def _device_mask(engine: SelfMaskEngine, image: torch.Tensor, original_size: Opt
     if bilateral_solver:                                                   # selfmask.py:226-234
         rgb = ops.denormalize_u8(image.contiguous())
         soft, _ = ops.bilateral_solve(rgb, dt.contiguous())
-        dt = (soft > 0.5).to(torch.uint8)                                  # comparison on the device result
+        dt = ops.threshold_f64_u8(soft, 0.5)                               # `> 0.5` on the device result
     if original_size is not None and tuple(original_size) != tuple(dt.shape):
         dt = ops.resize_nearest_u8(dt.contiguous(), int(original_size[0]), int(original_size[1]))   # index_dataset.py:215
     return dt
@@ -40,6 +40,28 @@ def pseudo_mask(engine: SelfMaskEngine, image: torch.Tensor, original_size: Opti
     return _device_mask(engine, image, original_size, bilateral_solver).cpu().numpy()
 
 
+@torch.no_grad()
+def pseudo_masks_batch(engine: SelfMaskEngine, images: torch.Tensor, original_sizes: Optional[Sequence[Tuple[int, int]]] = None,
+                       bilateral_solver: bool = True) -> List[torch.Tensor]:
+    """B images of ONE size in one pass (the reference loops batch 1, index_dataset.py:189-204): images f32 [B,3,H,W] on the
+    GPU -> list of B uint8 {0,1} masks on the GPU.  SelfMask runs batched; the bilateral solver's ~110 launches are shared by
+    the whole batch (zh_bilateral_solve_batch, blockIdx.y = image) — for one image it is launch/latency-bound."""
+    B = images.shape[0]
+    out = engine.forward(images.contiguous(), inference=True)
+    dts = out["dts"]                                                       # u8 [B,H,W]
+    if bilateral_solver:
+        rgb = torch.stack([ops.denormalize_u8(images[b].contiguous()) for b in range(B)])
+        soft, _ = ops.bilateral_solve(rgb, dts.contiguous())
+        dts = ops.threshold_f64_u8(soft, 0.5)
+    masks = []
+    for b in range(B):
+        dt = dts[b]
+        if original_sizes is not None and tuple(original_sizes[b]) != tuple(dt.shape):
+            dt = ops.resize_nearest_u8(dt.contiguous(), int(original_sizes[b][0]), int(original_sizes[b][1]))
+        masks.append(dt)
+    return masks
+
+
 def save_rle_json(mask: np.ndarray, path: str) -> Dict:
     """index_dataset.py:219-224: RLE-encode (Fortran order), dump as JSON (counts as str, like ujson reject_bytes=False),
     read back and assert the round trip."""
@@ -50,6 +72,23 @@ def save_rle_json(mask: np.ndarray, path: str) -> Dict:
     back = json.load(open(path))
     assert (rle.decode(back) == mask).sum() == mask.size
     return r
+
+
+@torch.no_grad()
+def generate_pseudo_masks_batched(engine: SelfMaskEngine, images: Sequence[torch.Tensor], original_sizes: Sequence[Tuple[int, int]],
+                                  out_paths: Sequence[str], bilateral_solver: bool = True, batch_size: int = 8) -> List[str]:
+    """generate_pseudo_masks with images grouped by shape (consecutive images of one H x W, up to batch_size) so that SelfMask
+    and the solver run batched.  Output files are identical to the batch-1 path (tests/test_bilateral_gpu.py)."""
+    i, n = 0, len(images)
+    while i < n:
+        j = i + 1
+        while j < n and j - i < batch_size and images[j].shape == images[i].shape:
+            j += 1
+        masks = pseudo_masks_batch(engine, torch.stack(list(images[i:j])), original_sizes[i:j], bilateral_solver)
+        for m, path in zip(masks, out_paths[i:j]):
+            save_rle_json(m.cpu().numpy(), path)
+        i = j
+    return list(out_paths)
 
 
 @torch.no_grad()
