@@ -88,22 +88,49 @@ __device__ __forceinline__ void yuv_bins(unsigned char R, unsigned char G, unsig
   l = (int)(Y / sl); u = (int)(U / sc); v = (int)(V / sc);
 }
 
+// Runs of equal keys inside a wave (consecutive pixels of a row mostly share their lattice cell: 16 pixels per spatial
+// cell, smooth colour): lane `l` is a run leader when its key differs from lane l-1's; returns the run length for leaders
+// (0 for the other lanes) and the mask of the run's lanes.  One atomic per run instead of one per pixel — the per-pixel
+// form spent ~0.9 ms per 8 images hammering the same 64-bit words / counters.
+__device__ __forceinline__ int wave_run(int key, int lane, u64& run_mask) {
+  const int prev = __shfl_up(key, 1, 64);
+  const bool leader = lane == 0 || key != prev;
+  const u64 lm = __ballot(leader);
+  const u64 above = lane == 63 ? 0ull : (lm & ~((2ull << lane) - 1ull));
+  const int next = above ? __ffsll((long long)above) - 1 : 64;
+  const u64 upto = next == 64 ? ~0ull : ((1ull << next) - 1ull);
+  run_mask = upto & ~((1ull << lane) - 1ull);
+  return leader ? next - lane : 0;
+}
+
 __global__ __launch_bounds__(256) void bg_cells_kernel(const unsigned char* rgb, int H, int W, double ss, double sl, double sc,
                                                        BgDims dm, int* cell, u64* bitmap, int* coords_out, BgBatch bt) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= (long)H * W) return;
+  const bool valid = p < (long)H * W;
   rgb += (size_t)blockIdx.y * bt.N * 3;
-  const int y = (int)(p / W), x = (int)(p - (long)y * W);
-  int l, u, v;
-  yuv_bins(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2], sl, sc, l, u, v);
-  const int cx = (int)((double)x / ss), cy = (int)((double)y / ss);
-  if (coords_out) { int* c = coords_out + 5 * ((size_t)blockIdx.y * bt.N + p); c[0] = cx; c[1] = cy; c[2] = l; c[3] = u; c[4] = v; }
-  if (cell) {
-    cell = ws_img(cell, bt); bitmap = ws_img(bitmap, bt);
-    l = min(l, dm.Nl - 1); u = min(u, dm.Nu - 1); v = min(v, dm.Nv - 1);
-    const long id = ((((long)v * dm.Nu + u) * dm.Nl + l) * dm.Ny + cy) * dm.Nx + cx;
-    cell[p] = (int)id;
-    atomicOr(&bitmap[id >> 6], 1ull << (id & 63));
+  int key = -1 - (int)(threadIdx.x & 63);                       // invalid lanes: unique keys, never a run with a neighbour
+  long id = 0;
+  if (valid) {
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    int l, u, v;
+    yuv_bins(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2], sl, sc, l, u, v);
+    const int cx = (int)((double)x / ss), cy = (int)((double)y / ss);
+    if (coords_out) { int* c = coords_out + 5 * ((size_t)blockIdx.y * bt.N + p); c[0] = cx; c[1] = cy; c[2] = l; c[3] = u; c[4] = v; }
+    if (cell) {
+      l = min(l, dm.Nl - 1); u = min(u, dm.Nu - 1); v = min(v, dm.Nv - 1);
+      id = ((((long)v * dm.Nu + u) * dm.Nl + l) * dm.Ny + cy) * dm.Nx + cx;
+      key = (int)id;
+    }
+  }
+  if (!cell) return;                                            // block-uniform
+  cell = ws_img(cell, bt); bitmap = ws_img(bitmap, bt);
+  if (valid) cell[p] = (int)id;
+  u64 rm;
+  const int run = wave_run(key, threadIdx.x & 63, rm);
+  if (valid && run > 0) {
+    const u64 bit = 1ull << (id & 63);
+    // idempotent: skip the atomic when the bit is already visible (a stale 0 only costs a redundant OR)
+    if (!(__hip_atomic_load(&bitmap[id >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&bitmap[id >> 6], bit);
   }
 }
 
@@ -173,20 +200,40 @@ __global__ __launch_bounds__(256) void bg_assign_kernel(const int* cell, const u
                                                         const unsigned char* t_u8, int* pix2v, unsigned* cnt_i, unsigned* tsum_i,
                                                         unsigned* nonbinary, BgBatch bt) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= N) return;
+  const bool valid = p < N;
+  const int lane = threadIdx.x & 63;
   cell = ws_img(cell, bt); bitmap = ws_img(bitmap, bt); wprefix = ws_img(wprefix, bt); pix2v = ws_img(pix2v, bt);
   cnt_i = ws_img(cnt_i, bt); tsum_i = ws_img(tsum_i, bt); nonbinary = ws_img(nonbinary, bt);
-  const int id = cell[p];
-  const u64 w = bitmap[id >> 6];
-  const int v = (int)(wprefix[id >> 6] + __popcll(w & ((1ull << (id & 63)) - 1ull)));
-  pix2v[p] = v;
-  atomicAdd(&cnt_i[v], 1u);
+  int v = -1 - lane;
+  unsigned t = 0;
+  if (valid) {
+    const int id = cell[p];
+    const u64 w = bitmap[id >> 6];
+    v = (int)(wprefix[id >> 6] + __popcll(w & ((1ull << (id & 63)) - 1ull)));
+    pix2v[p] = v;
+    if (t_u8) t = t_u8[(size_t)blockIdx.y * bt.N + p];
+  }
+  // one integer atomic per run of equal vertices (integer sums: the grouping cannot change the result)
+  u64 rm;
+  const int run = wave_run(v, lane, rm);
+  const u64 ones = __ballot(t != 0), big = __ballot(t > 1);
+  if (valid && run > 0) atomicAdd(&cnt_i[v], (unsigned)run);
   if (t_u8) {
-    const unsigned t = t_u8[(size_t)blockIdx.y * bt.N + p];
-    if (t) atomicAdd(&tsum_i[v], t);
-    if (t > 1) atomicOr(nonbinary, 1u);
+    if (big == 0) {                                              // wave-uniform: binary targets in this wave
+      const int k = __popcll(ones & rm);
+      if (valid && run > 0 && k) atomicAdd(&tsum_i[v], (unsigned)k);
+    } else {
+      if (valid && t) atomicAdd(&tsum_i[v], t);
+      if (lane == 0) atomicOr(nonbinary, 1u);
+    }
   }
 }
+
+// Vertex kernels are launched with a FIXED grid (VGRID blocks per image) and walk the 256-vertex blocks that actually exist
+// (ceil(nv / 256), known only on the device): the worst case (one vertex per pixel) would need H*W/256 blocks per image and
+// a typical image fills ~6 % of them — the idle blocks were most of the dispatch cost of every launch.
+#define VGRID 192
+#define FOR_VERTEX_BLOCKS(vb, nvp) for (int vb = blockIdx.x, vb##_n = (*(nvp) + 255) >> 8; vb < vb##_n; vb += gridDim.x)
 
 // ---- K4/K5: vertex -> cell, neighbour table (get_valid_idx, bilateral_solver.py:29-37,69-81)
 __global__ __launch_bounds__(256) void bg_vertices_kernel(const u64* bitmap, const unsigned* wprefix, long nwords, int* vcell, BgBatch bt) {
@@ -204,8 +251,9 @@ __global__ __launch_bounds__(256) void bg_vertices_kernel(const u64* bitmap, con
 __global__ __launch_bounds__(256) void bg_neighbors_kernel(const int* vcell, const u64* bitmap, const unsigned* wprefix, const int* nv,
                                                            BgDims dm, int* nbr, BgBatch bt) {
   vcell = ws_img(vcell, bt); bitmap = ws_img(bitmap, bt); wprefix = ws_img(wprefix, bt); nv = ws_img(nv, bt); nbr = ws_img(nbr, bt);
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= *nv) return;
+  FOR_VERTEX_BLOCKS(vb, nv) {
+  const int v = vb * 256 + threadIdx.x;
+  if (v >= *nv) continue;
   const long id = vcell[v];
   long r = id;
   int c[5];
@@ -227,6 +275,7 @@ __global__ __launch_bounds__(256) void bg_neighbors_kernel(const int* vcell, con
       }
       nbr[v * 10 + 2 * d + s] = out;
     }
+  }
 }
 
 // ---- splat finalisation, one thread per vertex: the float64 sums SciPy's CSR matvec forms, in its order.
@@ -240,8 +289,9 @@ __global__ __launch_bounds__(256) void bg_splat_final_kernel(const unsigned* cnt
                                                              double* cnt, double* wsplat, double* bsplat, BgBatch bt) {
   cnt_i = ws_img(cnt_i, bt); tsum_i = ws_img(tsum_i, bt); nonbinary = ws_img(nonbinary, bt); pix2v = ws_img(pix2v, bt);
   vcell = ws_img(vcell, bt); nv = ws_img(nv, bt); cnt = ws_img(cnt, bt); wsplat = ws_img(wsplat, bt); bsplat = ws_img(bsplat, bt);
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= *nv) return;
+  FOR_VERTEX_BLOCKS(vb, nv) {
+  const int v = vb * 256 + threadIdx.x;
+  if (v >= *nv) continue;
   const unsigned k = cnt_i[v];
   cnt[v] = (double)k;
   double sw = 0.0;
@@ -264,21 +314,25 @@ __global__ __launch_bounds__(256) void bg_splat_final_kernel(const unsigned* cnt
       }
   }
   bsplat[v] = sb;
+  }
 }
 
 // ---- bistochastisation (bilateral_solver.py:107-118)
 __global__ __launch_bounds__(256) void bg_bisto_step(const double* n_in, const double* m0, const int* nbr, const int* nv, double* n_out, BgBatch bt) {
   n_in = ws_img(n_in, bt); m0 = ws_img(m0, bt); nbr = ws_img(nbr, bt); nv = ws_img(nv, bt); n_out = ws_img(n_out, bt);
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= *nv) return;
-  const double nvv = n_in[v];
-  n_out[v] = sqrt(nvv * m0[v] / blur_gather(n_in, nbr + v * 10, nvv));
+  FOR_VERTEX_BLOCKS(vb, nv) {
+    const int v = vb * 256 + threadIdx.x;
+    if (v >= *nv) continue;
+    const double nvv = n_in[v];
+    n_out[v] = sqrt(nvv * m0[v] / blur_gather(n_in, nbr + v * 10, nvv));
+  }
 }
 __global__ __launch_bounds__(256) void bg_bisto_final(const double* n, const int* nbr, const int* nv, double* m, BgBatch bt) {
   n = ws_img(n, bt); nbr = ws_img(nbr, bt); nv = ws_img(nv, bt); m = ws_img(m, bt);
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= *nv) return;
-  m[v] = n[v] * blur_gather(n, nbr + v * 10, n[v]);
+  FOR_VERTEX_BLOCKS(vb, nv) {
+    const int v = vb * 256 + threadIdx.x;
+    if (v < *nv) m[v] = n[v] * blur_gather(n, nbr + v * 10, n[v]);
+  }
 }
 
 // ---- PCG (scipy.sparse.linalg.cg semantics, Jacobi preconditioner; bilateral_solver.py:133-147)
@@ -321,32 +375,37 @@ __device__ __forceinline__ double sum_partials(const double* part, int nb, doubl
 
 __global__ __launch_bounds__(256) void bg_fill_kernel(double* x, double val, const int* nv, BgBatch bt) {
   x = ws_img(x, bt); nv = ws_img(nv, bt);
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v < *nv) x[v] = val;
+  FOR_VERTEX_BLOCKS(vb, nv) {
+    const int v = vb * 256 + threadIdx.x;
+    if (v < *nv) x[v] = val;
+  }
 }
 __global__ __launch_bounds__(256) void cg_y0_kernel(CgPtrs c0, BgBatch bt) {          // flat initialisation y0 = splat(xw) / splat(w)
   const CgPtrs c = cg_img(c0, bt);
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v < *c.nv) c.x[v] = c.b[v] / c.wsplat[v];
+  FOR_VERTEX_BLOCKS(vb, c.nv) {
+    const int v = vb * 256 + threadIdx.x;
+    if (v < *c.nv) c.x[v] = c.b[v] / c.wsplat[v];
+  }
 }
 __global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c0, BgBatch bt) {
   __shared__ double red[4];
   const CgPtrs c = cg_img(c0, bt);
-  if ((int)blockIdx.x >= cg_active_blocks(c)) return;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  double rz = 0.0, rr = 0.0, bb = 0.0;
-  if (v < *c.nv) {
-    const double diag = c.lam * (c.m[v] - c.n[v] * 10.0 * c.n[v]) + c.wsplat[v];
-    const double mi = 1.0 / fmax(diag, c.a_diag_min);
-    c.minv[v] = mi;
-    const double r = c.b[v] - matvec_row(c, c.x, v);
-    c.r[v] = r;
-    const double z = mi * r;
-    c.z[v] = z;
-    rz = r * z; rr = r * r; bb = c.b[v] * c.b[v];
+  FOR_VERTEX_BLOCKS(vb, c.nv) {
+    const int v = vb * 256 + threadIdx.x;
+    double rz = 0.0, rr = 0.0, bb = 0.0;
+    if (v < *c.nv) {
+      const double diag = c.lam * (c.m[v] - c.n[v] * 10.0 * c.n[v]) + c.wsplat[v];
+      const double mi = 1.0 / fmax(diag, c.a_diag_min);
+      c.minv[v] = mi;
+      const double r = c.b[v] - matvec_row(c, c.x, v);
+      c.r[v] = r;
+      const double z = mi * r;
+      c.z[v] = z;
+      rz = r * z; rr = r * r; bb = c.b[v] * c.b[v];
+    }
+    const double s1 = block_sum(rz, red), s2 = block_sum(rr, red), s3 = block_sum(bb, red);
+    if (threadIdx.x == 0) { c.part_rz[vb] = s1; c.part_rr[vb] = s2; c.part_pq[vb] = s3; }
   }
-  const double s1 = block_sum(rz, red), s2 = block_sum(rr, red), s3 = block_sum(bb, red);
-  if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = s1; c.part_rr[blockIdx.x] = s2; c.part_pq[blockIdx.x] = s3; }
 }
 __global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c0, BgBatch bt) {        // one block per image: atol = rtol * ||b||
   __shared__ double red[4];
@@ -367,20 +426,24 @@ __global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c0, int it, BgBa
     if (blockIdx.x == 0 && threadIdx.x == 0 && c.sc[3] == 0.0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
     return;
   }
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v < *c.nv) c.p[v] = it == 0 ? c.z[v] : c.z[v] + (rho / c.sc[(it - 1) & 1]) * c.p[v];
+  const double beta = it == 0 ? 0.0 : rho / c.sc[(it - 1) & 1];
+  FOR_VERTEX_BLOCKS(vb, c.nv) {
+    const int v = vb * 256 + threadIdx.x;
+    if (v < *c.nv) c.p[v] = it == 0 ? c.z[v] : c.z[v] + beta * c.p[v];
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;
 }
 __global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c0, BgBatch bt) {
   __shared__ double red[4];
   const CgPtrs c = cg_img(c0, bt);
-  if ((int)blockIdx.x >= cg_active_blocks(c)) return;
   if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  double pq = 0.0;
-  if (v < *c.nv) { const double q = matvec_row(c, c.p, v); c.q[v] = q; pq = c.p[v] * q; }
-  const double s = block_sum(pq, red);
-  if (threadIdx.x == 0) c.part_pq[blockIdx.x] = s;
+  FOR_VERTEX_BLOCKS(vb, c.nv) {
+    const int v = vb * 256 + threadIdx.x;
+    double pq = 0.0;
+    if (v < *c.nv) { const double q = matvec_row(c, c.p, v); c.q[v] = q; pq = c.p[v] * q; }
+    const double s = block_sum(pq, red);
+    if (threadIdx.x == 0) c.part_pq[vb] = s;
+  }
 }
 __global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBatch bt) {
   __shared__ double red[4];
@@ -390,18 +453,20 @@ __global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBat
   if (c.sc[3] != 0.0) return;
   const double pq = sum_partials(c.part_pq, nb, red);
   const double alpha = c.sc[it & 1] / pq;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  double rz = 0.0, rr = 0.0;
-  if (v < *c.nv) {
-    c.x[v] += alpha * c.p[v];
-    const double r = c.r[v] - alpha * c.q[v];
-    c.r[v] = r;
-    const double z = c.minv[v] * r;
-    c.z[v] = z;
-    rz = r * z; rr = r * r;
+  FOR_VERTEX_BLOCKS(vb, c.nv) {
+    const int v = vb * 256 + threadIdx.x;
+    double rz = 0.0, rr = 0.0;
+    if (v < *c.nv) {
+      c.x[v] += alpha * c.p[v];
+      const double r = c.r[v] - alpha * c.q[v];
+      c.r[v] = r;
+      const double z = c.minv[v] * r;
+      c.z[v] = z;
+      rz = r * z; rr = r * r;
+    }
+    const double s1 = block_sum(rz, red), s2 = block_sum(rr, red);
+    if (threadIdx.x == 0) { c.part_rz[vb] = s1; c.part_rr[vb] = s2; }
   }
-  const double s1 = block_sum(rz, red), s2 = block_sum(rr, red);
-  if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = s1; c.part_rr[blockIdx.x] = s2; }
 }
 __global__ void cg_finish_kernel(CgPtrs c0, int maxiter, int* stats, const double* n_src, const double* m_src, double* n_out, double* m_out,
                                  BgBatch bt) {
@@ -527,7 +592,7 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
     (void)hipMemsetAsync(wb + L.ints, 0, 2 * istride + 256, stream);
     (void)hipMemsetAsync(wb + L.sc, 0, 256, stream);
   }
-  const dim3 blk(256), gN(zh_cdiv(N, 256), B), gV(L.nblocks, B), g1(1, B);
+  const dim3 blk(256), gN(zh_cdiv(N, 256), B), gV(L.nblocks < VGRID ? L.nblocks : VGRID, B), g1(1, B);
   hipLaunchKernelGGL(bg_cells_kernel, gN, blk, 0, stream, rgb, H, W, sigma_spatial, sigma_luma, sigma_chroma, d, cell, bitmap, (int*)nullptr, bt);
   hipLaunchKernelGGL(bg_scan_block_sums, dim3(L.nscan, B), blk, 0, stream, bitmap, L.nwords, blocksum, bt);
   hipLaunchKernelGGL(bg_scan_top, g1, blk, 0, stream, blocksum, L.nscan, nv, bt);
