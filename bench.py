@@ -48,6 +48,51 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: 
 FLOPS_PER_IMAGE_C2 = 124.4e9 + 0.146e9  # forward + semantic predict
 
 
+def gemm_roofline(ops, run_once, step_seconds):
+    """HIP events around every GEMM / attention launch of `run_once()` (eager, torch's current stream == launch stream):
+    roofline object for the GEMM family with the larger GPU time; FLOPs are ALGORITHMIC (2*M*N*K per launch)."""
+    prof = {}
+
+    def profiler(name, work, launch):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = launch()
+        e1.record()
+        prof.setdefault(name, []).append((work, e0, e1))
+        return r
+    ops.PROFILER = profiler
+    try:
+        for _ in range(2):
+            prof.clear()
+            run_once()
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    stats = {k: (len(v), sum(w for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
+    g1, g3 = stats.get("gemm_f16", (0, 0.0, 0.0)), stats.get("gemm_f16x3", (0, 0.0, 0.0))
+    dom = "gemm_f16" if g1[2] >= g3[2] else "gemm_f16x3"               # the kernel family with the larger GPU time
+    nl, fl, tt = stats[dom]
+    ach = fl / tt / 1e12
+    roof = {"bound": "mfma", "kernel": "gemm_f16_kernel" + ("<SPLIT=1> (zh_gemm_f16x3)" if dom == "gemm_f16x3" else " (zh_gemm_f16)"),
+            "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+            "traffic": None, "flops_per_launch": round(fl / nl), "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
+            "measured_on": "HIP events around every GEMM launch of an instrumented eager step on one stream (kernels not overlapped)",
+            "gemm_share_of_step": round(tt / step_seconds, 3)}
+    oth = "gemm_f16x3" if dom == "gemm_f16" else "gemm_f16"
+    if oth in stats:
+        no, fo, to = stats[oth]
+        roof["other_gemm"] = {"kernel": oth, "launches_per_step": no, "algorithmic_tflops": round(fo / to / 1e12, 1),
+                              "share_of_step": round(to / step_seconds, 3)}
+    if g3[0]:
+        roof["x3_note"] = "zh_gemm_f16x3 issues three MFMAs per algorithmic product: its MFMA-pipe rate is 3x its algorithmic TFLOP/s"
+    for an in ("attention_f16", "attention_f16x3"):
+        if an in stats:
+            na, fa, ta = stats[an]
+            roof[an + "_tflops"] = round(fa / ta / 1e12, 1)
+            roof[an + "_share_of_step"] = round(ta / step_seconds, 3)
+    return roof
+
+
 def bench_c5(args):
     """Config 5: CLIP ViT-L/14@336 `encode_image` over synthetic batches generated on the device, images sharded by
     rank, no communication until one final all-gather of the last step's embeddings (per-rank shards are the product)."""
@@ -77,7 +122,7 @@ def bench_c5(args):
         P[q + "mlp.c_proj.weight"], P[q + "mlp.c_proj.bias"] = w(q + "p", (D, 4 * D), D ** -0.5 * (2 * L) ** -0.5), w(q + "pb", (D,), 0.02)
         for ln in ("ln_1", "ln_2"):
             P[q + ln + ".weight"], P[q + ln + ".bias"] = w(q + ln + "w", (D,), 0.1, 1.0), w(q + ln + "b", (D,), 0.1)
-    enc = ClipImageEncoder(P, p, prefix="visual.")
+    enc = ClipImageEncoder(P, p, prefix="visual.", precision=args.precision)
     x = torch.randn((B, 3, 336, 336), generator=torch.Generator(device="cpu").manual_seed(2000 + rank)).to(dev)
     for _ in range(max(1, args.warmup)):
         emb = enc.encode_image(x)
@@ -100,6 +145,29 @@ def bench_c5(args):
         elapsed = float(t.item())
     T = g * g + 1
     flop = L * (2 * T * (D * 3 * D + D * D + 2 * D * 4 * D) + 4 * T * T * D) + 2 * g * g * 3 * p * p * D + 2 * D * E
+    roof = cpu = parity = None
+    if rank == 0:
+        roof = gemm_roofline(ops, lambda: enc.encode_image(x), elapsed / args.steps)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import zutis_ref as O
+        torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+        Pc = {k.replace("visual.", "encoder."): v.cpu() for k, v in P.items()}
+        ns = max(1, min(4, B))
+        xs = x[:ns].cpu()
+        with torch.no_grad():
+            O.clip_encode_image(Pc, xs[:1], p)                            # warm-up
+            times = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ref = O.clip_encode_image(Pc, xs, p)
+                times.append(time.perf_counter() - t1)
+        dt = sorted(times)[1]
+        cpu = {"value": round(ns / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{ns} of the {B} step images, oracle encode_image (24-layer ViT-L/14@336), median of 3 passes "
+                         f"({', '.join('%.1f' % t for t in times)} s); host has {os.cpu_count()} hardware threads"}
+        got = enc.encode_image(x[:ns]).cpu()
+        parity = {"embedding_max_abs_err": float((got - ref).abs().max()), "tolerance": 1e-3,
+                  "against": "fp32 oracle on the same %d images (unit-norm embeddings)" % ns}
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
@@ -107,11 +175,12 @@ def bench_c5(args):
         print(json.dumps({
             "metric": "images/sec, CLIP ViT-L/14@336 image-embedding extraction (BASELINE config 5)", "value": round(total / elapsed, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
+            "precision": {"mode": args.precision, "what": PRECISION_TEXT[args.precision]},
             "config": {"workload": f"C5: CLIP ViT-L/14@336 encode_image, {B}x3x336x336 per GPU per step, embeddings fp32 [{B},{E}], "
                                    "one all-gather of the last step's embeddings", "global_batch": world * B, "parallelism": f"dp{world}",
                        "flops_per_image": flop},
-            "model_tflops": round(total * flop / elapsed / 1e12 / world, 1), "roofline": None, "cpu_baseline": None,
+            "model_tflops": round(total * flop / elapsed / 1e12 / world, 1), "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "embedding_norm": round(float(emb.norm(dim=1).mean().item()), 6)}), flush=True)
 
 
@@ -241,56 +310,20 @@ def main():
         other = {"precision": oprec, "eng": oeng, "value": round(B * osteps / odt, 2), "ms_per_step": round(odt / osteps * 1e3, 3), "steps": osteps}
 
     # ---- roofline of the dominant kernel: HIP events (torch current stream == launch stream) around every launch
-    prof = {}
-
-    def profiler(name, work, launch):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = launch()
-        e1.record()
-        prof.setdefault(name, []).append((work, e0, e1))
-        return r
-
     roof = None
     if rank == 0:
-        ops.PROFILER = profiler
-        for i in range(2):
-            prof.clear()
+        def one_eager_step():
             out = eng.forward(x)
             eng.predict_semantic(out["patch_tokens"], text, (S, S))
-        torch.cuda.synchronize()
-        ops.PROFILER = None
-        stats = {k: (len(v), sum(w for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
-        g1, g3 = stats.get("gemm_f16", (0, 0.0, 0.0)), stats.get("gemm_f16x3", (0, 0.0, 0.0))
-        dom = "gemm_f16" if g1[2] >= g3[2] else "gemm_f16x3"               # the kernel family with the larger GPU time
-        nl, fl, tt = stats[dom]                                               # ALGORITHMIC flops (2*M*N*K) of its launches
-        ach = fl / tt / 1e12
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")     # separate rocprofv3 --pmc passes of this command
-        if os.path.exists(pmc) and B == 32 and S == 336:
-            traffic = json.load(open(pmc))["gemm_f16_kernel_all_variants"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction)"
-        roof = {"bound": "mfma", "kernel": "gemm_f16_kernel" + ("<SPLIT=1> (zh_gemm_f16x3)" if dom == "gemm_f16x3" else " (zh_gemm_f16)"),
-                "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": traffic_src, "flops_per_launch": round(fl / nl),
-                "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
-                "measured_on": "HIP events around every GEMM launch of an instrumented eager step on one stream (kernels not "
-                               "overlapped); rocprofv3 --stats of `bench.py --inflight 1` = profiles/r01_bench_kernel_stats.csv, "
-                               "of the default run with steps in flight = profiles/r01_bench_inflight_kernel_stats.csv",
-                "gemm_share_of_step": round(tt / (elapsed / args.steps), 3)}
-        oth = "gemm_f16x3" if dom == "gemm_f16" else "gemm_f16"
-        if oth in stats:                                                      # the other GEMM family of this precision mode
-            no, fo, to = stats[oth]
-            roof["other_gemm"] = {"kernel": oth, "launches_per_step": no, "algorithmic_tflops": round(fo / to / 1e12, 1),
-                                  "share_of_step": round(to / (elapsed / args.steps), 3)}
-        if g3[0]:
-            roof["x3_note"] = "zh_gemm_f16x3 issues three MFMAs per algorithmic product: its MFMA-pipe rate is 3x its algorithmic TFLOP/s"
-        for an in ("attention_f16", "attention_f16x3"):
-            if an in stats:
-                na, fa, ta = stats[an]
-                roof[an + "_tflops"] = round(fa / ta / 1e12, 1)
-                roof[an + "_share_of_step"] = round(ta / (elapsed / args.steps), 3)
+        roof = gemm_roofline(ops, one_eager_step, elapsed / args.steps)
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # separate rocprofv3 --pmc passes of this command
+        if os.path.exists(pmc) and B == 32 and S == 336 and args.precision == "fast":
+            roof["traffic"] = json.load(open(pmc))["gemm_f16_kernel_all_variants"]["hbm_bytes_per_launch"]
+            roof["traffic_source"] = ("profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                      "`bench.py --inflight 1` (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction) — recorded, not "
+                                      "re-measured by this run")
+        roof["measured_on"] += ("; rocprofv3 --stats of `bench.py --inflight 1` = profiles/r02_bench_kernel_stats.csv, of the default "
+                                "run with steps in flight = profiles/r02_bench_inflight_kernel_stats.csv")
 
     # ---- CPU baseline: the oracle (CPU port of the reference path) on a bounded sample, rank 0 at N=1 only
     cpu = None
@@ -299,7 +332,7 @@ def main():
         from oracle import zutis_ref as O
         torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
         Pc = O.to_torch_params(detgen.zutis_state_dict(cfg))
-        ns = max(1, min(args.cpu_sample, B))
+        ns = max(1, min(args.cpu_sample if S <= 336 else 4, B))          # 518 px / 920 classes: ~3 s per image on the host
         xs = x[:ns].cpu()
         tc = text.cpu()
 
