@@ -182,7 +182,7 @@ class _EngineBase:
 
     def _pack_clip_visual(self, w, P, prefix: str, D: int, layers: int, patch: int):
         """CLIP VisionTransformer parameters (clip_arch.py:335-354) -> conv (K padded to 64), enc.{i}.*, ln_pre/ln_post."""
-        h, c32 = self._h, self._c32
+        c32 = self._c32
         kc = 3 * patch * patch
         self.Kc = _rup(kc, 64)
         wc = torch.zeros((D, self.Kc), dtype=f32, device=self._device())
@@ -351,8 +351,7 @@ class ZutisEngine(_EngineBase):
         if key == self._packed_key:
             return
         P, D, w = self.params, self.D, {}
-        dev = self._device()
-        h, c32 = self._h, self._c32
+        c32 = self._c32
         self._pack_clip_visual(w, P, "encoder.", D, self.layers, self.patch)
         for ffn in ("ffn1", "ffn2"):
             for j in range(3):
