@@ -56,7 +56,12 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   //  it stays reachable through ZH_GEMM_TILE=64 for experiments)
   // few-tile GEMMs (batch-1 inference: M = 442 tokens -> 24 tiles of 128x128 on 256 CUs): 64x64 tiles on an 8-deep
   // ring put 4x the CUs to work; measured 32 -> 16 us on the 442x768x3072 MLP projection (tools/gemm_small.py)
-  if ((long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch <= 96) pick = 3064;
+  const long t128 = (long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch;
+  if (t128 <= 96) pick = 3064;
+  // narrow outputs that do not fill the chip with 128 x 128 tiles (decoder M = B*Q rows x N = 768): 128 x 64 tiles put twice the
+  // blocks to work; measured 19.6 -> 16.5 us (K = 768) and 32.7 -> 28.8 us (K = 2048) with the residual epilogue, while
+  // N = 1536 / 2048 keep 128 x 128 (tools/gemm_dec_tiles.py)
+  else if (pick == 128 && t128 <= 256 && N <= 768) pick = 64;
   if (dev.tile) {
     static const int known[] = {64, 128, 192, 256, 1192, 2064, 2128, 3064};
     bool okc = false;
