@@ -213,6 +213,15 @@ def test_selfmask_dropin_module(dev, golden_dir):
     assert isinstance(out["dts"], list) and out["dts"][0].dtype == torch.uint8 and out["dts"][0].device.type == "cpu"
     ref = np.unpackbits(g["small_dts"], axis=-1)[..., :W].astype(bool)
     assert (torch.stack(out["dts"]).numpy().astype(bool) != ref).mean() < 5e-3
+    # bilateral_solver=True (selfmask.py:226-237): "dts_bi" = solver(de-normalised image, dts) > 0.5, here from one batched
+    # device solve; must equal the oracle's NumPy/SciPy solver applied to the module's own dts
+    from oracle import bilateral_ref as B
+    with torch.no_grad():
+        out2 = net(x, inference=True, bilateral_solver=True)
+    assert len(out2["dts_bi"]) == b and out2["dts_bi"][0].dtype == torch.uint8 and out2["dts_bi"][0].device.type == "cpu"
+    for i in range(b):
+        soft, _ = B.bilateral_solver_output(B.denormalize_to_u8(x[i].cpu().numpy()), out2["dts"][i].numpy())
+        assert np.array_equal(out2["dts_bi"][i].numpy().astype(bool), soft > 0.5)
 
 
 @pytest.mark.parametrize("width,layers,patch,grid,embed,B", [(128, 2, 14, 3, 64, 3), (1024, 2, 14, 24, 768, 2)])

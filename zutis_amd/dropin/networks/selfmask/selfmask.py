@@ -121,11 +121,13 @@ class SelfMask(nn.Module):
             return out
         dts_dev = out["dts"]
         dict_outputs: Dict[str, List[torch.Tensor]] = {"dts": [d for d in dts_dev.cpu()]}   # selfmask.py:221-222
-        if bilateral_solver:
-            from utils.bilateral_solver import bilateral_solver_output_from_tensor
-            dts_bi = []
-            for b in range(x.shape[0]):                                                     # selfmask.py:226-234
-                soft, _ = bilateral_solver_output_from_tensor(x[b], dts_dev[b])
-                dts_bi.append(torch.from_numpy(np.clip(soft > 0.5, 0, 1).astype(np.uint8)))
-            dict_outputs["dts_bi"] = dts_bi
+        if bilateral_solver:                                                                # selfmask.py:226-237
+            # One batched device solve for all images (zh_bilateral_solve_batch) instead of the reference's per-image
+            # D2H -> PIL -> NumPy/SciPy round trip; only output 0 of bilateral_solver_output is used there (:230-231), so the
+            # hole-filling / labelling post-processing it also runs (and discards) is not reproduced.
+            from zutis_amd import ops as _ops
+            xf = x.float()
+            rgb = torch.stack([_ops.denormalize_u8(xf[b].contiguous()) for b in range(x.shape[0])])   # utils/utils.py:261-273
+            soft, _ = _ops.bilateral_solve(rgb, dts_dev.contiguous())
+            dict_outputs["dts_bi"] = [d for d in _ops.threshold_f64_u8(soft, 0.5).cpu()]
         return dict_outputs
