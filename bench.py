@@ -48,6 +48,47 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: 
 FLOPS_PER_IMAGE_C2 = 124.4e9 + 0.146e9  # forward + semantic predict
 
 
+def live_pmc_traffic(extra_args, timeout_s=240):
+    """HBM bytes per launch of the plain fp16-operand GEMM kernel, measured NOW: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC block cannot hold both counters; --kernel-trace
+    only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), corrected for gfx950 (FETCH_SIZE tallies 128-B requests at
+    64 B: read bytes = 2 * FETCH_SIZE; WRITE_SIZE exact; both in KiB).  Returns (bytes_per_launch | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tot, cnt = {}, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="zh_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--inflight", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-second-precision",
+               "--no-live-traffic"] + list(extra_args)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout_s, check=True)
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    k = r["Kernel_Name"]
+                    if "gemm_f16_kernel" in k and k.rstrip().endswith(", 0>(GemmArgs)") and r["Counter_Name"] == counter:
+                        tot[counter] = tot.get(counter, 0.0) + float(r["Counter_Value"])
+                        cnt[counter] = cnt.get(counter, 0) + 1
+        except Exception as e:                                   # profiler unavailable / refused: report, never fail the bench
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"live rocprofv3 pass failed ({type(e).__name__})"
+        shutil.rmtree(d, ignore_errors=True)
+    if not cnt.get("FETCH_SIZE") or not cnt.get("WRITE_SIZE"):
+        return None, "no GEMM dispatches in the counter output"
+    fetch = tot["FETCH_SIZE"] / cnt["FETCH_SIZE"] * 1024.0
+    write = tot["WRITE_SIZE"] / cnt["WRITE_SIZE"] * 1024.0
+    return round(2.0 * fetch + write), (f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --inflight 1 --steps 2` run by this "
+                                        f"bench ({cnt['FETCH_SIZE']} launches of the plain GEMM kernel): 2*FETCH_SIZE ({2 * fetch / 1e6:.1f} MB) + WRITE_SIZE "
+                                        f"({write / 1e6:.1f} MB) per launch, gfx950 correction")
+
+
 def gemm_roofline(ops, run_once, step_seconds):
     """HIP events around every GEMM / attention launch of `run_once()` (eager, torch's current stream == launch stream):
     roofline object for the GEMM family with the larger GPU time; FLOPs are ALGORITHMIC (2*M*N*K per launch)."""
@@ -68,14 +109,16 @@ def gemm_roofline(ops, run_once, step_seconds):
         torch.cuda.synchronize()
     finally:
         ops.PROFILER = None
-    stats = {k: (len(v), sum(w for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
+    fl = lambda w: w[0] if isinstance(w, tuple) else w
+    stats = {k: (len(v), sum(fl(w) for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
+    algo_bytes = {k: sum(w[1] for w, _, _ in v if isinstance(w, tuple)) / max(1, len(v)) for k, v in prof.items()}
     g1, g3 = stats.get("gemm_f16", (0, 0.0, 0.0)), stats.get("gemm_f16x3", (0, 0.0, 0.0))
     dom = "gemm_f16" if g1[2] >= g3[2] else "gemm_f16x3"               # the kernel family with the larger GPU time
-    nl, fl, tt = stats[dom]
-    ach = fl / tt / 1e12
+    nl, flops_dom, tt = stats[dom]
+    ach = flops_dom / tt / 1e12
     roof = {"bound": "mfma", "kernel": "gemm_f16_kernel" + ("<SPLIT=1> (zh_gemm_f16x3)" if dom == "gemm_f16x3" else " (zh_gemm_f16)"),
             "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
-            "traffic": None, "flops_per_launch": round(fl / nl), "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
+            "traffic": None, "algorithmic_bytes_per_launch": round(algo_bytes.get(dom, 0.0)), "flops_per_launch": round(flops_dom / nl), "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
             "measured_on": "HIP events around every GEMM launch of an instrumented eager step on one stream (kernels not overlapped)",
             "gemm_share_of_step": round(tt / step_seconds, 3)}
     oth = "gemm_f16x3" if dom == "gemm_f16" else "gemm_f16"
@@ -200,6 +243,7 @@ def main():
     ap.add_argument("--precision", default="fast", choices=["fast", "exact", "f16"],
                     help="engine precision (zutis_amd/engine.py): fast = fp16 MFMA operands in the transformer bodies + the fp32-class "
                          "x3 mode on the output-facing contractions (passes tests/test_precision_gpu.py at 1e-3); exact = x3 everywhere")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--no-second-precision", action="store_true", help="skip the secondary timed run at the other precision (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
@@ -316,12 +360,17 @@ def main():
             out = eng.forward(x)
             eng.predict_semantic(out["patch_tokens"], text, (S, S))
         roof = gemm_roofline(ops, one_eager_step, elapsed / args.steps)
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # separate rocprofv3 --pmc passes of this command
-        if os.path.exists(pmc) and B == 32 and S == 336 and args.precision == "fast":
-            roof["traffic"] = json.load(open(pmc))["gemm_f16_kernel_all_variants"]["hbm_bytes_per_launch"]
-            roof["traffic_source"] = ("profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                      "`bench.py --inflight 1` (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction) — recorded, not "
-                                      "re-measured by this run")
+        if world == 1 and not args.no_live_traffic:
+            extra = ["--precision", args.precision, "--batch", str(B), "--size", str(S), "--classes", str(n)]
+            roof["traffic"], roof["traffic_source"] = live_pmc_traffic(extra)
+        if roof.get("traffic") is None:
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # recorded passes of the same command
+            if os.path.exists(pmc) and B == 32 and S == 336 and args.precision == "fast":
+                roof["traffic"] = json.load(open(pmc))["gemm_f16_kernel_all_variants"]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = (str(roof.get("traffic_source") or "") + "; fell back to profiles/r02_pmc_traffic.json (recorded, all "
+                                          "GEMM variants pooled)").lstrip("; ")
+        if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 2)
         roof["measured_on"] += ("; rocprofv3 --stats of `bench.py --inflight 1` = profiles/r02_bench_kernel_stats.csv, of the default "
                                 "run with steps in flight = profiles/r02_bench_inflight_kernel_stats.csv")
 

@@ -99,6 +99,14 @@ def _hp(a):
     return (a.hi, a.plane) if isinstance(a, Act) else (a, 0)
 
 
+def _gemm_bytes(M, N, K, batch, strideA, strideW, op_bytes, out_bytes, has_residual) -> float:
+    """Compulsory (algorithmic) bytes of one GEMM launch: each operand once (a batch-shared operand once), the output once,
+    the fp32 residual once.  op_bytes = 2 for fp16 operands, 4 for split pairs."""
+    a = M * K * op_bytes * (batch if strideA else 1)
+    w = N * K * op_bytes * (batch if (strideW or batch == 1) else 1)
+    return float(a + w + M * N * batch * (out_bytes + (4 if has_residual else 0)))
+
+
 def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, act: int = ACT_NONE, *, M=None, N=None, K=None,
             lda=None, ldw=None, ldc=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None,
             strideR: int = 0):
@@ -124,7 +132,8 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
         assert bias.dtype == f32 and bias.numel() >= N
     args = (_p(a), lda, strideA, A.plane, _p(w), ldw, strideW, W.plane, _p(o), ldc, strideC, planeC, kind,
             float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream())
-    _lib.check(_launch("gemm_f16x3", 2.0 * M * N * K * batch, lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
+    nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 4, 4 if kind == 0 else (4 if kind == 2 else 2), residual is not None)
+    _lib.check(_launch("gemm_f16x3", (2.0 * M * N * K * batch, nbytes), lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
     return out
 
 
@@ -154,7 +163,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
         assert bias.dtype == f32 and bias.numel() >= N
     args = (_p(A), lda, strideA, _p(W), ldw, strideW, _p(out), ldc, strideC, int(out.dtype == f16),
             _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream())
-    _lib.check(_launch("gemm_f16", 2.0 * M * N * K * batch, lambda: L.zh_gemm_f16(*args)), "zh_gemm_f16")
+    nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 2, 2 if out.dtype == f16 else 4, residual is not None)
+    _lib.check(_launch("gemm_f16", (2.0 * M * N * K * batch, nbytes), lambda: L.zh_gemm_f16(*args)), "zh_gemm_f16")
     return out_ret
 
 
