@@ -100,3 +100,24 @@ def test_precision_site_sets():
         E.resolve_precision("bf16")
     with pytest.raises(E.ZutisHipError):
         E.resolve_precision(["nope"])
+
+
+def test_split_weight_packing_host_logic():
+    """ops.split_weight (pack-time, plain torch — runs on CPU): W * 2^s with max|W| in [2^13, 2^14), hi + lo reproduces the
+    scaled weight to ~2^-22 relative, lo is a NORMAL fp16 number wherever it is non-zero for typical weights, out_scale = 2^-s."""
+    import math
+    import torch
+    from zutis_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for scale in (0.03, 1.0, 1e-4, 300.0):
+        w = torch.randn((64, 128), generator=g) * scale
+        a = ops.split_weight(w)
+        assert a.t.shape == (2, 64, 128) and a.plane == 64 * 128
+        s = -math.log2(a.out_scale)
+        assert s == int(s) and 2 ** 13 <= float(w.abs().max()) * 2 ** s < 2 ** 14
+        rec = (a.t[0].double() + a.t[1].double()) * a.out_scale
+        assert float(((rec - w.double()).abs() / w.double().abs().clamp_min(float(w.abs().max()) * 2 ** -10)).max()) < 2 ** -21
+        lo = a.t[1].float().abs()
+        assert float((lo[lo > 0] < 6.1e-5).float().mean()) < 0.02          # (almost) no subnormal lo halves
+    z = ops.split_weight(torch.zeros((4, 64)))
+    assert z.out_scale == 1.0 and float(z.t.abs().max()) == 0.0

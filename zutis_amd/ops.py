@@ -87,7 +87,7 @@ def split_weight(w32: torch.Tensor) -> Act:
     w = w32.detach().to(f32)
     m = float(w.abs().max()) if w.numel() else 0.0
     s = 0 if m == 0.0 or not math.isfinite(m) else 13 - math.floor(math.log2(m))
-    s = max(-14, min(24, s))
+    s = max(-14, min(60, s))                        # 2^-60 is still a normal fp32 out_scale
     ws = w * (2.0 ** s)
     hi = ws.to(f16)
     lo = (ws - hi.to(f32)).to(f16)
