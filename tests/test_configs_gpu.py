@@ -152,3 +152,28 @@ def test_extract_image_embeddings_dropin_files_and_pickle(dev, tmp_path):
     assert resize_crop_box(640, 427, 224) == ((335, 224), (56, 0))          # torchvision: int(224*640/427) = 335, round(55.5) = 56
     assert resize_crop_box(427, 640, 224) == ((224, 335), (0, 56))
     assert resize_crop_box(500, 375, 336) == ((448, 336), (56, 0))
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fast", 2.5e-4)])
+def test_c1_vitb32_224_batch4_vs_oracle(dev, precision, tol):
+    """BASELINE config 1 as SURVEY 8d defines it: ViT-B/32 + head, x = randn[4,3,224,224] (seed 0), 81 categories — the
+    reference's own CPU-runnable case; HIP engine vs the oracle on the same inputs, semantic labels at 224x224."""
+    from zutis_amd import detgen
+    from zutis_amd.engine import ZutisEngine
+    from oracle import zutis_ref as O
+    cfg = detgen.VIT_B32
+    sd = detgen.zutis_state_dict(cfg)
+    x = torch.randn((4, 3, 224, 224), generator=torch.Generator().manual_seed(0))
+    text = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim))
+    with torch.no_grad():
+        ref = O.zutis_forward(O.to_torch_params(sd), x, cfg.patch, cfg.dec_heads)
+        lo_ref = O.semantic_logits_lowres(ref["patch_tokens"], text).numpy()
+        lab_ref = O.predict_semantic(ref["patch_tokens"], text, size=(224, 224))
+    eng = ZutisEngine({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, cfg.patch, cfg.dec_heads, precision=precision)
+    out = eng.forward(x.to(dev))
+    lo = eng.semantic_logits_lowres(out["patch_tokens"], text.to(dev)).cpu().numpy()
+    lab = eng.predict_semantic(out["patch_tokens"], text.to(dev), (224, 224)).cpu().numpy()
+    assert out["mask_proposals"].shape == (4, 6, 100, 14, 14) and out["patch_tokens"].shape == (4, 14, 14, 512)
+    assert np.abs(lo - lo_ref).max() < tol
+    assert (lab == lab_ref).mean() > (0.9995 if precision == "exact" else 0.995)
+    assert np.abs(out["mask_proposals"].cpu().numpy() - ref["mask_proposals"].numpy()).max() < (2e-4 if precision == "exact" else 1e-3)
