@@ -28,6 +28,9 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
                "zh_gemm_f16: lda/ldw/strides must be multiples of 8 halves (16-byte rows)");
   ZH_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "zh_gemm_f16: A/W must be 16-byte aligned");
   ZH_CHECK_ARG(act >= 0 && act <= 4, "zh_gemm_f16: bad activation %d", act);
+  // the kernel addresses an operand row as base + (32-bit element offset): keep one batch item's A / W below 2^32 elements
+  ZH_CHECK_ARG((long)(M - 1) * lda + K <= 0xFFFFFFFFL && (long)(N - 1) * ldw + K <= 0xFFFFFFFFL,
+               "zh_gemm_f16: an operand exceeds 2^32 elements per batch item (M=%d lda=%ld N=%d ldw=%ld)", M, lda, N, ldw);
   ZH_CHECK_ARG(!residual || res_rows > 0, "zh_gemm_f16: residual needs res_rows > 0");
   GemmArgs p;
   p.A = (const half_t*)A; p.lda = lda; p.sA = strideA;

@@ -43,6 +43,9 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   ZH_CHECK_ARG(planeA != 0 && planeW != 0, "zh_gemm_f16x3: operands must be split pairs (plane offset of the lo half)");
   ZH_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "zh_gemm_f16x3: A/W must be 16-byte aligned");
   ZH_CHECK_ARG(act >= 0 && act <= 4, "zh_gemm_f16x3: bad activation %d", act);
+  // the kernel addresses an operand row as base + (32-bit element offset): keep one batch item's A / W below 2^32 elements
+  ZH_CHECK_ARG((long)(M - 1) * lda + K <= 0xFFFFFFFFL && (long)(N - 1) * ldw + K <= 0xFFFFFFFFL,
+               "zh_gemm_f16x3: an operand exceeds 2^32 elements per batch item (M=%d lda=%ld N=%d ldw=%ld)", M, lda, N, ldw);
   ZH_CHECK_ARG(out_kind >= 0 && out_kind <= 2, "zh_gemm_f16x3: out_kind %d not in {0 f32, 1 f16, 2 split pair}", out_kind);
   ZH_CHECK_ARG(out_kind != 2 || (planeC != 0 && planeC % 4 == 0), "zh_gemm_f16x3: split output needs planeC (multiple of 4)");
   ZH_CHECK_ARG(!residual || (res_rows > 0 && out_kind == 0), "zh_gemm_f16x3: residual needs res_rows > 0 and an f32 output");
