@@ -12,7 +12,7 @@ void zh_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* zh_last_error(void) { return g_err; }
-extern "C" int zh_version(void) { return 100; }
+extern "C" int zh_version(void) { return 200; }   // 2xx: split-pair (lo_plane) arguments, zh_gemm_f16x3, batched solver, device NMS
 extern "C" const char* zh_arch(void) { return "gfx950"; }
 
 // ---- host-side COCO RLE (pycocotools maskApi.c rleEncode + rleToString restated): the reference encodes every kept
