@@ -130,9 +130,11 @@ int zh_im2col_f16(const float* x, void* out, int B, int Cin, int H, int W, int p
 int zh_posembed_bicubic(const float* pos, float* out, int grid, int h, int w, int D, float scale_h, float scale_w,
                         int has_cls, zh_stream_t stream);
 
-/* F.interpolate(scale_factor=2, bilinear) on channels-last tokens: zutis.py:491-495. */
+/* F.interpolate(scale_factor=2, bilinear) on channels-last tokens: zutis.py:491-495.  relu != 0: max(., 0) after the
+ * interpolation — the engine applies the (linear) first ffn1 layer and the text-space projection to the h*w tokens and
+ * upsamples their outputs (a linear map commutes with the interpolation, whose weights sum to 1), zutis.py:491-503,319. */
 int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, long lo_plane,
-                              zh_stream_t stream);
+                              int relu, zh_stream_t stream);
 
 /* PositionEmbeddingSine(normalize=True): positional_embedding.py:29-52 -> [h*w, D] channels-last. */
 int zh_sine_pe(float* out, int h, int w, int D, float temperature, zh_stream_t stream);

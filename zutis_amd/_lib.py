@@ -44,7 +44,7 @@ _SIGS = {
     "zh_im2col_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _l, _vp]),
     "zh_posembed_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "zh_select_upsample_mask": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
-    "zh_upsample2x_bilinear_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _vp]),
+    "zh_upsample2x_bilinear_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "zh_sine_pe": (_i, [_vp, _i, _i, _i, _f, _vp]),
     "zh_add_rowperiodic_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _l, _l, _vp]),
     "zh_fill_f32": (_i, [_vp, _f, _l, _vp]),

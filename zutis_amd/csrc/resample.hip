@@ -124,7 +124,7 @@ extern "C" int zh_posembed_bicubic(const float* pos, float* out, int grid, int h
 // ---- x2 bilinear upsample, channels-last tokens (networks/zutis.py:491-495): [B,h,w,D] fp32 -> [B,2h,2w,D]
 //      fp16 and/or fp32.  src = max(0.5*(dst+0.5)-0.5, 0); weights {0.25,0.75} (edges clamp).
 __global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* x, float* out_f32, half_t* out_f16, int B, int h, int w, int D,
-                                                          long lo_plane) {
+                                                          long lo_plane, int relu) {
   // One workgroup per 2x2 output quad {2j+1,2j+2} x {2k+1,2k+2}, j in [-1,h-1], k in [-1,w-1]: the four outputs interpolate the
   // same four inputs (rows j,j+1 x cols k,k+1, clamped), so every input float4 is loaded once per quad instead of once per
   // output (the per-output form re-read 4x the tensor through L2 and ran at 2 TB/s).  Each output still evaluates ATen's own
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* x, floa
           const float r0 = __fmaf_rn(v00[e], lx0, __fmul_rn(v01[e], lx1[sx]));
           const float r1 = __fmaf_rn(v10[e], lx0, __fmul_rn(v11[e], lx1[sx]));
           o[e] = __fmaf_rn(r0, ly0, __fmul_rn(r1, ly1[sy]));
+          if (relu) o[e] = fmaxf(o[e], 0.0f);
         }
         const long oi = (orow[sy] + ocol[sx]) * nv + c;
         if (out_f32) ((f32x4*)out_f32)[oi] = o;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* x, floa
 }
 
 extern "C" int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* out_f16, int B, int h, int w, int D, long lo_plane,
-                                         hipStream_t stream) {
+                                         int relu, hipStream_t stream) {
   ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && h > 0 && w > 0 && D > 0 && D % 4 == 0 && lo_plane % 4 == 0,
                "zh_upsample2x_bilinear_cl: bad arguments");
   const long quads = (long)B * (h + 1) * (w + 1);          // one workgroup per 2x2 output quad
@@ -189,7 +190,7 @@ extern "C" int zh_upsample2x_bilinear_cl(const float* x, float* out_f32, void* o
   const int nv = D / 4;
   const int threads = nv >= 256 ? 256 : ((nv + 63) / 64) * 64;
   hipLaunchKernelGGL(upsample2x_cl_kernel, dim3((unsigned)quads), dim3(threads), 0, stream, x, out_f32, (half_t*)out_f16, B, h, w, D,
-                     lo_plane);
+                     lo_plane, relu);
   ZH_CHECK_LAUNCH("zh_upsample2x_bilinear_cl");
   return ZH_OK;
 }

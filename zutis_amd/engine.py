@@ -379,6 +379,11 @@ class ZutisEngine(_EngineBase):
     # ------------------------------------------------------------------ encoder
     def encode(self, x: torch.Tensor):
         """clip_arch.py:377-411 -> (patch tokens f32 [B,hw,D] (ln_post applied, cls dropped), h, w)."""
+        tok, _, h, w = self._encode(x, False)
+        return tok, h, w
+
+    def _encode(self, x: torch.Tensor, want16: bool, want32: bool = True):
+        """encode() plus, on request, the fp16 / split-pair copy of the tokens the head's GEMMs read (same LayerNorm launch)."""
         self._pack()
         if not (x.is_cuda and x.dtype == f32 and x.dim() == 4 and x.shape[1] == 3):
             raise ZutisHipError("encode: expected float32 CUDA tensor [B,3,H,W]")
@@ -388,27 +393,33 @@ class ZutisEngine(_EngineBase):
         h, w = (H - p) // p + 1, (Wd - p) // p + 1
         T = 1 + h * w
         X = self._clip_trunk(x, self._geometry(h, w)["pos"], h, w)
-        tok = self._buf("tok", (B, h * w, D), f32)
-        ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B * h * w, D, out_f32=tok,
+        tok = self._buf("tok", (B, h * w, D), f32) if want32 else None
+        tok16 = self._abuf("tok16", (B * h * w, D), self._x3("ffn1", "textproj")) if want16 else None
+        ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B * h * w, D, out_f32=tok, out_f16=tok16,
                       in_group_rows=h * w, in_group_stride=T, in_offset=1)                 # :403-404
-        return tok, h, w
+        return tok, tok16, h, w
 
     # ------------------------------------------------------------------ full forward
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         """networks/zutis.py:472-532."""
-        tok, h, w = self.encode(x)
+        _, tok16, h, w = self._encode(x, True, want32=False)
         W_, D, B, Q, L = self._w, self.D, x.shape[0], self.Q, self.dec_layers
         h2, w2 = 2 * h, 2 * w
         M = h2 * w2
         geo = self._geometry(h, w)
-        TOK = self._abuf("TOK16", (B * M, D), self._x3("ffn1", "textproj"))
-        ops.upsample2x_cl(tok, B, h, w, D, out_f16=TOK)                                     # :491-495
+        # zutis.py:491-503 upsamples the tokens x2 and then applies ffn1; zutis.py:319 projects the upsampled tokens.  Both first
+        # steps are LINEAR maps of the tokens and bilinear interpolation is a convex combination (weights 0.25 / 0.75, sum 1),
+        # so W.up(t) + b == up(W.t + b): the first ffn1 layer and the text-space projection run on the h*w tokens (4x fewer rows)
+        # and their outputs are upsampled (ReLU after the interpolation, where the reference has it).  Same function, different
+        # rounding order (fp32-class in the x3 mode); the [B, 4hw, 768] upsampled token tensor is never formed.
         Fh = P_shape0(W_["ffn1.0.w"])
+        h1 = self._buf("ffn_h1_lo", (B * h * w, Fh), f32)
+        self._gemm("ffn1", tok16, W_["ffn1.0.w"], h1, bias=W_["ffn1.0.b"])                  # :500-503 (layer 0, pre-ReLU)
         f1 = self._abuf("ffn_h1", (B * M, Fh), self._x3("ffn1"))
+        ops.upsample2x_cl(h1, B, h, w, Fh, out_f16=f1, relu=True)                           # :491-495 + ReLU
         f2 = self._abuf("ffn_h2", (B * M, Fh), self._x3("ffn1"))
         # decoder_input feeds the K/V projections, memory + pos and the mask einsum: a split pair needs the x3 ffn1 to fill it
         DEC = self._abuf("DEC16", (B * M, D), self._x3("mask", "dec_kv"))
-        self._gemm("ffn1", TOK, W_["ffn1.0.w"], f1, bias=W_["ffn1.0.b"], act=ops.ACT_RELU)  # :500-503
         self._gemm("ffn1", f1, W_["ffn1.1.w"], f2, bias=W_["ffn1.1.b"], act=ops.ACT_RELU)
         self._gemm("ffn1", f2, W_["ffn1.2.w"], DEC, bias=W_["ffn1.2.b"])
         KIN = self._abuf("KIN16", (B * M, D), self._x3("dec_kv"))
@@ -426,8 +437,10 @@ class ZutisEngine(_EngineBase):
         masks = torch.empty((B, L, Q, h2, w2), dtype=f32, device=x.device)
         self._gemm("mask", q16, DEC, masks, act=ops.ACT_SIGMOID, M=L * Q, N=M, K=D, lda=D, ldw=D, ldc=M,
                    batch=B, strideA=L * Q * D, strideW=M * D, strideC=L * Q * M)            # :196-198,209
+        tsl = self._buf("textspace_lo", (B * h * w, self.E), f32)
+        self._gemm("textproj", tok16, W_["projT"], tsl)                                     # :319 on the h*w tokens
         ts = self._buf("textspace", (B * M, self.E), f32)
-        self._gemm("textproj", TOK, W_["projT"], ts)                                        # :319
+        ops.upsample2x_cl(tsl, B, h, w, self.E, out_f32=ts)                                 # :491-495
         pt = torch.empty((B, h2, w2, self.E), dtype=f32, device=x.device)
         ws = self._buf("gln_ws", (max(1, ops.global_ln_l2_workspace_size(B, M, self.E)),), torch.uint8)
         pt16 = self._abuf("pt16", (B * M, self.E), self._x3("logits"))   # the copy predict_semantic's class-logit GEMM consumes

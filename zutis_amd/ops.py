@@ -276,10 +276,11 @@ def posembed_bicubic(pos, out, grid, h, w, D, scale_h, scale_w, has_cls=True):
                                      int(has_cls), _stream()), "zh_posembed_bicubic")
 
 
-def upsample2x_cl(x, B, h, w, D, out_f32=None, out_f16=None):
+def upsample2x_cl(x, B, h, w, D, out_f32=None, out_f16=None, relu=False):
     L = _lib.load()
     out_f16, lo = _hp(out_f16)
-    _lib.check(L.zh_upsample2x_bilinear_cl(_p(x), _p(out_f32), _p(out_f16), B, h, w, D, lo, _stream()), "zh_upsample2x_bilinear_cl")
+    _lib.check(L.zh_upsample2x_bilinear_cl(_p(x), _p(out_f32), _p(out_f16), B, h, w, D, lo, int(relu), _stream()),
+               "zh_upsample2x_bilinear_cl")
 
 
 def sine_pe(out, h, w, D, temperature=10000.0):
