@@ -44,15 +44,19 @@ int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
 
-/* C[b][m][n] = act(sum_k A[b][m][k]*W[b][n][k] + bias[n]) + residual[b][m % res_rows][n]
+/* C[b][m][n] = act(sum_k A[b][m][k]*W[b][n][k] + bias[n] + pos[m][n]) + residual[b][m % res_rows][n]
  * A [M,K] f16 (lda), W [N,K] f16 (ldw) — torch Linear layout; C f32 or f16 (out_f16); bias/residual f32 or NULL.
  * K % 64 == 0; lda/ldw % 8 == 0.  residual may alias C (in-place x += ...).
- * Replaces: conv1-as-GEMM clip_arch.py:378; in_proj/out_proj/c_fc/c_proj clip_arch.py:314-320; MLP zutis.py:546-549;
- * decoder projections + FFN transformer.py:272-290; einsum("bdqc,bhwc->bdqhw")+sigmoid zutis.py:196-198,209 (batched);
- * einsum("bhwn,nc->bhwc") zutis.py:319; einsum("nc,bchw->bnhw") zutis.py:361-365 (batched, strideA = 0). */
+ * pos (optional, pos_y and pos_x both NULL = none): output rows are pixels, m = image * pos_h*pos_w + y * pos_w + x, and
+ * pos[m][n] = pos_y[y][n] + pos_x[x][n] with tables [pos_h, ld_pos] / [pos_w, ld_pos], fp32 or (pos_f16) fp16, ld_pos % 8 == 0,
+ * N % 4 == 0.  This is the
+ * `pos` term of the decoder's key projection of `memory + pos` (transformer.py:281-283): the sine PE is [py(y) | px(x)]
+ * (positional_embedding.py:47-52), so pos @ Wk^T separates into two small input-independent tables and `memory + pos` is
+ * never materialised; the accumulators start from the table values (read under the operand prefetch). */
 int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, long strideW,
                 void* C, long ldc, long strideC, int out_f16,
                 const float* bias, const float* residual, long ldr, long strideR, int res_rows,
+                const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
                 int act, int M, int N, int K, int batch, zh_stream_t stream);
 
 /* The same contraction at the reference's precision (the reference computes every Linear / einsum in fp32:
@@ -64,6 +68,7 @@ int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, 
 int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void* W, long ldw, long strideW, long planeW,
                   void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
                   const float* bias, const float* residual, long ldr, long strideR, int res_rows,
+                  const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
                   int act, int M, int N, int K, int batch, zh_stream_t stream);
 
 /* Flash attention: O = softmax(scale * Q K^T) V per (image, head); Q [Tq, heads*dh] rows with stride ldq, etc.

@@ -53,6 +53,37 @@ def test_gemm_epilogues(dev, act):
             assert torch.allclose(out.float().cpu(), ref, atol=1e-2, rtol=2e-3)
 
 
+@pytest.mark.parametrize("N,act", [(256, 0), (264, 2), (40, 0)])
+def test_gemm_pos_tables(dev, N, act):
+    """out[m] = act(A W^T + bias + Ty[(m % (h*w)) // w] + Tx[m % w]): the separable `pos @ Wk^T` term of the composed decoder
+    K projection (engine._decoder_kv).  f32 and fp16 outputs; the fp16 one must be the single rounding of the fp32 one."""
+    from zutis_amd import ops
+    hh, ww, B, K = 6, 10, 5, 128
+    M = B * hh * ww - 7                                                     # last image ragged: rows clamp, not wrap
+    A, W = _randn((M, K), 31, 0.5).to(f16), _randn((N, K), 32, 0.2).to(f16)
+    bias, Ty, Tx = _randn((N,), 33), _randn((hh, N), 34), _randn((ww, N), 35)
+    m = torch.arange(M)
+    ref = A.double() @ W.double().t() + bias.double() + Ty.double()[(m % (hh * ww)) // ww] + Tx.double()[m % ww]
+    ref = F.relu(ref) if act == 2 else ref
+    kw = dict(bias=bias.to(dev), pos=(Ty.to(dev), Tx.to(dev)), act=act)
+    o16 = torch.empty((M, N), dtype=f16, device=dev)
+    ops.gemm(A.to(dev), W.to(dev), o16, **kw)
+    assert float((o16.cpu().double() - ref).abs().max()) < 1e-2
+    if act == 0:
+        o32 = torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm(A.to(dev), W.to(dev), o32, **kw)
+        assert float((o32.cpu().double() - ref).abs().max()) < 2e-4
+        assert torch.equal(o16.cpu(), o32.cpu().to(f16))
+    # fp16 tables (what the engine uses when K itself is fp16): same sum from the rounded tables
+    Th, Tw = Ty.to(f16), Tx.to(f16)
+    ref16 = A.double() @ W.double().t() + bias.double() + Th.double()[(m % (hh * ww)) // ww] + Tw.double()[m % ww]
+    ref16 = F.relu(ref16) if act == 2 else ref16
+    o32 = torch.empty((M, N), dtype=f32, device=dev)
+    if act == 0:
+        ops.gemm(A.to(dev), W.to(dev), o32, bias=bias.to(dev), pos=(Th.to(dev), Tw.to(dev)))
+        assert float((o32.cpu().double() - ref16).abs().max()) < 2e-4
+
+
 def test_gemm_inplace_residual_and_batched(dev):
     from zutis_amd import ops
     B, M, N, K = 3, 100, 140, 64

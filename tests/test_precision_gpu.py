@@ -90,6 +90,34 @@ def test_gemm_x3_epilogues_and_outputs(dev, act):
             ops.gemm_x3(Ad, Wd, Act.empty((M, N), False, dev), act=act)
 
 
+@pytest.mark.parametrize("N", [256, 264])
+def test_gemm_x3_pos_tables(dev, N):
+    """The composed K projection in the x3 mode: accumulators start from the pos tables (times 2^s, exact); fp32 / fp16 /
+    split-pair outputs."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    hh, ww, B, K = 6, 10, 9, 256
+    M = B * hh * ww
+    A, W = _randn((M, K), 41, 0.5), _randn((N, K), 42, 0.2)
+    bias, Ty, Tx = _randn((N,), 43), _randn((hh, N), 44), _randn((ww, N), 45)
+    m = torch.arange(M)
+    ref = A.double() @ W.double().t() + bias.double() + Ty.double()[(m % (hh * ww)) // ww] + Tx.double()[m % ww]
+    Ad, Wd = _split_act(A, dev), ops.split_weight(W.to(dev))
+    kw = dict(bias=bias.to(dev), pos=(Ty.to(dev), Tx.to(dev)))
+    o32 = torch.empty((M, N), dtype=f32, device=dev)
+    ops.gemm_x3(Ad, Wd, o32, **kw)
+    tol = 1e-6 * max(1.0, float(ref.abs().max()))                        # fp32 accumulation that starts from the table value
+    assert float((o32.cpu().double() - ref).abs().max()) < tol
+    o16 = Act.empty((M, N), False, dev)
+    ops.gemm_x3(Ad, Wd, o16, **kw)
+    assert torch.equal(o16.hi.cpu(), o32.cpu().to(f16))
+    osp = Act.empty((M, N), True, dev)
+    ops.gemm_x3(Ad, Wd, osp, **kw)
+    assert torch.equal(osp.hi.cpu(), o16.hi.cpu())
+    both = osp.t[0].float() + osp.t[1].float()
+    assert float((both.cpu().double() - ref).abs().max()) < tol
+
+
 def test_gemm_x3_batched_activation_operands(dev):
     """The mask einsum form (zutis.py:196-198): both operands are activations (split pairs, scale 1), batched."""
     from zutis_amd import ops

@@ -9,7 +9,7 @@ shapes = [("qkv", 14144, 2304, 768), ("out", 14144, 768, 768), ("fc", 14144, 307
 for name, M, N, K in shapes:
     A = torch.randn(M, K, device=dev).half(); W = torch.randn(N, K, device=dev).half(); out = torch.empty(M, N, device=dev, dtype=torch.float16)
     res = {}
-    for tile in ("auto", "128", "192", "1192", "256"):
+    for tile in ("auto", "128", "192", "256"):
         if tile == "auto": os.environ.pop("ZH_GEMM_TILE", None)
         else: os.environ["ZH_GEMM_TILE"] = tile
         for _ in range(3): ops.gemm(A, W, out)

@@ -20,6 +20,7 @@ static bool launch_gemm(const GemmArgs& p, int batch, int out_f16, hipStream_t s
 extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, long strideW,
                            void* C, long ldc, long strideC, int out_f16,
                            const float* bias, const float* residual, long ldr, long strideR, int res_rows,
+                           const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
                            int act, int M, int N, int K, int batch, hipStream_t stream) {
   ZH_CHECK_ARG(A && W && C, "zh_gemm_f16: null operand");
   ZH_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "zh_gemm_f16: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
@@ -32,12 +33,15 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   ZH_CHECK_ARG((long)(M - 1) * lda + K <= 0xFFFFFFFFL && (long)(N - 1) * ldw + K <= 0xFFFFFFFFL,
                "zh_gemm_f16: an operand exceeds 2^32 elements per batch item (M=%d lda=%ld N=%d ldw=%ld)", M, lda, N, ldw);
   ZH_CHECK_ARG(!residual || res_rows > 0, "zh_gemm_f16: residual needs res_rows > 0");
+  ZH_CHECK_ARG(zh_pos_tables_ok(pos_y, pos_x, ld_pos, pos_h, pos_w, N), "zh_gemm_f16: pos tables need both pointers 16-byte aligned, "
+               "pos_h, pos_w > 0, ld_pos %% 8 == 0 and N %% 4 == 0");
   GemmArgs p;
   p.A = (const half_t*)A; p.lda = lda; p.sA = strideA;
   p.W = (const half_t*)W; p.ldw = ldw; p.sW = strideW;
   p.C = C; p.ldc = ldc; p.sC = strideC;
   p.planeA = p.planeW = p.planeC = 0; p.out_scale = 1.0f;
   p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
+  p.pos_y = pos_y; p.pos_x = pos_x; p.ld_pos = ld_pos; p.pos_hw = pos_h * pos_w; p.pos_w = pos_w; p.pos_f16 = pos_f16;
   p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
   // super-tile height: 3..8 measure within 1 % of each other on the model, 16 / 32 lose 13 / 36 % on 8192^3
   // (tools/gemm_vs_blaslt.py) — the order in which an XCD's 32 resident tiles share panels matters
@@ -66,10 +70,10 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   // N = 1536 / 2048 keep 128 x 128 (tools/gemm_dec_tiles.py)
   else if (pick == 128 && t128 <= 256 && N <= 768) pick = 64;
   if (dev.tile) {
-    static const int known[] = {64, 128, 192, 256, 1192, 2064, 2128, 3064};
+    static const int known[] = {64, 128, 192, 256, 2064, 2128, 3064};
     bool okc = false;
     for (int k : known) okc |= (k == dev.tile);
-    ZH_CHECK_ARG(okc, "zh_gemm_f16: ZH_GEMM_TILE=%d is not a tile code (64|128|192|256|1192|2064|2128|3064)", dev.tile);
+    ZH_CHECK_ARG(okc, "zh_gemm_f16: ZH_GEMM_TILE=%d is not a tile code (64|128|192|256|2064|2128|3064)", dev.tile);
     pick = dev.tile;
   }
   // 16-byte row stores need 16-B aligned rows; an f16 residual is not supported (none on the hot path)
@@ -84,7 +88,6 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   else if (pick == 64) ok = launch_gemm<2, 2, 4, 2, 4, 2>(p, batch, out_f16, stream);   // 128 x 64
   else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 4, 2>(p, batch, out_f16, stream);
   else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 4, 2>(p, batch, out_f16, stream);
-  else if (pick == 1192) ok = launch_gemm<2, 2, 4, 6, 4, 2>(p, batch, out_f16, stream);   // 128 x 192, 4 waves, 2 blocks/CU: experiment only (ZH_GEMM_TILE), measured 10-20 % slower than 256 x 192 on the N=768 GEMMs
   else ok = launch_gemm<2, 4, 8, 4, 4, 2>(p, batch, out_f16, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16: (out_f16=%d, act=%d) is not an instantiated epilogue (f32: none|sigmoid; f16: none|quickgelu|relu|gelu_erf)",
                out_f16, act);

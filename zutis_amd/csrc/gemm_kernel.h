@@ -42,6 +42,9 @@ struct GemmArgs {
   float out_scale;               // SPLIT: accumulators are multiplied by this before the bias (weights packed as W * 2^s)
   const float* bias;
   const float* R; long ldr, sR; int res_rows;
+  // separable per-pixel row bias (rows are pixels m = img * pos_hw + y * pos_w + x): pos_y[y][n] + pos_x[x][n] is added to
+  // the accumulator before the activation — the tile's accumulators START from it, loaded under the ring's prologue
+  const void* pos_y; const void* pos_x; long ld_pos; int pos_hw, pos_w, pos_f16;   // tables fp32, or fp16 (pos_f16)
   int M, N, K, act, nbm, nbn, vec_ok, group_m;
 #ifdef ZH_GEMM_PROBE
   long long* probe;   // developer build (tools/gemm_probe.py): 4 timestamps per block
@@ -171,6 +174,118 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 
   const int nk = p.K / BK;                    // even: K % 64 == 0
   const int frow = lane & 15, fk = lane >> 4;
+  // ---- pos tables: accumulators start from pos_y[y] + pos_x[x] (N % 4 == 0 checked on the host).  SPLIT: the accumulator is
+  // scaled by out_scale = 2^-s afterwards — start from the table value times 2^s (exact).
+  // In the MFMA accumulator layout a lane owns 4 columns of ONE row per 16x16 subtile, so reading the tables straight from
+  // global memory costs TM*TN*2 loads per lane that each touch 16 different table rows: ~1 MB of L1 line traffic per
+  // 256x256 tile for a 25-50 KB unique slice (measured: +130 us on the 230-us K projection, fp16 or fp32 tables alike).
+  // Instead the block copies the tile's slice — all pos_w rows of pos_x and the few rows of pos_y its pixels span, BN
+  // columns — into the ring slot the prologue leaves free (slot STAGES-1), every line fetched once, and the lanes pick their
+  // rows out of LDS.  The copy's global loads are issued BEFORE the prologue's DMA (vmcnt retires in order: the counted waits
+  // of the ring can only over-wait) and stored after it.  Slices that do not fit the slot (wide images) take the direct path.
+  constexpr int POS_SLOT_BYTES = STAGE_HALVES * 2, POS_NT = 64 * NW;
+  constexpr int POS_MAXIT = (POS_SLOT_BYTES / 16 + POS_NT - 1) / POS_NT;
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t pos_v[POS_MAXIT];
+  const unsigned pos_q0 = p.pos_y ? (unsigned)m0 % (unsigned)p.pos_hw : 0u;
+  const unsigned pos_y0 = p.pos_y ? pos_q0 / (unsigned)p.pos_w : 0u, pos_x0 = pos_q0 - pos_y0 * (unsigned)p.pos_w;
+  const int pos_rsb = BN * (p.pos_f16 ? 2 : 4) + 16;                          // LDS row stride of the slice (bytes)
+  const int pos_rows = p.pos_y ? p.pos_w + (int)((pos_x0 + BM - 1) / (unsigned)p.pos_w) + 1 : 0;
+  const bool pos_lds = p.pos_y && pos_rows * pos_rsb <= POS_SLOT_BYTES;
+  char* const pos_slot = (char*)(smem + (STAGES - 1) * STAGE_HALVES);
+  auto pos_fetch_t = [&](auto tag) {                            // global -> registers, one 16-byte chunk per thread and pass
+    typedef decltype(tag) T;
+    constexpr int EPC = 16 / (int)sizeof(T), CPR = BN / EPC;    // elements per chunk, chunks per row
+    const int total = pos_rows * CPR, hgt = p.pos_hw / p.pos_w;
+#pragma unroll
+    for (int it = 0; it < POS_MAXIT; ++it) {
+      int c = tid + it * POS_NT;
+      c = c < total ? c : total - 1;                            // branch-free: the surplus threads re-fetch the last chunk
+      const int row = c / CPR, ch = c - row * CPR;
+      const bool isx = row < p.pos_w;                           // selects, not branches: the loads of all passes batch
+      const unsigned ry = (pos_y0 + (unsigned)(isx ? 0 : row - p.pos_w)) % (unsigned)hgt;
+      const T* base = isx ? (const T*)p.pos_x : (const T*)p.pos_y;
+      int n = n0 + ch * EPC;
+      n = n < p.N ? n : 0;                                      // columns >= N are never stored
+      pos_v[it] = *(const u32x4_t*)(base + (long)(isx ? (unsigned)row : ry) * p.ld_pos + n);
+    }
+  };
+  auto pos_apply_t = [&](auto tag) {                            // registers -> LDS slice -> accumulators
+    typedef decltype(tag) T;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    constexpr int EPC = 16 / (int)sizeof(T), CPR = BN / EPC;
+    const int total = pos_rows * CPR;
+#pragma unroll
+    for (int it = 0; it < POS_MAXIT; ++it) {
+      const int c = tid + it * POS_NT;
+      const int row = c / CPR, ch = c - row * CPR;
+      if (c < total) *(u32x4_t*)(pos_slot + row * pos_rsb + ch * 16) = pos_v[it];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float isc = SPLIT ? 1.0f / p.out_scale : 1.0f;
+    const int rmax = p.M - 1 - m0;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+      int r = (wr * TM + mt) * 16 + frow;
+      r = r < rmax ? r : rmax;                                  // rows >= M are never stored
+      const unsigned q = pos_x0 + (unsigned)r, jy = q / (unsigned)p.pos_w, x = q - jy * (unsigned)p.pos_w;
+      const char* lx = pos_slot + x * pos_rsb + ((wc * TN) * 16 + fk * 4) * (int)sizeof(T);
+      const char* ly = pos_slot + (p.pos_w + jy) * pos_rsb + ((wc * TN) * 16 + fk * 4) * (int)sizeof(T);
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const T4 a = *(const T4*)(lx + nt * 16 * (int)sizeof(T)), b = *(const T4*)(ly + nt * 16 * (int)sizeof(T));
+        acc[nt][mt] = (f32x4){(float)a[0] + (float)b[0], (float)a[1] + (float)b[1], (float)a[2] + (float)b[2], (float)a[3] + (float)b[3]} * isc;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slice is consumed before the ring may reuse the slot
+  };
+  auto pos_direct_t = [&](auto tag) {                           // slice larger than the slot: straight from global memory
+    typedef decltype(tag) T;                                    // float or half_t table elements
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    const float isc = SPLIT ? 1.0f / p.out_scale : 1.0f;
+    constexpr int G = TM * TN > 16 ? (16 / TN > 0 ? 16 / TN : 1) : TM;    // rows of subtiles per batch: <= 32 loads in flight
+#pragma unroll
+    for (int g = 0; g < TM; g += G) {
+      T4 ry[G][TN], rx[G][TN];
+#pragma unroll
+      for (int ml = 0; ml < G; ++ml) {
+        const int m = m0 + (wr * TM + g + ml) * 16 + frow;
+        const unsigned pix = (unsigned)(m < p.M ? m : p.M - 1) % (unsigned)p.pos_hw;
+        const unsigned y = pix / (unsigned)p.pos_w, x = pix - y * (unsigned)p.pos_w;
+        const T* ty = (const T*)p.pos_y + (long)y * p.ld_pos;
+        const T* tx = (const T*)p.pos_x + (long)x * p.ld_pos;
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+          n = n < p.N ? n : 0;                                 // branch-free (columns >= N are never stored): the loads batch
+          ry[ml][nt] = *(const T4*)(ty + n);
+          rx[ml][nt] = *(const T4*)(tx + n);
+        }
+      }
+#pragma unroll
+      for (int ml = 0; ml < G; ++ml)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          const T4 a = ry[ml][nt], b = rx[ml][nt];
+          acc[nt][g + ml] = (f32x4){(float)a[0] + (float)b[0], (float)a[1] + (float)b[1], (float)a[2] + (float)b[2], (float)a[3] + (float)b[3]} * isc;
+        }
+    }
+  };
+  auto pos_before_prologue = [&]() {
+    if (!pos_lds) return;
+    if (p.pos_f16) pos_fetch_t(half_t{});
+    else pos_fetch_t(float{});
+  };
+  auto pos_after_prologue = [&]() {
+    if (!p.pos_y) return;
+    if (pos_lds) {
+      if (p.pos_f16) pos_apply_t(half_t{});
+      else pos_apply_t(float{});
+    } else {
+      if (p.pos_f16) pos_direct_t(half_t{});
+      else pos_direct_t(float{});
+    }
+  };
   const int foff = frow * BK + ((fk ^ ((-(frow >> 2)) & 3)) * 8);   // per-lane offset inside a 16-row subtile
   const half_t* rdA = smem + (wr * TM * 16) * BK + foff;
   const half_t* rdW = smem + (NPL * BM + wc * TN * 16) * BK + foff;
@@ -183,9 +298,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     // per wave), so two slices of prefetch cover ~1.5 us of load latency with a 3-slot ring.
     constexpr int DISTX = STAGES - 1, AHEADX = STAGES - 2;
     static_assert(AHEADX >= 1 && AHEADX * NP < 64, "ring too shallow / vmcnt overflow");
+    pos_before_prologue();
 #pragma unroll
     for (int s = 0; s < DISTX; ++s)
       if (s < nk) issue_stage(s);
+    pos_after_prologue();
     half8_t fa[2 * TM], fw[2 * TN];
     int slot = 0, wslot = DISTX % STAGES;
     auto read_frags = [&]() {
@@ -245,9 +362,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       advance();
     }
   } else {
+  pos_before_prologue();
 #pragma unroll
   for (int s = 0; s < DIST; ++s)
     if (s < nk) issue_stage(s % STAGES);
+  pos_after_prologue();
 
   // Register double-buffered fragments: while the MFMAs of slice kt run, the ds_read_b128 of slice kt+1 are in
   // flight (the LDS latency at the head of every slice was exposed on all 8 waves at once behind the barrier).
@@ -456,6 +575,13 @@ static void launch_one(GemmArgs p, int batch, hipStream_t stream) {
 // Relative time estimate of a tiling: rounds of the 256-CU chip x time of one round.  With `bpc` blocks resident
 // per CU a round takes bpc x the tile's own time; `eff` is the measured relative speed of the tile shape at
 // K=768 (256x256: 1.0, 256x192: 0.95, 128x128: 0.8 — tools/gemm_bench.py on MI355X).
+// host-side check of the optional pos tables (both or neither)
+static inline bool zh_pos_tables_ok(const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int N) {
+  if (!pos_y && !pos_x) return true;
+  return pos_y && pos_x && pos_h > 0 && pos_w > 0 && ld_pos >= N && ld_pos % 8 == 0 && N % 4 == 0 &&
+         (((uintptr_t)pos_y | (uintptr_t)pos_x) & 15) == 0;
+}
+
 static inline double tiling_cost(long M, long N, int batch, int BM, int BN, int bpc, double eff) {
   const long tiles = (long)zh_cdiv(M, BM) * zh_cdiv(N, BN) * batch;
   const long slots = 256L * bpc;

@@ -34,6 +34,7 @@ static bool launch_x3(const GemmArgs& p, int batch, int out_kind, hipStream_t st
 extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void* W, long ldw, long strideW, long planeW,
                              void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
                              const float* bias, const float* residual, long ldr, long strideR, int res_rows,
+                             const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
                              int act, int M, int N, int K, int batch, hipStream_t stream) {
   ZH_CHECK_ARG(A && W && C, "zh_gemm_f16x3: null operand");
   ZH_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "zh_gemm_f16x3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
@@ -49,12 +50,15 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   ZH_CHECK_ARG(out_kind >= 0 && out_kind <= 2, "zh_gemm_f16x3: out_kind %d not in {0 f32, 1 f16, 2 split pair}", out_kind);
   ZH_CHECK_ARG(out_kind != 2 || (planeC != 0 && planeC % 4 == 0), "zh_gemm_f16x3: split output needs planeC (multiple of 4)");
   ZH_CHECK_ARG(!residual || (res_rows > 0 && out_kind == 0), "zh_gemm_f16x3: residual needs res_rows > 0 and an f32 output");
+  ZH_CHECK_ARG(zh_pos_tables_ok(pos_y, pos_x, ld_pos, pos_h, pos_w, N), "zh_gemm_f16x3: pos tables need both pointers 16-byte aligned, "
+               "pos_h, pos_w > 0, ld_pos %% 8 == 0 and N %% 4 == 0");
   ZH_CHECK_ARG(out_scale > 0.0f, "zh_gemm_f16x3: out_scale must be positive");
   GemmArgs p;
   p.A = (const half_t*)A; p.lda = lda; p.sA = strideA; p.planeA = planeA;
   p.W = (const half_t*)W; p.ldw = ldw; p.sW = strideW; p.planeW = planeW;
   p.C = C; p.ldc = ldc; p.sC = strideC; p.planeC = planeC; p.out_scale = out_scale;
   p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
+  p.pos_y = pos_y; p.pos_x = pos_x; p.ld_pos = ld_pos; p.pos_hw = pos_h * pos_w; p.pos_w = pos_w; p.pos_f16 = pos_f16;
   p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
   p.group_m = gemm_dev_overrides().group_m;
 #ifdef ZH_GEMM_PROBE

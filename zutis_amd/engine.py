@@ -6,9 +6,10 @@ Data layout in HBM (one GPU, B images, T = 1 + h*w encoder tokens, M = 4*h*w dec
   QKV16    f16 [B*T, 3D]       packed q|k|v, consumed in place by flash attention (strided heads)
   H16      f16 [B*T, 4D]       QuickGELU(c_fc) — never stored in fp32
   TOK16    f16 [B*M, D]        x2-upsampled patch tokens (A operand of ffn1 and of the text-space projection)
-  DEC16    f16 [B*M, D]        decoder_input (ffn1 output) = V-projection input and mask-einsum operand
-  KIN16    f16 [B*M, D]        decoder_input + sine PE = K-projection input
-  KALL/VALL f16 [B*M, L*D]     cross-attention K / V of all L decoder layers from ONE GEMM each
+  F2       f16 [B*M, 256]      ffn1's second hidden layer = input of the composed K / V projections and of ffn1's last layer
+  DEC16    f16 [B*M, D]        decoder_input (ffn1 output) = mask-einsum operand
+  KALL/VALL f16 [B*M, L*D]     cross-attention K / V of all L decoder layers from ONE GEMM each (K = 256: ffn1's last Linear
+                               composed in at pack time; the sine-PE term enters as two small fp32 tables in the K epilogue)
   weights  f16, packed once per parameter version ([N,K] row-major = torch Linear layout, K contiguous)
 
 Precision (DESIGN.md "Precision"): the reference computes in fp32 end to end.  Every contraction here is a *site* with a
@@ -155,9 +156,16 @@ class _EngineBase:
     def _c32(t):
         return t.detach().to(f32).contiguous()
 
-    def _pack_decoder(self, w, P, D, n_layers):
+    def _pack_decoder(self, w, P, D, n_layers, memory_linear=None):
         """decoder.layers.{i}.* (transformer.py:231-251) -> dec.{i}.*; the cross-attention K / V weights of all layers
-        are concatenated so the memory tokens are projected by ONE GEMM each."""
+        are concatenated so the memory tokens are projected by ONE GEMM each.
+
+        memory_linear = (W2 [D, F], b2 [D]): the memory is itself the output of a Linear layer, memory = f @ W2^T + b2
+        (ZUTIS: the last layer of ffn1, zutis.py:500-503).  The two projections are then composed at pack time (fp64 products,
+        rounded to fp32 once) so they contract over F instead of D:
+            K_all = (memory + pos) @ Wk^T + bk = f @ (Wk W2)^T + (Wk b2 + bk) + pos @ Wk^T
+            V_all =  memory        @ Wv^T + bv = f @ (Wv W2)^T + (Wv b2 + bv)
+        and "ca_k_pos_w" keeps Wk in fp32 for the per-geometry `pos @ Wk^T` tables (ZutisEngine._geometry)."""
         c32 = self._c32
         h = lambda t: self._hw(t, "dec")
         kw, kb, vw, vb = [], [], [], []
@@ -175,8 +183,15 @@ class _EngineBase:
             w[q + "l2_w"], w[q + "l2_b"] = h(P[p + "linear2.weight"]), c32(P[p + "linear2.bias"])
             for n in ("norm1", "norm2", "norm3"):
                 w[q + n + ".w"], w[q + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
-        w["ca_k_w"], w["ca_k_b"] = self._hw(torch.cat(kw, 0), "dec_kv"), c32(torch.cat(kb, 0))       # [L*D, D]
-        w["ca_v_w"], w["ca_v_b"] = self._hw(torch.cat(vw, 0), "dec_kv"), c32(torch.cat(vb, 0))
+        kw, kb, vw, vb = (torch.cat(t, 0).detach() for t in (kw, kb, vw, vb))                        # [L*D, D], [L*D]
+        if memory_linear is not None:
+            f64 = torch.float64
+            W2, b2 = (t.detach().to(f64) for t in memory_linear)
+            w["ca_k_pos_w"] = c32(kw)
+            kb, vb = kb.to(f64) + kw.to(f64) @ b2, vb.to(f64) + vw.to(f64) @ b2
+            kw, vw = kw.to(f64) @ W2, vw.to(f64) @ W2                                                # [L*D, F]
+        w["ca_k_w"], w["ca_k_b"] = self._hw(kw.to(f32), "dec_kv"), c32(kb)
+        w["ca_v_w"], w["ca_v_b"] = self._hw(vw.to(f32), "dec_kv"), c32(vb)
         w["dec.norm.w"], w["dec.norm.b"] = c32(P["decoder.norm.weight"]), c32(P["decoder.norm.bias"])
         w["query_embed"] = c32(P["query_embed"])
 
@@ -245,19 +260,27 @@ class _EngineBase:
             self._gemm("fc", Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
             self._gemm("proj", Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
 
-    def _decoder(self, MEM16, KIN16, B, M, D, Q, L, heads, stack_all: bool):
-        """transformer.py:114-152 over :262-291 (post-norm), tgt = zeros, query_pos = query_embed.
-        MEM16 f16 [B*M, D] = value input, KIN16 = key input (memory + pos, or memory itself).  Returns f16 rows with
-        decoder.norm applied: every layer stacked as [B,L,Q,D] (stack_all) or the last layer only [B*Q, D]; the fp32
-        copy of the last layer's normed output is left in buffer "dec_out32"."""
+    def _decoder_kv(self, VIN16, KIN16, B, M, D, L, k_pos=None):
+        """Cross-attention K / V of all L layers (transformer.py:281-284) from ONE GEMM each: [B*M, L*D] fp16 (split pairs
+        when both the projection and the decoder run x3).  VIN16 / KIN16 are the value / key inputs in the layout the packed
+        "ca_v_w" / "ca_k_w" contract over; k_pos = (Ty [h2, L*D], Tx [w2, L*D]): fp32 tables, K row m = y * w2 + x starts
+        from Ty[y] + Tx[x] (the `pos` term of `memory + pos` when the projections were composed at pack time)."""
+        W_ = self._w
+        xk = self._x3("dec") and self._x3("dec_kv")                                        # K lo planes feed the x3 scores
+        KALL = self._abuf("KALL", (B * M, L * D), xk)
+        VALL = self._abuf("VALL", (B * M, L * D), xk)
+        self._gemm("dec_kv", KIN16, W_["ca_k_w"], KALL, bias=W_["ca_k_b"], pos=k_pos)
+        self._gemm("dec_kv", VIN16, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
+        return KALL, VALL
+
+    def _decoder(self, KALL, VALL, B, M, D, Q, L, heads, stack_all: bool):
+        """transformer.py:114-152 over :262-291 (post-norm), tgt = zeros, query_pos = query_embed, on the projected memory
+        of _decoder_kv.  Returns f16 rows with decoder.norm applied: every layer stacked as [B,L,Q,D] (stack_all) or the last
+        layer only [B*Q, D]; the fp32 copy of the last layer's normed output is left in buffer "dec_out32"."""
         W_, dh, R = self._w, D // heads, B * Q
         xd = self._x3("dec")
         Ff = P_shape0(W_["dec.0.l1_w"])
-        xk = xd and self._x3("dec_kv")                                                     # K lo planes feed the x3 scores
-        KALL = self._abuf("KALL", (B * M, L * D), xk)
-        VALL = self._abuf("VALL", (B * M, L * D), xk)
-        self._gemm("dec_kv", KIN16, W_["ca_k_w"], KALL, bias=W_["ca_k_b"])                 # all layers' K / V at once
-        self._gemm("dec_kv", MEM16, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
+        xk = bool(KALL.plane)
         qpos = W_["query_embed"]
         tgt = self._buf("tgt", (R, D), f32)
         t1 = self._buf("t1", (R, D), f32)
@@ -356,7 +379,7 @@ class ZutisEngine(_EngineBase):
         for ffn in ("ffn1", "ffn2"):
             for j in range(3):
                 w[f"{ffn}.{j}.w"], w[f"{ffn}.{j}.b"] = self._hw(P[f"{ffn}.layers.{j}.weight"], ffn), c32(P[f"{ffn}.layers.{j}.bias"])
-        self._pack_decoder(w, P, D, self.dec_layers)
+        self._pack_decoder(w, P, D, self.dec_layers, memory_linear=(P["ffn1.layers.2.weight"], P["ffn1.layers.2.bias"]))
         self._w, self._packed_key = w, key
         self._geo.clear()
 
@@ -372,7 +395,16 @@ class ZutisEngine(_EngineBase):
             ops.posembed_bicubic(self._w["encoder.positional_embedding"], pos, self.grid, h, w, D, sh, sw, True)
             pe = torch.empty((4 * h * w, D), dtype=f32, device=dev)
             ops.sine_pe(pe, 2 * h, 2 * w, D)
-            g = {"pos": pos, "pe": pe}
+            # `pos @ Wk^T` (transformer.py:281 through :283's key projection, all layers): the sine PE is [py(y) | px(x)]
+            # (positional_embedding.py:47-52), so the term is Ty[y] + Tx[x] with two small tables (fp64 products, stored fp32)
+            # that the K GEMM's accumulators start from
+            h2, w2, f64 = 2 * h, 2 * w, torch.float64
+            wk = self._w["ca_k_pos_w"].to(f64)
+            pe3 = pe.view(h2, w2, D)
+            tdt = f32 if self._x3("dec_kv") else f16      # fp16 K: fp16 tables (their slice of a tile then stays in L1)
+            Ty = (pe3[:, 0, : D // 2].to(f64) @ wk[:, : D // 2].t()).to(tdt).contiguous()        # [h2, L*D]
+            Tx = (pe3[0, :, D // 2:].to(f64) @ wk[:, D // 2:].t()).to(tdt).contiguous()          # [w2, L*D]
+            g = {"pos": pos, "pe": pe, "k_pos": (Ty, Tx)}
             self._geo_put((h, w), g)
         return g
 
@@ -418,13 +450,15 @@ class ZutisEngine(_EngineBase):
         f1 = self._abuf("ffn_h1", (B * M, Fh), self._x3("ffn1"))
         ops.upsample2x_cl(h1, B, h, w, Fh, out_f16=f1, relu=True)                           # :491-495 + ReLU
         f2 = self._abuf("ffn_h2", (B * M, Fh), self._x3("ffn1"))
-        # decoder_input feeds the K/V projections, memory + pos and the mask einsum: a split pair needs the x3 ffn1 to fill it
-        DEC = self._abuf("DEC16", (B * M, D), self._x3("mask", "dec_kv"))
+        # decoder_input (ffn1's output) is the mask einsum's operand: a split pair needs the x3 ffn1 to fill it
+        DEC = self._abuf("DEC16", (B * M, D), self._x3("mask"))
         self._gemm("ffn1", f1, W_["ffn1.1.w"], f2, bias=W_["ffn1.1.b"], act=ops.ACT_RELU)
         self._gemm("ffn1", f2, W_["ffn1.2.w"], DEC, bias=W_["ffn1.2.b"])
-        KIN = self._abuf("KIN16", (B * M, D), self._x3("dec_kv"))
-        ops.add_rowperiodic_f16(DEC, geo["pe"], KIN, B * M, D, M)                           # transformer.py:281 memory+pos
-        inter16 = self._decoder(DEC, KIN, B, M, D, Q, L, self.dec_heads, stack_all=True)    # transformer.py:114-152
+        # the decoder's K / V projections of decoder_input (+ pos) contract over ffn1's hidden width (256) instead of D (768):
+        # ffn1's last Linear is composed into them at pack time (_pack_decoder) — 3x fewer flops on 22 % of the model's GEMM
+        # work, and `memory + pos` (transformer.py:281) is never materialised
+        KALL, VALL = self._decoder_kv(f2, f2, B, M, D, L, k_pos=geo["k_pos"])
+        inter16 = self._decoder(KALL, VALL, B, M, D, Q, L, self.dec_heads, stack_all=True)  # transformer.py:114-152
         RQ = B * L * Q
         g1 = self._abuf("ffn2_h1", (RQ, Fh), self._x3("ffn2"))
         g2 = self._abuf("ffn2_h2", (RQ, Fh), self._x3("ffn2"))
@@ -837,7 +871,8 @@ class SelfMaskEngine(_EngineBase):
         tok16 = self._abuf("tok16", (B * h * w, D), self._x3("dec_kv"))
         ops.layernorm(X, W_["norm.w"], W_["norm.b"], 1e-6, B * h * w, D, out_f32=tok, out_f16=tok16,
                       in_group_rows=h * w, in_group_stride=T, in_offset=1)               # norm(x)[:, 1:]  :298, selfmask.py:94-100
-        q16 = self._decoder(tok16, tok16, B, h * w, D, Q, L, self.heads, stack_all=False)    # selfmask.py:110-116 (pos=None)
+        KALL, VALL = self._decoder_kv(tok16, tok16, B, h * w, D, L)                          # selfmask.py:110-116 (pos=None)
+        q16 = self._decoder(KALL, VALL, B, h * w, D, Q, L, self.heads, stack_all=False)
         FEAT = self._abuf("FEAT16", (B * M, D), self._x3("mask"))
         ops.upsample2x_cl(tok, B, h, w, D, out_f16=FEAT)                                 # forward_pixel_decoder :131-135
         masks = torch.empty((B, 1, Q, 2 * h, 2 * w), dtype=f32, device=x.device)

@@ -107,11 +107,22 @@ def _gemm_bytes(M, N, K, batch, strideA, strideW, op_bytes, out_bytes, has_resid
     return float(a + w + M * N * batch * (out_bytes + (4 if has_residual else 0)))
 
 
+def _pos(pos, N):
+    """Argument words of the optional separable row bias: pos = (pos_y [h, >=N], pos_x [w, >=N]), both fp32 or both fp16 ->
+    rows are pixels m = img * h*w + y * w + x and pos_y[y] + pos_x[x] is added before the activation."""
+    if pos is None:
+        return (None, None, 0, 0, 0, 0)
+    ty, tx = pos
+    assert ty.dtype == tx.dtype and ty.dtype in (f32, f16) and ty.dim() == 2 and tx.dim() == 2 and ty.stride(1) == 1 and tx.stride(1) == 1
+    assert ty.stride(0) == tx.stride(0) and ty.shape[1] >= N and tx.shape[1] >= N
+    return (_p(ty), _p(tx), ty.stride(0), ty.shape[0], tx.shape[0], int(ty.dtype == f16))
+
+
 def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, act: int = ACT_NONE, *, M=None, N=None, K=None,
             lda=None, ldw=None, ldc=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None,
-            strideR: int = 0):
-    """out = act((A @ W^T) * W.out_scale + bias) + residual at the reference's fp32-class precision: A and W are split pairs
-    (Act with plane != 0); out is an f32 tensor, an fp16 tensor / plain Act, or a split Act."""
+            strideR: int = 0, pos=None):
+    """out = act((A @ W^T) * W.out_scale + bias + pos) + residual at the reference's fp32-class precision: A and W are split
+    pairs (Act with plane != 0); out is an f32 tensor, an fp16 tensor / plain Act, or a split Act.  pos: see _pos()."""
     L = _lib.load()
     if not (isinstance(A, Act) and isinstance(W, Act) and A.plane and W.plane):
         raise _lib.ZutisHipError("gemm_x3: both operands must be split pairs")
@@ -131,7 +142,8 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
     if bias is not None:
         assert bias.dtype == f32 and bias.numel() >= N
     args = (_p(a), lda, strideA, A.plane, _p(w), ldw, strideW, W.plane, _p(o), ldc, strideC, planeC, kind,
-            float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream())
+            float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N),
+            act, M, N, K, batch, _stream())
     nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 4, 4 if kind == 0 else (4 if kind == 2 else 2), residual is not None)
     _lib.check(_launch("gemm_f16x3", (2.0 * M * N * K * batch, nbytes), lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
     return out
@@ -139,8 +151,8 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
 
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residual=None, res_rows: int = 0,
          act: int = ACT_NONE, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, batch: int = 1,
-         strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None, strideR: int = 0):
-    """out = act(A @ W^T + bias) + residual[m % res_rows].  A [M,K] f16, W [N,K] f16, out f32|f16 [M,N].
+         strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None, strideR: int = 0, pos=None):
+    """out = act(A @ W^T + bias + pos) + residual[m % res_rows].  A [M,K] f16, W [N,K] f16, out f32|f16 [M,N]; pos: see _pos().
     Act operands / outputs are read / written through their hi plane (plain fp16)."""
     L = _lib.load()
     A, W, out_ret = _hp(A)[0], _hp(W)[0], out
@@ -162,7 +174,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
     if bias is not None:
         assert bias.dtype == f32 and bias.numel() >= N
     args = (_p(A), lda, strideA, _p(W), ldw, strideW, _p(out), ldc, strideC, int(out.dtype == f16),
-            _p(bias), _p(residual), ldr or 0, strideR, res_rows, act, M, N, K, batch, _stream())
+            _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N), act, M, N, K, batch, _stream())
     nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 2, 2 if out.dtype == f16 else 4, residual is not None)
     _lib.check(_launch("gemm_f16", (2.0 * M * N * K * batch, nbytes), lambda: L.zh_gemm_f16(*args)), "zh_gemm_f16")
     return out_ret
