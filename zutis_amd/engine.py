@@ -6,8 +6,8 @@ Data layout in HBM (one GPU, B images, T = 1 + h*w encoder tokens, M = 4*h*w dec
   QKV16    f16 [B*T, 3D]       packed q|k|v, consumed in place by flash attention (strided heads)
   H16      f16 [B*T, 4D]       QuickGELU(c_fc) — never stored in fp32
   TOK16    f16 [B*M, D]        x2-upsampled patch tokens (A operand of ffn1 and of the text-space projection)
-  F2       f16 [B*M, 256]      ffn1's second hidden layer = input of the composed K / V projections and of ffn1's last layer
-  DEC16    f16 [B*M, D]        decoder_input (ffn1 output) = mask-einsum operand
+  F2X      f16 [B*M, 320]      ffn1's second hidden layer (256) | 1 | 0...: input of the composed K / V projections and the
+                               mask einsum's operand (decoder_input = ffn1's last Linear of it is never formed)
   KALL/VALL f16 [B*M, L*D]     cross-attention K / V of all L decoder layers from ONE GEMM each (K = 256: ffn1's last Linear
                                composed in at pack time; the sine-PE term enters as two small fp32 tables in the K epilogue)
   weights  f16, packed once per parameter version ([N,K] row-major = torch Linear layout, K contiguous)
@@ -90,6 +90,7 @@ class _EngineBase:
         self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
         self._bufs: Dict[Tuple, torch.Tensor] = {}
         self._buf_gen = 0             # bumped on every (re)allocation: launch plans check it
+        self._buf_const: Dict[str, torch.Tensor] = {}   # buffers with constant regions: name -> the tensor that was initialised
         self._pt16_of = self._text16_of = None   # which tensors the cached f16 copies "pt16" / "text16" were made from
 
     def fork(self):
@@ -98,7 +99,7 @@ class _EngineBase:
         import copy
         self._pack()
         e = copy.copy(self)
-        e._bufs, e._buf_gen = {}, 0
+        e._bufs, e._buf_gen, e._buf_const = {}, 0, {}
         # input-independent tables are shared; captured graphs are not (they replay into the parent's buffers and stream)
         e._geo = {k: v for k, v in self._geo.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
         e._pt16_of = e._text16_of = None       # provenance of the f16 copies held in the (new, empty) buffer cache
@@ -378,7 +379,21 @@ class ZutisEngine(_EngineBase):
         self._pack_clip_visual(w, P, "encoder.", D, self.layers, self.patch)
         for ffn in ("ffn1", "ffn2"):
             for j in range(3):
+                if (ffn, j) == ("ffn1", 2):
+                    continue                              # composed into its consumers below: decoder_input is never formed
                 w[f"{ffn}.{j}.w"], w[f"{ffn}.{j}.b"] = self._hw(P[f"{ffn}.layers.{j}.weight"], ffn), c32(P[f"{ffn}.layers.{j}.bias"])
+        # decoder_input = f @ W2^T + b2 (ffn1's last Linear, zutis.py:500-503; f = its 256-wide hidden layer) has two consumers,
+        # both linear in it: the decoder's K / V projections (_pack_decoder composes W2 into them) and the mask einsum
+        # (zutis.py:196-198)  q . decoder_input[m] = (W2^T q) . f[m] + q . b2.  With f stored with a constant ones column
+        # (FX columns: f | 1 | 0...), the einsum contracts [W2^T q | q.b2 | 0] with it over FX = 320 instead of D = 768, and
+        # the [B*M, 768] decoder_input tensor and its GEMM disappear.  "mask_q.w" maps a query to that FX-vector.
+        W2, b2 = P["ffn1.layers.2.weight"].detach(), P["ffn1.layers.2.bias"].detach()
+        self.Fh = W2.shape[1]
+        self.FX = _rup(self.Fh + 1, 64)
+        wq = torch.zeros((self.FX, D), dtype=f32, device=self._device())
+        wq[: self.Fh] = W2.t()
+        wq[self.Fh] = b2
+        w["mask_q.w"] = self._hw(wq, "mask")
         self._pack_decoder(w, P, D, self.dec_layers, memory_linear=(P["ffn1.layers.2.weight"], P["ffn1.layers.2.bias"]))
         self._w, self._packed_key = w, key
         self._geo.clear()
@@ -444,19 +459,22 @@ class ZutisEngine(_EngineBase):
         # so W.up(t) + b == up(W.t + b): the first ffn1 layer and the text-space projection run on the h*w tokens (4x fewer rows)
         # and their outputs are upsampled (ReLU after the interpolation, where the reference has it).  Same function, different
         # rounding order (fp32-class in the x3 mode); the [B, 4hw, 768] upsampled token tensor is never formed.
-        Fh = P_shape0(W_["ffn1.0.w"])
+        Fh, FX = self.Fh, self.FX
         h1 = self._buf("ffn_h1_lo", (B * h * w, Fh), f32)
         self._gemm("ffn1", tok16, W_["ffn1.0.w"], h1, bias=W_["ffn1.0.b"])                  # :500-503 (layer 0, pre-ReLU)
         f1 = self._abuf("ffn_h1", (B * M, Fh), self._x3("ffn1"))
         ops.upsample2x_cl(h1, B, h, w, Fh, out_f16=f1, relu=True)                           # :491-495 + ReLU
-        f2 = self._abuf("ffn_h2", (B * M, Fh), self._x3("ffn1"))
-        # decoder_input (ffn1's output) is the mask einsum's operand: a split pair needs the x3 ffn1 to fill it
-        DEC = self._abuf("DEC16", (B * M, D), self._x3("mask"))
+        # ffn1's hidden layer 2 with the constant columns [1, 0, ...] behind it (see _pack): rows are FX wide
+        f2x = self._abuf("ffn_h2x", (B * M, FX), self._x3("ffn1"))
+        if self._buf_const.get("ffn_h2x") is not f2x.t:              # once per (re)allocation of the cached buffer
+            f2x.t[:, :, Fh:] = 0
+            f2x.t[0, :, Fh] = 1
+            self._buf_const["ffn_h2x"] = f2x.t
+        f2 = f2x.view(f2x.hi[:, :Fh])
         self._gemm("ffn1", f1, W_["ffn1.1.w"], f2, bias=W_["ffn1.1.b"], act=ops.ACT_RELU)
-        self._gemm("ffn1", f2, W_["ffn1.2.w"], DEC, bias=W_["ffn1.2.b"])
-        # the decoder's K / V projections of decoder_input (+ pos) contract over ffn1's hidden width (256) instead of D (768):
-        # ffn1's last Linear is composed into them at pack time (_pack_decoder) — 3x fewer flops on 22 % of the model's GEMM
-        # work, and `memory + pos` (transformer.py:281) is never materialised
+        # ffn1's last Linear (-> decoder_input) is composed into its consumers at pack time.  The decoder's K / V projections
+        # of decoder_input (+ pos) contract over the hidden width (256) instead of D (768) — 3x fewer flops on what was 22 % of
+        # the model's GEMM work — and `memory + pos` (transformer.py:281) is never materialised
         KALL, VALL = self._decoder_kv(f2, f2, B, M, D, L, k_pos=geo["k_pos"])
         inter16 = self._decoder(KALL, VALL, B, M, D, Q, L, self.dec_heads, stack_all=True)  # transformer.py:114-152
         RQ = B * L * Q
@@ -469,8 +487,10 @@ class ZutisEngine(_EngineBase):
         self._gemm("ffn2", g2, W_["ffn2.2.w"], q32, bias=W_["ffn2.2.b"])
         ops.l2norm_rows(q32, RQ, D, out_f16=q16)                                            # :515
         masks = torch.empty((B, L, Q, h2, w2), dtype=f32, device=x.device)
-        self._gemm("mask", q16, DEC, masks, act=ops.ACT_SIGMOID, M=L * Q, N=M, K=D, lda=D, ldw=D, ldc=M,
-                   batch=B, strideA=L * Q * D, strideW=M * D, strideC=L * Q * M)            # :196-198,209
+        qw = self._abuf("mask_q", (RQ, FX), self._x3("mask"))
+        self._gemm("mask", q16, W_["mask_q.w"], qw)                                         # [W2^T q | q.b2 | 0]
+        self._gemm("mask", qw, f2x, masks, act=ops.ACT_SIGMOID, M=L * Q, N=M, K=FX, lda=FX, ldw=FX, ldc=M,
+                   batch=B, strideA=L * Q * FX, strideW=M * FX, strideC=L * Q * M)          # :196-198,209
         tsl = self._buf("textspace_lo", (B * h * w, self.E), f32)
         self._gemm("textproj", tok16, W_["projT"], tsl)                                     # :319 on the h*w tokens
         ts = self._buf("textspace", (B * M, self.E), f32)
