@@ -123,6 +123,16 @@ def gemm_roofline(ops, run_once, step_seconds):
             "traffic": None, "algorithmic_bytes_per_launch": round(algo_bytes.get(dom, 0.0)), "flops_per_launch": round(flops_dom / nl), "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
             "measured_on": "HIP events around every GEMM launch of an instrumented eager step on one stream (kernels not overlapped)",
             "gemm_share_of_step": round(tt / step_seconds, 3)}
+    # the same launches grouped by problem shape (M x N x K [x batch]), largest GPU time first: which GEMMs set the average
+    by = {}
+    for w, a, b in prof[dom]:
+        if isinstance(w, tuple) and len(w) > 2:
+            e = by.setdefault(w[2], [0, 0.0, 0.0])
+            e[0] += 1; e[1] += w[0]; e[2] += a.elapsed_time(b) * 1e-3
+    roof["by_shape"] = [{"MxNxK": "x".join(str(d) for d in (k[:3] if k[3] == 1 else k)), "launches": v[0], "avg_us": round(v[2] / v[0] * 1e6, 1),
+                         "tflops": round(v[1] / v[2] / 1e12, 1), "frac": round(v[1] / v[2] / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 3),
+                         "share_of_kernel_time": round(v[2] / tt, 3)}
+                        for k, v in sorted(by.items(), key=lambda kv: -kv[1][2])[:8]]
     oth = "gemm_f16x3" if dom == "gemm_f16" else "gemm_f16"
     if oth in stats:
         no, fo, to = stats[oth]

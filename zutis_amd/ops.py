@@ -145,7 +145,7 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
             float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N),
             act, M, N, K, batch, _stream())
     nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 4, 4 if kind == 0 else (4 if kind == 2 else 2), residual is not None)
-    _lib.check(_launch("gemm_f16x3", (2.0 * M * N * K * batch, nbytes), lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
+    _lib.check(_launch("gemm_f16x3", (2.0 * M * N * K * batch, nbytes, (M, N, K, batch)), lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
     return out
 
 
@@ -176,7 +176,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
     args = (_p(A), lda, strideA, _p(W), ldw, strideW, _p(out), ldc, strideC, int(out.dtype == f16),
             _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N), act, M, N, K, batch, _stream())
     nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 2, 2 if out.dtype == f16 else 4, residual is not None)
-    _lib.check(_launch("gemm_f16", (2.0 * M * N * K * batch, nbytes), lambda: L.zh_gemm_f16(*args)), "zh_gemm_f16")
+    _lib.check(_launch("gemm_f16", (2.0 * M * N * K * batch, nbytes, (M, N, K, batch)), lambda: L.zh_gemm_f16(*args)), "zh_gemm_f16")
     return out_ret
 
 
