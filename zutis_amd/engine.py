@@ -30,7 +30,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, compose, ops
 from ._lib import ZutisHipError
 
 from .ops import Act
@@ -186,11 +186,8 @@ class _EngineBase:
                 w[q + n + ".w"], w[q + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
         kw, kb, vw, vb = (torch.cat(t, 0).detach() for t in (kw, kb, vw, vb))                        # [L*D, D], [L*D]
         if memory_linear is not None:
-            f64 = torch.float64
-            W2, b2 = (t.detach().to(f64) for t in memory_linear)
             w["ca_k_pos_w"] = c32(kw)
-            kb, vb = kb.to(f64) + kw.to(f64) @ b2, vb.to(f64) + vw.to(f64) @ b2
-            kw, vw = kw.to(f64) @ W2, vw.to(f64) @ W2                                                # [L*D, F]
+            kw, kb, vw, vb = compose.compose_memory_linear(kw, kb, vw, vb, *memory_linear)           # [L*D, F]
         w["ca_k_w"], w["ca_k_b"] = self._hw(kw.to(f32), "dec_kv"), c32(kb)
         w["ca_v_w"], w["ca_v_b"] = self._hw(vw.to(f32), "dec_kv"), c32(vb)
         w["dec.norm.w"], w["dec.norm.b"] = c32(P["decoder.norm.weight"]), c32(P["decoder.norm.bias"])
@@ -390,9 +387,7 @@ class ZutisEngine(_EngineBase):
         W2, b2 = P["ffn1.layers.2.weight"].detach(), P["ffn1.layers.2.bias"].detach()
         self.Fh = W2.shape[1]
         self.FX = _rup(self.Fh + 1, 64)
-        wq = torch.zeros((self.FX, D), dtype=f32, device=self._device())
-        wq[: self.Fh] = W2.t()
-        wq[self.Fh] = b2
+        wq = compose.mask_query_weight(W2, b2, self.FX)
         w["mask_q.w"] = self._hw(wq, "mask")
         self._pack_decoder(w, P, D, self.dec_layers, memory_linear=(P["ffn1.layers.2.weight"], P["ffn1.layers.2.bias"]))
         self._w, self._packed_key = w, key
@@ -413,12 +408,8 @@ class ZutisEngine(_EngineBase):
             # `pos @ Wk^T` (transformer.py:281 through :283's key projection, all layers): the sine PE is [py(y) | px(x)]
             # (positional_embedding.py:47-52), so the term is Ty[y] + Tx[x] with two small tables (fp64 products, stored fp32)
             # that the K GEMM's accumulators start from
-            h2, w2, f64 = 2 * h, 2 * w, torch.float64
-            wk = self._w["ca_k_pos_w"].to(f64)
-            pe3 = pe.view(h2, w2, D)
-            tdt = f32 if self._x3("dec_kv") else f16      # fp16 K: fp16 tables (their slice of a tile then stays in L1)
-            Ty = (pe3[:, 0, : D // 2].to(f64) @ wk[:, : D // 2].t()).to(tdt).contiguous()        # [h2, L*D]
-            Tx = (pe3[0, :, D // 2:].to(f64) @ wk[:, D // 2:].t()).to(tdt).contiguous()          # [w2, L*D]
+            tdt = f32 if self._x3("dec_kv") else f16      # fp16 K: fp16 tables (the tile's slice is staged through LDS)
+            Ty, Tx = compose.separable_pos_tables(pe, self._w["ca_k_pos_w"], 2 * h, 2 * w, tdt)   # [2h, L*D], [2w, L*D]
             g = {"pos": pos, "pe": pe, "k_pos": (Ty, Tx)}
             self._geo_put((h, w), g)
         return g
