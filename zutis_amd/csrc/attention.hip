@@ -40,7 +40,7 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 // key sets (decoder self-attention over 100 queries, small images) are not left with the 2^-11 rounding of single P / V
 // values.  One block per CU (the lo planes of K and V double the LDS tiles).
 template <int DH, int NWAVE, int X3>
-__global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_f16_kernel(AttnArgs p) {
   constexpr int NT = 64 * NWAVE;
   constexpr int KS = DH + 8;          // K row stride (halves)
   constexpr int NKS = DH / 16;        // k-steps of QK^T
@@ -82,13 +82,21 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
   for (int d = 0; d < NDT; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY;
+  // Row sums of P ride the MFMA pipe: one extra "d tile" whose V^T operand is all ones accumulates sum_k P[k][q] in every row
+  // of lacc (32 v_add_f32 per key tile leave the VALU, which is the bound; the sum is of the SAME rounded P the numerator uses).
+  f32x16 lacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  half8_t ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (half_t)1.0f;
 
-  // cooperative tile loads: chunk c -> (row = c / CPR, col chunk = c % CPR).  Two register sets: tile t+2 is requested
-  // while tile t is computed and tile t+1 (requested one iteration earlier) waits in the other set, so a global load has two
-  // key tiles of compute to land (one tile — ~0.5 us — did not cover the loaded L2 latency: the loop was latency-bound).
+  // cooperative tile loads: chunk c -> (row = c / CPR, col chunk = c % CPR).  Tile t+1 is requested before tile t is computed
+  // and stored into the other LDS buffer after it (a second register set, i.e. two tiles of load latency cover, measured no
+  // gain — the kernel is VALU-bound — and its 16 registers are what keeps dh = 64 at three waves per SIMD).
   struct TileRegs { half8_t k[NLD], v[NLD], kl[X3 ? NLD : 1], vl[X3 ? NLD : 1]; };
-  TileRegs ra, rb;
+  TileRegs ra;
   auto load_tile = [&](int kbase, TileRegs& r) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -138,7 +146,6 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
   load_tile(0, ra);
   store_tile(0, ra);
   __syncthreads();
-  if (ntiles > 1) load_tile(KT, ra);
 
   auto compute = [&](int t) {
     const int kbase = t * KT;
@@ -193,26 +200,24 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
     const float m_new = fmaxf(m_run, mx * p.scale_log2);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    float ps4[4] = {0.f, 0.f, 0.f, 0.f};      // four independent partial sums (fixed order: deterministic)
     half8_t pf[2][2], pl[X3 ? 2 : 1][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
-        ps4[r & 3] += e;
         half_t eh = (half_t)e;
         if (X3) asm volatile("" : "+v"(eh));      // one conversion only: see zh_store_h4 (common.h)
         pf[u][r >> 3][r & 7] = eh;
         if (X3) pl[u][r >> 3][r & 7] = (half_t)(e - (float)eh);
       }
-    const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-    l_run = l_run * alpha + psum;
     if (__any(alpha != 1.0f)) {
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
     }
 
     // ---- O^T += V^T P^T
@@ -220,6 +225,8 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[u][ks], lacc, 0, 0, 0);
+        if (X3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pl[u][ks], lacc, 0, 0, 0);
         const half_t* vp = sV + (32 * u + 16 * ks + tr_row) * VS + tr_col;
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
@@ -246,21 +253,20 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : 2) void attn_f16_kernel(AttnAr
   };
 
   // buffer (t+1)&1 was last read in iteration t-1 and every wave passed the barrier that ended it => free to overwrite
-  for (int t = 0; t < ntiles; t += 2) {
-    if (t + 2 < ntiles) load_tile((t + 2) * KT, rb);
+  for (int t = 0; t < ntiles; t += 2) {           // two tiles per trip: the LDS buffer index is a compile-time constant
+    if (t + 1 < ntiles) load_tile((t + 1) * KT, ra);
     compute(t);
     if (t + 1 < ntiles) store_tile(1, ra);
     __syncthreads();
-    if (t + 1 < ntiles) {
-      if (t + 3 < ntiles) load_tile((t + 3) * KT, ra);
-      compute(t + 1);
-      if (t + 2 < ntiles) store_tile(0, rb);
-      __syncthreads();
-    }
+    if (t + 1 >= ntiles) break;
+    if (t + 2 < ntiles) load_tile((t + 2) * KT, ra);
+    compute(t + 1);
+    if (t + 2 < ntiles) store_tile(0, ra);
+    __syncthreads();
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
+  // every row of lacc holds the full row sum of this lane's query (the MFMA already summed both key halves)
+  const float inv = 1.0f / lacc[0];
   const int qr = q0 + ql;
   if (qr < p.Tq) {
     half_t* op = p.O + (long)img * p.sO + (long)qr * p.ldo + hoff + 4 * hh;
