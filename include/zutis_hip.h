@@ -40,6 +40,10 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 #define ZH_ACT_SIGMOID 3   /* networks/zutis.py:209 */
 #define ZH_ACT_GELU_ERF 4  /* nn.GELU, networks/selfmask/vision_transformer.py:79 */
 
+/* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
+ * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
+ * does) — ctypes cannot see a changed argument list. */
+#define ZH_ABI_VERSION 210 /* 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);

@@ -94,6 +94,15 @@ class _RecordingProxy:
         return fn
 
 
+def header_abi_version() -> int:
+    """ZH_ABI_VERSION of include/zutis_hip.h (the header travels with the package: bindings and library must agree on it)."""
+    import re
+    m = re.search(r"^#define\s+ZH_ABI_VERSION\s+(\d+)", open(HEADER).read(), re.M)
+    if not m:
+        raise ZutisHipError(f"{HEADER}: ZH_ABI_VERSION not found")
+    return int(m.group(1))
+
+
 def load(raw: bool = False):
     """Load the shared library (building nothing: run `python -m zutis_amd.build` / __graft_entry__.build())."""
     global _lib
@@ -105,6 +114,11 @@ def load(raw: bool = False):
             "Build it with `python -m zutis_amd.build`.")
     import torch  # noqa: F401  (first: the process must use ONE HIP runtime — the one torch loads; libzutis_hip binds to it)
     lib = C.CDLL(LIB_PATH)
+    lib.zh_version.restype = C.c_int
+    built, want = lib.zh_version(), header_abi_version()
+    if built != want:       # a stale build: ctypes would pass the new argument lists to the old entry points
+        raise ZutisHipError(f"{LIB_PATH} was built for ABI {built} but include/zutis_hip.h declares {want}: "
+                            "rebuild it with `python -m zutis_amd.build`.")
     for name, (res, args) in _SIGS.items():
         if not hasattr(lib, name):
             continue  # symbol check is test_capi's job; optional groups may be absent in partial builds

@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         deps = [src, os.path.join(CSRC, "common.h")]
         if os.path.basename(src).startswith("gemm"):
             deps.append(os.path.join(CSRC, "gemm_kernel.h"))
-        if os.path.basename(src) == "plan.hip":                     # includes the dispatcher generated from the header
+        if os.path.basename(src) in ("plan.hip", "capi.hip"):       # the dispatcher generated from the header / ZH_ABI_VERSION
             deps.append(os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h"))
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):
             continue

@@ -1,5 +1,6 @@
 // C-ABI plumbing for libzutis_hip: version + thread-local error text.
 #include "common.h"
+#include "../../include/zutis_hip.h"
 #include <stdarg.h>
 
 static thread_local char g_err[512] = "";
@@ -12,7 +13,7 @@ void zh_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* zh_last_error(void) { return g_err; }
-extern "C" int zh_version(void) { return 200; }   // 2xx: split-pair (lo_plane) arguments, zh_gemm_f16x3, batched solver, device NMS
+extern "C" int zh_version(void) { return ZH_ABI_VERSION; }   // include/zutis_hip.h
 extern "C" const char* zh_arch(void) { return "gfx950"; }
 
 // ---- host-side COCO RLE (pycocotools maskApi.c rleEncode + rleToString restated): the reference encodes every kept
