@@ -39,6 +39,9 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 // amplified (|s| * 2^-11 absolute) — and the probabilities are split in registers, O += Vh.Ph + Vl.Ph + Vh.Pl, so short
 // key sets (decoder self-attention over 100 queries, small images) are not left with the 2^-11 rounding of single P / V
 // values.  One block per CU (the lo planes of K and V double the LDS tiles).
+#ifndef ZH_ATTN_ABL
+#define ZH_ATTN_ABL 0      // developer ablations (tools/attn_ablate.py): 1 no exp, 2 no P.V, 4 no K.Q^T, 8 no tile traffic and no
+#endif                     // barriers, 16 no barriers, 32 barriers only, 64 no LDS stores.  0 in the product build.
 template <int DH, int NWAVE, int X3>
 __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_f16_kernel(AttnArgs p) {
   constexpr int NT = 64 * NWAVE;
@@ -163,7 +166,11 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         half8_t kf = *(const half8_t*)(kp + 16 * ks);
+#if ZH_ATTN_ABL & 4
+        s[u][ks] += (float)kf[0] * (float)qf[ks][0];
+#else
         s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[u], 0, 0, 0);
+#endif
         if (X3) {
           half8_t kl = *(const half8_t*)(sKl[t & 1] + (32 * u + krow) * KS + 8 * hh + 16 * ks);
           s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf[ks], s[u], 0, 0, 0);
@@ -205,7 +212,11 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#if ZH_ATTN_ABL & 1
+        const float e = __builtin_fmaf(s[u][r], p.scale_log2, -m_new);
+#else
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
+#endif
         half_t eh = (half_t)e;
         if (X3) asm volatile("" : "+v"(eh));      // one conversion only: see zh_store_h4 (common.h)
         pf[u][r >> 3][r & 7] = eh;
@@ -221,6 +232,10 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
     }
 
     // ---- O^T += V^T P^T
+#if ZH_ATTN_ABL & 2
+    oacc[0][0] += (float)pf[0][0][0] + (float)pf[1][1][7] + (float)pf[0][1][3] + (float)pf[1][0][5];
+    lacc[0] += 1.0f;
+#else
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -248,11 +263,34 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
           }
         }
       }
+#endif
     }
 
   };
 
   // buffer (t+1)&1 was last read in iteration t-1 and every wave passed the barrier that ended it => free to overwrite
+#if ZH_ATTN_ABL & 8                                      // ablation: no tile traffic, no barriers
+  for (int t = 0; t < ntiles; ++t) compute(t & 1);
+#elif ZH_ATTN_ABL & 16                                   // ablation: tile traffic kept, barriers removed (racy: timing only)
+  for (int t = 0; t < ntiles; t += 2) {
+    if (t + 1 < ntiles) load_tile((t + 1) * KT, ra);
+    compute(t);
+    if (t + 1 < ntiles) store_tile(1, ra);
+    if (t + 1 >= ntiles) break;
+    if (t + 2 < ntiles) load_tile((t + 2) * KT, ra);
+    compute(t + 1);
+    if (t + 2 < ntiles) store_tile(0, ra);
+  }
+#elif ZH_ATTN_ABL & 32                                   // ablation: barriers kept, tile traffic removed
+  for (int t = 0; t < ntiles; ++t) { compute(t & 1); __syncthreads(); }
+#elif ZH_ATTN_ABL & 64                                   // ablation: global loads kept (consumed by a cheap op), no LDS stores
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) load_tile((t + 1) * KT, ra);
+    compute(t & 1);
+    if (t + 1 < ntiles) m_run += 1e-30f * (float)ra.k[0][0] * (float)ra.v[NLD - 1][7];
+    __syncthreads();
+  }
+#else
   for (int t = 0; t < ntiles; t += 2) {           // two tiles per trip: the LDS buffer index is a compile-time constant
     if (t + 1 < ntiles) load_tile((t + 1) * KT, ra);
     compute(t);
@@ -264,6 +302,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
     if (t + 2 < ntiles) store_tile(0, ra);
     __syncthreads();
   }
+#endif
 
   // every row of lacc holds the full row sum of this lane's query (the MFMA already summed both key halves)
   const float inv = 1.0f / lacc[0];
