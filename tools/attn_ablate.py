@@ -1,15 +1,19 @@
 """Where an attention key tile's time goes: the kernel rebuilt with pieces removed (-DZH_ATTN_ABL=mask: 1 no exp, 2 no P.V,
-4 no K.Q^T, 8 no tile traffic / barriers, 16 no barriers, 32 barriers only, 64 no LDS stores), timed on the encoder and cross-attention shapes.  `--build` compiles the variants
+4 no K.Q^T, 8 no tile traffic / barriers, 16 no barriers, 32 barriers only, 64 no LDS stores), timed on the encoder and cross-attention shapes.
+CAVEAT: a variant that stops writing the LDS tiles computes on constant data and clocks higher (power) — the
+no-traffic columns overstate what the traffic costs.  `--build` compiles the variants
 (hipcc, no GPU needed) into tools/_abl/; without it the script times whatever is there (run on the GPU box)."""
 import ctypes as C, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
 MASKS = [0, 1, 2, 4, 8, 16, 32, 64]
-VARIANTS = {"product": [], "no-exp": ["-DZH_ATTN_ABL=1"]}      # --ab: whole-kernel variants timed ABBA in one process (edit to taste)
+# --ab: whole-kernel variants timed ABBA in one process and compared with the first one: name -> (flags, source or None = product)
+VARIANTS = {"product": ([], None), "variant": ([], os.path.join(HERE, "_abl", "attn_variant.hip"))}   # drop a modified attention.hip there
+VARIANTS = {k: v for k, v in VARIANTS.items() if v[1] is None or os.path.exists(v[1])}
 if "--build" in sys.argv and "--ab" in sys.argv:
-    for name, flags in VARIANTS.items():
+    for name, (flags, src) in VARIANTS.items():
         out = os.path.join(HERE, "_abl", f"libattn_{name}.so")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared"] + flags +
-                              [os.path.join(ROOT, "zutis_amd/csrc/attention.hip"), os.path.join(ROOT, "zutis_amd/csrc/capi.hip"), "-o", out])
+                              [src or os.path.join(ROOT, "zutis_amd/csrc/attention.hip"), os.path.join(ROOT, "zutis_amd/csrc/capi.hip"), "-o", out])
     sys.exit(0)
 if "--build" in sys.argv:
     for m in MASKS:
@@ -45,6 +49,12 @@ for name, B, H, dh, Tq, Tk in [("enc", 32, 12, 64, 442, 442), ("cross", 32, 8, 9
         fns[m] = (lambda L=L: L.zh_attention_f16(q.data_ptr(), D, Tq * D, k.data_ptr(), D, Tk * D, v.data_ptr(), D, Tk * D, o.data_ptr(), D, Tq * D,
                                                  B, H, Tq, Tk, dh, dh ** -0.5, 0, 0, 0, 0, s))
         assert fns[m]() == 0
+    if "--ab" in sys.argv:                                            # variants must agree with the first one
+        outs = {}
+        for m in MASKS:
+            o.zero_(); fns[m](); torch.cuda.synchronize(); outs[m] = o.float().clone()
+        diffs = " ".join(f"{m}:{float((outs[m] - outs[MASKS[0]]).abs().max()):.1e}" for m in MASKS[1:])
+        print(f"{name:8s} max |diff| vs {MASKS[0]}: {diffs}  (|o| max {float(outs[MASKS[0]].abs().max()):.2f})")
     best = {m: 1e9 for m in MASKS}
     for order in (MASKS, MASKS[::-1], MASKS, MASKS[::-1]):           # ABBA: the first variant timed after a pause runs colder
         for m in order:
