@@ -25,6 +25,7 @@ port of the reference path, timed on the host cores on a bounded sample, rank 0,
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -257,6 +258,8 @@ def main():
                          "x3 mode on the output-facing contractions (passes tests/test_precision_gpu.py at 1e-3); exact = x3 everywhere")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--no-second-precision", action="store_true", help="skip the secondary timed run at the other precision (N = 1)")
+    ap.add_argument("--h2d", action="store_true", help="developer: every step first copies its batch from pinned host memory (async, on the "
+                    "step's stream) — the PCIe-inclusive rate quoted in DESIGN.md; the headline keeps inputs resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--torch-gpu-baseline", action="store_true", default=True,
@@ -308,13 +311,15 @@ def main():
         flight, and times `steps` steps through zutis_amd.distributed.StepPipeline.  Returns (engine, seconds)."""
         eng = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
         lanes = []
+        host_x = x.cpu().pin_memory() if args.h2d else None
         for li in range(n_lanes):
             e = eng if li == 0 else eng.fork()       # own activation buffers, shared packed weights
             e.forward(x)                             # eager warm-up: packs weights, sizes the buffer cache
             plan = None
+            xin = x.clone() if args.h2d else x       # --h2d: the lane's own input buffer, refilled from the host every step
 
-            def one_step(e=e):
-                out = e.forward(x)
+            def one_step(e=e, xin=xin):
+                out = e.forward(xin)
                 lo = e.semantic_logits_lowres(out["patch_tokens"], text)
                 labels = torch.empty((B, S, S), dtype=torch.int64, device=dev)
                 ops.upsample_argmax(lo, labels, B, n, lo.shape[2], lo.shape[3], S, S)
@@ -327,10 +332,14 @@ def main():
                 lo, labels = one_step()
             lanes.append(zd.Lane(lo.view(B, n, hw2), gathered=torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) if dist_on else None,
                                  stream=torch.cuda.Stream(device=dev) if n_lanes > 1 else None,
-                                 state={"eng": e, "plan": plan, "labels": labels, "step": one_step}))
+                                 state={"eng": e, "plan": plan, "labels": labels, "step": one_step, "xin": xin}))
         torch.cuda.synchronize()
 
         def launch(grp, ids):
+            if args.h2d:         # the step's batch crosses PCIe first, in stream order before the step's kernels
+                for ln in grp:
+                    with torch.cuda.stream(ln.stream) if ln.stream is not None else contextlib.nullcontext():
+                        ln.state["xin"].copy_(host_x, non_blocking=True)
             if n_lanes > 1:      # consecutive steps replayed interleaved, one stream each, from one C loop
                 zplan.run_many([ln.state["plan"] for ln in grp], [ln.stream.cuda_stream for ln in grp])
             else:                # plain eager loop on the current stream (payload tensor is re-bound: eager steps allocate)
@@ -465,7 +474,7 @@ def main():
                                    f"predict(semantic,size=({S},{S}))", "global_batch": world * B, "image_size": S,
                        "n_classes": n, "parallelism": f"dp{world}", "accumulate": "f32", "residual_stream": "f32",
                        "collective": "all_gather(low-res logits) per step, overlapped" if dist_on else "none",
-                       "steps_in_flight": n_lanes,
+                       "steps_in_flight": n_lanes, **({"input": "pinned host batch copied in every step (--h2d)"} if args.h2d else {}),
                        "launch": ("native launch plans, interleaved on %d HIP streams" % n_lanes) if n_lanes > 1 else "eager, 1 stream",
                        "flops_per_image": FLOPS_PER_IMAGE_C2 if (S, n) == (336, 81) else None},
             "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1) if (S, n) == (336, 81) else None,
