@@ -44,6 +44,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.zh_global_ln_l2_workspace_size(2, 1764, 512) == 2 * ((1764 * 512 + 4095) // 4096) * 16
 
 
+def test_stale_library_is_refused(monkeypatch):
+    """A library built for another ABI version must not be bound: ctypes would hand the new argument lists to old entry points."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "header_abi_version", lambda: 99999)
+    with pytest.raises(_lib.ZutisHipError, match="built for ABI"):
+        _lib.load()
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
