@@ -68,7 +68,7 @@ def resolve_precision(precision) -> frozenset:
     if "attn" in sites:
         sites.add("qkv")                      # Q / K lo planes come from the x3 QKV projection
     if sites & {"mask", "dec_kv"}:
-        sites.add("ffn1")                     # decoder_input's lo plane comes from the x3 ffn1
+        sites.add("ffn1")                     # their operand (ffn1's hidden layer, F2X) gets its lo plane from the x3 ffn1
     return frozenset(sites)
 
 
