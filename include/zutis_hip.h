@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 220 /* 210: pos_y / pos_x tables on the GEMMs; 220: LayerNorm-by-linearity arguments, zh_rowstats_f32 */
+#define ZH_ABI_VERSION 210 /* 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -61,19 +61,7 @@ int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, 
                 void* C, long ldc, long strideC, int out_f16,
                 const float* bias, const float* residual, long ldr, long strideR, int res_rows,
                 const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
-                const float* ln_part, int ln_nparts, int ln_D, float ln_eps, const float* ln_colsum,
-                void* out16, long ld16, long plane16, float* part_out,
                 int act, int M, int N, int K, int batch, zh_stream_t stream);
-/* LayerNorm by linearity (clip_arch.py:318-320  x + attn(ln_1(x)),  x + mlp(ln_2(x)); vision_transformer.py:160-170):
- *   ln(x) @ W^T + b  =  rs * (x @ (W * gamma)^T)  -  (mu * rs) * colsum  +  (beta @ W^T + b)        rs = 1 / sqrt(var + eps)
- * so the GEMM that follows a LayerNorm reads the UN-normalised rows (an fp16 / split-pair copy of the residual stream), with
- * gamma folded into its weights at pack time, and normalises its own accumulators; the LayerNorm pass and its output tensor
- * disappear.  Consumer arguments: ln_part [M][ln_nparts][2] = partial (sum x, sum x^2) of every A row over the LayerNorm
- * width ln_D, ln_eps, ln_colsum [N] = sum_k W[n][k] of the operand as rounded.  Producer arguments (the GEMM that writes the
- * residual stream: fp32 output, batch 1): out16 / ld16 / plane16 = fp16 (plane16 != 0: split-pair) copy of the finished rows,
- * part_out [M][parts][2] = the partial moments of the finished rows, one slot per column tile; parts = zh_gemm_f16_ln_parts(M, N,
- * batch) for this shape.  Rows that enter the first block come from zh_rowstats_f32. */
-int zh_gemm_f16_ln_parts(int M, int N, int batch);
 
 /* The same contraction at the reference's precision (the reference computes every Linear / einsum in fp32:
  * clip_arch.py:286-292 keeps LayerNorm fp32, zutis.py:55 casts the CLIP weights to fp32).  A and W are split pairs
@@ -85,10 +73,7 @@ int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void
                   void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
                   const float* bias, const float* residual, long ldr, long strideR, int res_rows,
                   const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
-                  const float* ln_part, int ln_nparts, int ln_D, float ln_eps, const float* ln_colsum,
-                  void* out16, long ld16, long plane16, float* part_out,
                   int act, int M, int N, int K, int batch, zh_stream_t stream);
-int zh_gemm_f16x3_ln_parts(int M, int N, int batch);
 
 /* Flash attention: O = softmax(scale * Q K^T) V per (image, head); Q [Tq, heads*dh] rows with stride ldq, etc.
  * f16 in/out, fp32 softmax/accumulate; head_dim in {64, 96}.
@@ -128,10 +113,6 @@ int zh_layernorm_f32(const float* x, long in_group_rows, long in_group_stride, l
                      const float* gamma, const float* beta, float eps,
                      float* out_f32, void* out_f16, void* out_f16_plus, float* out_f32_plus,
                      const float* add, int add_rows, int rows, int D, long lo_plane, zh_stream_t stream);
-
-/* Moments of the rows entering a transformer stack whose LayerNorms are folded into the GEMMs (see zh_gemm_f16): part[r] =
- * (sum x, sum x^2) — one slot per row — and, optionally, the fp16 (lo_plane != 0: split-pair) copy of x the first GEMM reads. */
-int zh_rowstats_f32(const float* x, float* part, void* out_f16, int rows, int D, long lo_plane, zh_stream_t stream);
 
 /* cat(class_embedding, patch_emb) + pos_embed, then ln_pre: clip_arch.py:384-397.  out [B,T,D] f32.
  * gamma = beta = NULL: no LayerNorm (DINO ViT prepare_tokens, selfmask/vision_transformer.py:269-281). */

@@ -29,13 +29,9 @@ _SIGS = {
     "zh_version": (C.c_int, []),
     "zh_arch": (C.c_char_p, []),
     "zh_last_error": (C.c_char_p, []),
-    "zh_gemm_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i,
-                         _vp, _i, _i, _f, _vp, _vp, _l, _l, _vp, _i, _i, _i, _i, _i, _vp]),
-    "zh_gemm_f16_ln_parts": (_i, [_i, _i, _i]),
-    "zh_gemm_f16x3_ln_parts": (_i, [_i, _i, _i]),
-    "zh_rowstats_f32": (_i, [_vp, _vp, _vp, _i, _i, _l, _vp]),
-    "zh_gemm_f16x3": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _f, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i,
-                           _vp, _i, _i, _f, _vp, _vp, _l, _l, _vp, _i, _i, _i, _i, _i, _vp]),
+    "zh_gemm_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "zh_gemm_f16x3": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _f, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i,
+                           _vp]),
     "zh_attention_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _l, _l, _l, _l, _vp]),
     "zh_attention_causal_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _f, _l, _l, _l, _l, _vp]),
     "zh_embed_tokens_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),

@@ -17,41 +17,10 @@ static bool launch_gemm(const GemmArgs& p, int batch, int out_f16, hipStream_t s
   }
 }
 
-// Tile choice for an (M, N, batch) problem — shared by the launch and by zh_gemm_f16_ln_parts (the consumer of a producer's
-// partial LayerNorm moments must know how many column tiles the producer ran).
-static int pick_tile_f16(int M, int N, int batch) {
-  const double c256 = tiling_cost(M, N, batch, 256, 256, 1, 1.0);
-  const double c192 = tiling_cost(M, N, batch, 256, 192, 1, 0.95);
-  const double c128 = tiling_cost(M, N, batch, 128, 128, 2, 0.8);
-  int pick = (c128 < c256 && c128 < c192) ? 128 : (c192 < c256 ? 192 : 256);
-  // (a 128x64 tile for the decoder's M = B*Q GEMMs measured no better than 128x128: they are slice-latency bound;
-  //  it stays reachable through ZH_GEMM_TILE=64 for experiments)
-  // few-tile GEMMs (batch-1 inference: M = 442 tokens -> 24 tiles of 128x128 on 256 CUs): 64x64 tiles on an 8-deep
-  // ring put 4x the CUs to work; measured 32 -> 16 us on the 442x768x3072 MLP projection (tools/gemm_small.py)
-  const long t128 = (long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch;
-  if (t128 <= 96) pick = 3064;
-  // narrow outputs that do not fill the chip with 128 x 128 tiles (decoder M = B*Q rows x N = 768): 128 x 64 tiles put twice the
-  // blocks to work; measured 19.6 -> 16.5 us (K = 768) and 32.7 -> 28.8 us (K = 2048) with the residual epilogue, while
-  // N = 1536 / 2048 keep 128 x 128 (tools/gemm_dec_tiles.py)
-  else if (pick == 128 && t128 <= 256 && N <= 768) pick = 64;
-  return pick;
-}
-static int tile_bn_f16(int pick) {
-  switch (pick) { case 256: return 256; case 192: return 192; case 128: case 2128: return 128; default: return 64; }
-}
-
-// Number of column tiles (= partial-moment slots per row) the fp32-output, LDS-staged form of zh_gemm_f16 runs for this shape.
-extern "C" int zh_gemm_f16_ln_parts(int M, int N, int batch) {
-  const GemmDevOverrides& dev = gemm_dev_overrides();
-  return zh_cdiv(N, tile_bn_f16(dev.tile ? dev.tile : pick_tile_f16(M, N, batch)));
-}
-
 extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, long strideW,
                            void* C, long ldc, long strideC, int out_f16,
                            const float* bias, const float* residual, long ldr, long strideR, int res_rows,
                            const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
-                           const float* ln_part, int ln_nparts, int ln_D, float ln_eps, const float* ln_colsum,
-                           void* out16, long ld16, long plane16, float* part_out,
                            int act, int M, int N, int K, int batch, hipStream_t stream) {
   ZH_CHECK_ARG(A && W && C, "zh_gemm_f16: null operand");
   ZH_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "zh_gemm_f16: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
@@ -73,11 +42,6 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   p.planeA = p.planeW = p.planeC = 0; p.out_scale = 1.0f;
   p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
   p.pos_y = pos_y; p.pos_x = pos_x; p.ld_pos = ld_pos; p.pos_hw = pos_h * pos_w; p.pos_w = pos_w; p.pos_f16 = pos_f16;
-  ZH_CHECK_ARG(zh_ln_args_ok(ln_part, ln_nparts, ln_D, ln_colsum, out16, ld16, plane16, part_out, !out_f16, N, batch),
-               "zh_gemm_f16: LayerNorm arguments: consumer needs ln_part + ln_colsum (16-byte aligned), 0 < ln_nparts <= 64, ln_D > 0; "
-               "producer (out16 / part_out) needs an fp32 output, batch 1, ld16 %% 4 == 0, plane16 %% 4 == 0");
-  p.ln_part = ln_part; p.ln_nparts = ln_nparts; p.ln_D = ln_D; p.ln_eps = ln_eps; p.ln_colsum = ln_colsum;
-  p.C16 = (half_t*)out16; p.ldc16 = ld16; p.planeC16 = plane16; p.part_out = part_out;
   p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
   // super-tile height: 3..8 measure within 1 % of each other on the model, 16 / 32 lose 13 / 36 % on 8192^3
   // (tools/gemm_vs_blaslt.py) — the order in which an XCD's 32 resident tiles share panels matters
@@ -91,7 +55,20 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
              (!bias || ((uintptr_t)bias & 15) == 0) &&
              (!residual || (ldr % 4 == 0 && strideR % 4 == 0 && ((uintptr_t)residual & 15) == 0));
   ZH_CHECK_ARG((long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch < (1L << 31), "zh_gemm_f16: grid too large");
-  int pick = pick_tile_f16(M, N, batch);
+  const double c256 = tiling_cost(M, N, batch, 256, 256, 1, 1.0);
+  const double c192 = tiling_cost(M, N, batch, 256, 192, 1, 0.95);
+  const double c128 = tiling_cost(M, N, batch, 128, 128, 2, 0.8);
+  int pick = (c128 < c256 && c128 < c192) ? 128 : (c192 < c256 ? 192 : 256);
+  // (a 128x64 tile for the decoder's M = B*Q GEMMs measured no better than 128x128: they are slice-latency bound;
+  //  it stays reachable through ZH_GEMM_TILE=64 for experiments)
+  // few-tile GEMMs (batch-1 inference: M = 442 tokens -> 24 tiles of 128x128 on 256 CUs): 64x64 tiles on an 8-deep
+  // ring put 4x the CUs to work; measured 32 -> 16 us on the 442x768x3072 MLP projection (tools/gemm_small.py)
+  const long t128 = (long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch;
+  if (t128 <= 96) pick = 3064;
+  // narrow outputs that do not fill the chip with 128 x 128 tiles (decoder M = B*Q rows x N = 768): 128 x 64 tiles put twice the
+  // blocks to work; measured 19.6 -> 16.5 us (K = 768) and 32.7 -> 28.8 us (K = 2048) with the residual epilogue, while
+  // N = 1536 / 2048 keep 128 x 128 (tools/gemm_dec_tiles.py)
+  else if (pick == 128 && t128 <= 256 && N <= 768) pick = 64;
   if (dev.tile) {
     static const int known[] = {64, 128, 192, 256, 2064, 2128, 3064};
     bool okc = false;
@@ -102,7 +79,6 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   // 16-byte row stores need 16-B aligned rows; an f16 residual is not supported (none on the hot path)
   const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&
                        ((N * esz) % 16 == 0) && !(out_f16 && residual);
-  ZH_CHECK_ARG(wide_ok || !(out16 || part_out), "zh_gemm_f16: out16 / part_out need the 16-byte aligned (LDS-staged) output form");
   bool ok;
   if (!p.vec_ok) ok = launch_gemm<2, 2, 4, 4, 4, 0>(p, batch, out_f16, stream);      // scalar-store fallback: small tile only
   else if (!wide_ok) ok = launch_gemm<2, 2, 4, 4, 4, 1>(p, batch, out_f16, stream);  // direct 8/16-B stores

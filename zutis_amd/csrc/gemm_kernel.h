@@ -45,14 +45,6 @@ struct GemmArgs {
   // separable per-pixel row bias (rows are pixels m = img * pos_hw + y * pos_w + x): pos_y[y][n] + pos_x[x][n] is added to
   // the accumulator before the activation — the tile's accumulators START from it, loaded under the ring's prologue
   const void* pos_y; const void* pos_x; long ld_pos; int pos_hw, pos_w, pos_f16;   // tables fp32, or fp16 (pos_f16)
-  // LayerNorm by linearity: LN(x) @ W^T + b = rs * (x @ (W.gamma)^T) - (mu * rs) * colsum + (beta @ W^T + b),
-  // so the GEMM that consumes a LayerNorm reads the UN-normalised rows and normalises its own output.
-  //   consumer: ln_part [M][ln_nparts][2] = partial (sum x, sum x^2) of each A row (written by the GEMM that produced it),
-  //             ln_D / ln_eps = the LayerNorm width and eps, ln_colsum [N] = sum_k W[n][k] of the operand as the MFMA sees it
-  //   producer (fp32 output, LDS-staged epilogue): C16 = fp16 (split-pair) copy of the finished rows, the next GEMM's operand;
-  //             part_out [M][nbn][2] = per-column-tile partial moments of the finished rows
-  const float* ln_part; int ln_nparts, ln_D; float ln_eps; const float* ln_colsum;
-  half_t* C16; long ldc16, planeC16; float* part_out;
   int M, N, K, act, nbm, nbn, vec_ok, group_m;
 #ifdef ZH_GEMM_PROBE
   long long* probe;   // developer build (tools/gemm_probe.py): 4 timestamps per block
@@ -455,20 +447,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const long cb = (long)batch * p.sC;
   const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
   const float osc = SPLIT ? p.out_scale : 1.0f;
-  // (rs, mu * rs) of output row m from the producer's partial moments, summed in slot order (deterministic); identity without LN.
-  // var = E[x^2] - mu^2 in fp32: fine for a residual stream (|mu| << rms); the stand-alone LayerNorm kernel stays two-pass.
-  auto ln_row = [&](int m, float& rs, float& mrs) {
-    rs = 1.0f; mrs = 0.0f;
-    if (p.ln_part) {
-      const float* q = p.ln_part + (long)(m < p.M ? m : p.M - 1) * p.ln_nparts * 2;
-      float s1 = 0.f, s2 = 0.f;
-      for (int j = 0; j < p.ln_nparts; ++j) { s1 += q[2 * j]; s2 += q[2 * j + 1]; }
-      const float inv = 1.0f / (float)p.ln_D, mu = s1 * inv;
-      const float var = fmaxf(s2 * inv - mu * mu, 0.0f);
-      rs = 1.0f / sqrtf(var + p.ln_eps);
-      mrs = mu * rs;
-    }
-  };
   if (VEC == 2) {
     // LDS-staged epilogue: the direct form stores 32-byte runs (4 lanes x 8 B) into 16 different 128-B lines per
     // instruction and measured 2.4 TB/s, fully exposed (34 % of a K=768 tile).  Here each wave transposes its tile through
@@ -483,31 +461,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     constexpr int NIT = PR * CPRW / 64;
     static_assert((PR * CPRW) % 64 == 0, "epilogue slab must divide into full wave reads");
     static_assert(NW * PR * RS <= (int)sizeof(smem), "epilogue slabs exceed the ring");
-    // producer of LayerNorm moments (fp32 output only): per-wave area of per-chunk (sum, sum^2), then per-block area of
-    // per-(row, wave column) sums, behind the slabs
-    // (a lane that has consumed a 16-byte slab chunk parks the chunk's (sum, sum^2) in its first 8 bytes; per-block area of
-    //  per-(row, wave column) sums behind the slabs)
-    constexpr int STATB = OUT == 0 ? BM * WN * 8 : 0;
-    static_assert(NW * PR * RS + STATB <= (int)sizeof(smem), "epilogue slabs + moment area exceed the ring");
     __syncthreads();                                        // ring no longer read; every LDS-DMA has landed
     char* slab = (char*)smem + wave * (PR * RS);
-    float* statb = (float*)((char*)smem + NW * (PR * RS));
-    const bool lnc = p.ln_part != nullptr;
 #pragma clang loop unroll(full)
     for (int pass = 0; pass < TM / MTP; ++pass) {
-      float rsv[MTP], mrs[MTP];
-#pragma clang loop unroll(full)
-      for (int ml = 0; ml < MTP; ++ml) ln_row(m0 + wr * TM * 16 + pass * PR + ml * 16 + frow, rsv[ml], mrs[ml]);
 #pragma clang loop unroll(full)
       for (int nt = 0; nt < TN; ++nt) {
         const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
-        if (lnc && n < p.N) cs = *(const f32x4*)(p.ln_colsum + n);
 #pragma clang loop unroll(full)
         for (int ml = 0; ml < MTP; ++ml) {
-          f32x4 v = SPLIT ? acc[nt][pass * MTP + ml] * osc : acc[nt][pass * MTP + ml];
-          v = v * rsv[ml] - cs * mrs[ml] + bv;
+          f32x4 v = SPLIT ? acc[nt][pass * MTP + ml] * osc + bv : acc[nt][pass * MTP + ml] + bv;
           if (ACT != ZH_ACT_NONE) {
             v[0] = zh_act(v[0], ACT); v[1] = zh_act(v[1], ACT); v[2] = zh_act(v[2], ACT); v[3] = zh_act(v[3], ACT);
           }
@@ -527,43 +492,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         const int m = m0 + wr * TM * 16 + pass * PR + row;
         const int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
         f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
-        const bool inb = m < p.M && n < p.N;
-        if (inb) {
+        if (m < p.M && n < p.N) {
           if (OUT == 0 && R) d += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
           if (OUT == 1) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
-          else if (OUT == 0) {
-            *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
-            if (p.C16) zh_store_h4(p.C16 + (long)m * p.ldc16 + n, p.planeC16, d);
-          } else {
+          else if (OUT == 0) *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
+          else {
             zh_store_h4((half_t*)p.C + cb + (long)m * p.ldc + n, p.planeC, d);
           }
         }
-        if (OUT == 0 && p.part_out) {
-          const float s1 = inb ? (d[0] + d[1]) + (d[2] + d[3]) : 0.f;
-          const float s2 = inb ? (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) : 0.f;
-          *(float2*)(slab + row * RS + ch * 16) = make_float2(s1, s2);
-        }
-      }
-      if (OUT == 0 && p.part_out && lane < PR) {             // this wave's LDS writes above are visible to it in program order
-        float s1 = 0.f, s2 = 0.f;
-#pragma clang loop unroll(full)
-        for (int ch = 0; ch < CPRW; ++ch) {
-          const float2 q = *(const float2*)(slab + lane * RS + ch * 16);
-          s1 += q.x; s2 += q.y;
-        }
-        *(float2*)(statb + 2 * ((wr * TM * 16 + pass * PR + lane) * WN + wc)) = make_float2(s1, s2);
-      }
-    }
-    if (OUT == 0 && p.part_out) {                            // block-wide: the WN wave columns of every row, then one slot per (row, n-tile)
-      __syncthreads();
-      if (tid < BM && m0 + tid < p.M) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma clang loop unroll(full)
-        for (int w = 0; w < WN; ++w) {
-          const float2 q = *(const float2*)(statb + 2 * (tid * WN + w));
-          s1 += q.x; s2 += q.y;
-        }
-        *(float2*)(p.part_out + ((long)(m0 + tid) * p.nbn + tn) * 2) = make_float2(s1, s2);
       }
     }
   } else if (VEC) {
@@ -577,11 +513,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       for (int mt = 0; mt < TM; ++mt) {
         const int m = m0 + (wr * TM + mt) * 16 + frow;
         if (nok && m < p.M) {
-          float rsv, mrs;
-          ln_row(m, rsv, mrs);
-          f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-          if (p.ln_part) cs = *(const f32x4*)(p.ln_colsum + n);
-          f32x4 v = acc[nt][mt] * osc * rsv - cs * mrs + bv;
+          f32x4 v = acc[nt][mt] * osc + bv;
           if (ACT != ZH_ACT_NONE) {
             v[0] = zh_act(v[0], ACT); v[1] = zh_act(v[1], ACT); v[2] = zh_act(v[2], ACT); v[3] = zh_act(v[3], ACT);
           }
@@ -602,16 +534,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     for (int mt = 0; mt < TM; ++mt) {
       const int m = m0 + (wr * TM + mt) * 16 + frow;
       const long rrow = R ? (long)(m % p.res_rows) * p.ldr : 0;
-      float rsv, mrs;
-      ln_row(m, rsv, mrs);
 #pragma clang loop unroll(full)
       for (int nt = 0; nt < TN; ++nt) {
         const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
 #pragma clang loop unroll(full)
         for (int e = 0; e < 4; ++e) {
           if (m < p.M && n + e < p.N) {
-            float x = acc[nt][mt][e] * osc * rsv;
-            if (p.ln_part) x -= mrs * p.ln_colsum[n + e];
+            float x = acc[nt][mt][e] * osc;
             if (p.bias) x += p.bias[n + e];
             x = zh_act(x, ACT);
             if (R) x += R[rrow + n + e];
@@ -651,18 +580,6 @@ static inline bool zh_pos_tables_ok(const void* pos_y, const void* pos_x, long l
   if (!pos_y && !pos_x) return true;
   return pos_y && pos_x && pos_h > 0 && pos_w > 0 && ld_pos >= N && ld_pos % 8 == 0 && N % 4 == 0 &&
          (((uintptr_t)pos_y | (uintptr_t)pos_x) & 15) == 0;
-}
-
-// host-side check of the optional LayerNorm-by-linearity arguments (consumer: ln_part / ln_colsum; producer: out16 / part_out)
-static inline bool zh_ln_args_ok(const float* ln_part, int ln_nparts, int ln_D, const float* ln_colsum, const void* out16, long ld16,
-                                 long plane16, const float* part_out, bool out_is_f32, int N, int batch) {
-  if (ln_part || ln_colsum) {
-    if (!(ln_part && ln_colsum && ln_nparts > 0 && ln_nparts <= 64 && ln_D > 0 && ((uintptr_t)ln_colsum & 15) == 0 && N % 4 == 0)) return false;
-  }
-  if (out16 || part_out) {
-    if (!(out_is_f32 && batch == 1 && (!out16 || (ld16 >= N && ld16 % 4 == 0 && plane16 % 4 == 0 && ((uintptr_t)out16 & 7) == 0)))) return false;
-  }
-  return true;
 }
 
 static inline double tiling_cost(long M, long N, int batch, int BM, int BN, int bpc, double eff) {

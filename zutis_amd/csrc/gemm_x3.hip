@@ -31,26 +31,10 @@ static bool launch_x3(const GemmArgs& p, int batch, int out_kind, hipStream_t st
   return false;
 }
 
-// Tile choice (shared with zh_gemm_f16x3_ln_parts): 256 x 128 or 192 x 128 (8 waves, 144 / 120 KiB ring, one block per CU; the
-// 192-row tile quantises N = 768 GEMMs into 1.73 rounds of the chip instead of 1.31) or 128 x 64 (4 waves, two blocks per CU)
-static int pick_tile_x3(int M, int N, int batch) {
-  const int forced = gemm_dev_overrides().tile;
-  if (forced == 64 || forced == 192 || forced == 256) return forced;
-  const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
-  const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
-  const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
-  return (c64 < c256 && c64 < c192) ? 64 : (c192 < c256 ? 192 : 256);
-}
-
-// Number of column tiles (= partial-moment slots per row) of the fp32-output, LDS-staged form of zh_gemm_f16x3 for this shape.
-extern "C" int zh_gemm_f16x3_ln_parts(int M, int N, int batch) { return zh_cdiv(N, pick_tile_x3(M, N, batch) == 64 ? 64 : 128); }
-
 extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void* W, long ldw, long strideW, long planeW,
                              void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
                              const float* bias, const float* residual, long ldr, long strideR, int res_rows,
                              const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
-                             const float* ln_part, int ln_nparts, int ln_D, float ln_eps, const float* ln_colsum,
-                             void* out16, long ld16, long plane16, float* part_out,
                              int act, int M, int N, int K, int batch, hipStream_t stream) {
   ZH_CHECK_ARG(A && W && C, "zh_gemm_f16x3: null operand");
   ZH_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "zh_gemm_f16x3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
@@ -75,11 +59,6 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   p.C = C; p.ldc = ldc; p.sC = strideC; p.planeC = planeC; p.out_scale = out_scale;
   p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
   p.pos_y = pos_y; p.pos_x = pos_x; p.ld_pos = ld_pos; p.pos_hw = pos_h * pos_w; p.pos_w = pos_w; p.pos_f16 = pos_f16;
-  ZH_CHECK_ARG(zh_ln_args_ok(ln_part, ln_nparts, ln_D, ln_colsum, out16, ld16, plane16, part_out, out_kind == 0, N, batch),
-               "zh_gemm_f16x3: LayerNorm arguments: consumer needs ln_part + ln_colsum (16-byte aligned), 0 < ln_nparts <= 64, ln_D > 0; "
-               "producer (out16 / part_out) needs an fp32 output, batch 1, ld16 %% 4 == 0, plane16 %% 4 == 0");
-  p.ln_part = ln_part; p.ln_nparts = ln_nparts; p.ln_D = ln_D; p.ln_eps = ln_eps; p.ln_colsum = ln_colsum;
-  p.C16 = (half_t*)out16; p.ldc16 = ld16; p.planeC16 = plane16; p.part_out = part_out;
   p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
   p.group_m = gemm_dev_overrides().group_m;
 #ifdef ZH_GEMM_PROBE
@@ -95,8 +74,12 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
                        (out_kind == 1 ? (N % 8 == 0) : true) && (out_kind != 2 || (ldc % 8 == 0 && planeC % 8 == 0 && N % 8 == 0));
   // 256 x 128 or 192 x 128 (8 waves, 144 / 120 KiB ring, one block per CU; the 192-row tile quantises N = 768 GEMMs into
   // 1.73 rounds of the chip instead of 1.31) or 128 x 64 (4 waves, two blocks per CU) for small problems
-  const int pick = pick_tile_x3(M, N, batch);
-  ZH_CHECK_ARG(wide_ok || !(out16 || part_out), "zh_gemm_f16x3: out16 / part_out need the 16-byte aligned (LDS-staged) output form");
+  const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
+  const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
+  const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
+  int pick = (c64 < c256 && c64 < c192) ? 64 : (c192 < c256 ? 192 : 256);
+  const int forced = gemm_dev_overrides().tile;
+  if (forced == 64 || forced == 192 || forced == 256) pick = forced;
   bool ok;
   if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
   else if (!wide_ok) ok = launch_x3<2, 2, 4, 2, 3, 1>(p, batch, out_kind, stream);

@@ -88,39 +88,6 @@ extern "C" int zh_layernorm_f32(const float* x, long in_group_rows, long in_grou
   return ZH_OK;
 }
 
-// ---- moments of the rows that ENTER a transformer stack whose LayerNorms are folded into the following GEMMs (zh_gemm_f16:
-//      "LayerNorm by linearity"): part[r] = (sum x, sum x^2), one slot per row, plus the fp16 / split-pair copy the first GEMM reads.
-//      Inside the stack the residual GEMMs' epilogues produce both (clip_arch.py:318-320).
-__global__ __launch_bounds__(256) void rowstats_kernel(const float* x, float* part, half_t* out16, int rows, int D, long lo_plane) {
-  const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  const int nv = D >> 2;
-  const f32x4* xp = (const f32x4*)(x + r * D);
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    const int c = lane + 64 * j;
-    if (c < nv) {
-      const f32x4 v = xp[c];
-      s1 += (v[0] + v[1]) + (v[2] + v[3]);
-      s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-      if (out16) zh_store_h4(out16 + r * D + 4 * c, lo_plane, v);
-    }
-  }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if (lane == 0) { part[2 * r] = s1; part[2 * r + 1] = s2; }
-}
-
-extern "C" int zh_rowstats_f32(const float* x, float* part, void* out_f16, int rows, int D, long lo_plane, hipStream_t stream) {
-  ZH_CHECK_ARG(x && part && rows > 0 && lo_plane % 4 == 0, "zh_rowstats_f32: bad arguments");
-  ZH_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV && D > 0, "zh_rowstats_f32: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXV);
-  hipLaunchKernelGGL(rowstats_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, x, part, (half_t*)out_f16, rows, D, lo_plane);
-  ZH_CHECK_LAUNCH("zh_rowstats_f32");
-  return ZH_OK;
-}
-
 // ---- token assembly + ln_pre: networks/clip_arch.py:384-397
 //   t[b,0] = class_embedding + pos[0];  t[b,1+i] = patch[b,i] + pos[1+i];  X = LN(t)
 struct AsmArgs {

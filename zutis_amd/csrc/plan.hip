@@ -4,7 +4,7 @@
 #include "../../include/zutis_hip.h"
 #include <string.h>
 
-struct ZhCmd { int op; int pad; unsigned long long a[40]; };
+struct ZhCmd { int op; int pad; unsigned long long a[32]; };
 
 static inline float zh_w2f(unsigned long long w) { unsigned u = (unsigned)w; float f; memcpy(&f, &u, 4); return f; }
 static inline double zh_w2d(unsigned long long w) { double d; memcpy(&d, &w, 8); return d; }

@@ -118,44 +118,9 @@ def _pos(pos, N):
     return (_p(ty), _p(tx), ty.stride(0), ty.shape[0], tx.shape[0], int(ty.dtype == f16))
 
 
-def _ln(ln, emit, N):
-    """Argument words of the LayerNorm-by-linearity extensions (zutis_hip.h).
-    ln   = (part f32 [M, nparts, 2], nparts, D, eps, colsum f32 [N]): this GEMM consumes un-normalised rows and normalises its output;
-    emit = (out16 Act | None, part_out f32 [M, parts, 2] | None): this (fp32-output) GEMM also writes the fp16 / split-pair copy of its
-           finished rows and their partial moments."""
-    c = (None, 0, 0, 0.0, None)
-    if ln is not None:
-        part, nparts, D, eps, colsum = ln
-        assert part.dtype == f32 and colsum.dtype == f32 and colsum.numel() >= N
-        c = (_p(part), int(nparts), int(D), float(eps), _p(colsum))
-    e = (None, 0, 0, None)
-    if emit is not None:
-        o16, part_out = emit
-        oh, pl = _hp(o16) if o16 is not None else (None, 0)
-        assert part_out is None or part_out.dtype == f32
-        e = (_p(oh), oh.stride(-2) if oh is not None else 0, pl, _p(part_out))
-    return c + e
-
-
-def gemm_ln_parts(M: int, N: int, batch: int = 1, x3: bool = False) -> int:
-    """Partial-moment slots per row that a producer GEMM of this shape writes (= its number of column tiles)."""
-    L = _lib.load(raw=True)
-    return int((L.zh_gemm_f16x3_ln_parts if x3 else L.zh_gemm_f16_ln_parts)(M, N, batch))
-
-
-def rowstats(x: torch.Tensor, part: torch.Tensor, out_f16=None, rows=None, D=None):
-    """part[r] = (sum x[r], sum x[r]^2) and, optionally, the fp16 / split-pair copy of x (zh_rowstats_f32)."""
-    L = _lib.load()
-    rows = x.shape[0] if rows is None else rows
-    D = x.shape[-1] if D is None else D
-    oh, pl = _hp(out_f16) if out_f16 is not None else (None, 0)
-    assert x.dtype == f32 and part.dtype == f32 and part.numel() >= 2 * rows
-    _lib.check(L.zh_rowstats_f32(_p(x), _p(part), _p(oh), rows, D, pl, _stream()), "zh_rowstats_f32")
-
-
 def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, act: int = ACT_NONE, *, M=None, N=None, K=None,
             lda=None, ldw=None, ldc=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None,
-            strideR: int = 0, pos=None, ln=None, emit=None):
+            strideR: int = 0, pos=None):
     """out = act((A @ W^T) * W.out_scale + bias + pos) + residual at the reference's fp32-class precision: A and W are split
     pairs (Act with plane != 0); out is an f32 tensor, an fp16 tensor / plain Act, or a split Act.  pos: see _pos()."""
     L = _lib.load()
@@ -177,7 +142,7 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
     if bias is not None:
         assert bias.dtype == f32 and bias.numel() >= N
     args = (_p(a), lda, strideA, A.plane, _p(w), ldw, strideW, W.plane, _p(o), ldc, strideC, planeC, kind,
-            float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N), *_ln(ln, emit, N),
+            float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N),
             act, M, N, K, batch, _stream())
     nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 4, 4 if kind == 0 else (4 if kind == 2 else 2), residual is not None)
     _lib.check(_launch("gemm_f16x3", (2.0 * M * N * K * batch, nbytes, (M, N, K, batch)), lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
@@ -186,7 +151,7 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
 
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residual=None, res_rows: int = 0,
          act: int = ACT_NONE, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, batch: int = 1,
-         strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None, strideR: int = 0, pos=None, ln=None, emit=None):
+         strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None, strideR: int = 0, pos=None):
     """out = act(A @ W^T + bias + pos) + residual[m % res_rows].  A [M,K] f16, W [N,K] f16, out f32|f16 [M,N]; pos: see _pos().
     Act operands / outputs are read / written through their hi plane (plain fp16)."""
     L = _lib.load()
@@ -209,7 +174,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
     if bias is not None:
         assert bias.dtype == f32 and bias.numel() >= N
     args = (_p(A), lda, strideA, _p(W), ldw, strideW, _p(out), ldc, strideC, int(out.dtype == f16),
-            _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N), *_ln(ln, emit, N), act, M, N, K, batch, _stream())
+            _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N), act, M, N, K, batch, _stream())
     nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 2, 2 if out.dtype == f16 else 4, residual is not None)
     _lib.check(_launch("gemm_f16", (2.0 * M * N * K * batch, nbytes, (M, N, K, batch)), lambda: L.zh_gemm_f16(*args)), "zh_gemm_f16")
     return out_ret
