@@ -43,8 +43,9 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   p.bias = bias; p.R = residual; p.ldr = ldr; p.sR = strideR; p.res_rows = res_rows;
   p.pos_y = pos_y; p.pos_x = pos_x; p.ld_pos = ld_pos; p.pos_hw = pos_h * pos_w; p.pos_w = pos_w; p.pos_f16 = pos_f16;
   p.M = M; p.N = N; p.K = K; p.act = act; p.nbm = p.nbn = 0;
-  // super-tile height: 3..8 measure within 1 % of each other on the model, 16 / 32 lose 13 / 36 % on 8192^3
-  // (tools/gemm_vs_blaslt.py) — the order in which an XCD's 32 resident tiles share panels matters
+  // super-tile height: 3..8 measure within 1-3 % of each other on the model (4: least fabric traffic, 134 vs 141 MB per launch,
+  // and the best step), 14: -1 %, 16 / 32 lose 13 / 36 % on 8192^3 (tools/gemm_vs_blaslt.py) — the order in which an XCD's 32
+  // resident tiles share panels matters
   const GemmDevOverrides& dev = gemm_dev_overrides();
   p.group_m = dev.group_m;
 #ifdef ZH_GEMM_PROBE
