@@ -12,7 +12,7 @@ VARIANTS = {k: v for k, v in VARIANTS.items() if v[1] is None or os.path.exists(
 if "--build" in sys.argv and "--ab" in sys.argv:
     for name, (flags, src) in VARIANTS.items():
         out = os.path.join(HERE, "_abl", f"libattn_{name}.so")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared"] + flags +
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-I", os.path.join(ROOT, "zutis_amd/csrc")] + flags +
                               [src or os.path.join(ROOT, "zutis_amd/csrc/attention.hip"), os.path.join(ROOT, "zutis_amd/csrc/capi.hip"), "-o", out])
     sys.exit(0)
 if "--build" in sys.argv:

@@ -22,7 +22,7 @@ struct AttnArgs {
   const half_t* K; long ldk, sK;
   const half_t* V; long ldv, sV;
   half_t* O; long ldo, sO;
-  int Tq, Tk, H;
+  int Tq, Tk, H, nqb, groups;
   float scale_log2;
   int causal;       // keys > query masked (CLIP text tower, clip_arch.py:525-531)
   long planeQ, planeK, planeV, planeO;   // X3 kernels: lo planes of the split-pair Q / K / V inputs; planeO != 0: O is written as a split pair
@@ -57,8 +57,16 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
   __shared__ __attribute__((aligned(16))) half_t sVl[X3 ? 2 : 1][X3 ? KT * VS : 8];   // lo plane of V (X3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int head = blockIdx.y, img = blockIdx.z;
-  const int q0 = blockIdx.x * (32 * NWAVE) + wave * 32;
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2, so the query
+  // blocks of one (image, head) — which all stream the same K / V — get ids that are congruent mod 8 and meet in one L2:
+  // id = ((group / 8) * nqb + qb) * 8 + group % 8, group = img * heads + head.  The grid is padded to a multiple of 8 groups.
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int rr = id >> 3;
+  const int qb = rr % p.nqb;
+  const int group = (rr / p.nqb) * 8 + (id & 7);
+  if (group >= p.groups) return;                        // padding blocks (whole workgroup, before any barrier)
+  const int head = group % p.H, img = group / p.H;
+  const int q0 = qb * (32 * NWAVE) + wave * 32;
   const int ql = lane & 31, hh = lane >> 5;
   const long hoff = (long)head * DH;
 
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
 
   int ntiles = (p.Tk + KT - 1) / KT;
   if (p.causal) {                                           // key tiles entirely above this block's last query are skipped
-    const int qlast = min(p.Tq, (int)(blockIdx.x + 1) * (32 * NWAVE)) - 1;
+    const int qlast = min(p.Tq, (qb + 1) * (32 * NWAVE)) - 1;
     ntiles = min(ntiles, qlast / KT + 1);
   }
   const int qidx = q0 + ql;
@@ -345,7 +353,11 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   p.planeQ = planeQ; p.planeK = planeK; p.planeV = planeV; p.planeO = planeO;
   // 128-query (4-wave) blocks: each K/V tile is shared four ways.  A 64-query (2-wave) variant was measured slower on
   // every shape of the model (encoder 301 vs 423 TF, cross-attention 230 vs 397 TF) and was dropped.
-  dim3 grid(zh_cdiv(Tq, 128), heads, batch);
+  p.nqb = zh_cdiv(Tq, 128);
+  p.groups = heads * batch;
+  const long nblk = (long)zh_cdiv(p.groups, 8) * 8 * p.nqb;  // decoded XCD-aware in the kernel
+  ZH_CHECK_ARG(nblk < (1L << 31), "zh_attention_f16: grid too large");
+  dim3 grid((unsigned)nblk);
   const bool x3 = planeQ != 0;
   if (head_dim == 64) {
     if (x3) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1>), grid, dim3(256), 0, stream, p);
