@@ -6,7 +6,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzutis_hip.so")
+LIB_PATH = os.environ.get("ZUTIS_HIP_LIB") or os.path.join(HERE, "libzutis_hip.so")   # override: developer A/B builds only
 HEADER = os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h")
 
 _lib = None

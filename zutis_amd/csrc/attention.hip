@@ -61,9 +61,15 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
   // blocks of one (image, head) — which all stream the same K / V — get ids that are congruent mod 8 and meet in one L2:
   // id = ((group / 8) * nqb + qb) * 8 + group % 8, group = img * heads + head.  The grid is padded to a multiple of 8 groups.
   const int id = blockIdx.y * gridDim.x + blockIdx.x;
+#ifdef ZH_ATTN_PLAIN_ORDER                               // developer A/B build: query blocks of a group on consecutive ids
+  const int rr = id;
+  const int qb = rr % p.nqb;
+  const int group = rr / p.nqb;
+#else
   const int rr = id >> 3;
   const int qb = rr % p.nqb;
   const int group = (rr / p.nqb) * 8 + (id & 7);
+#endif
   if (group >= p.groups) return;                        // padding blocks (whole workgroup, before any barrier)
   const int head = group % p.H, img = group / p.H;
   const int q0 = qb * (32 * NWAVE) + wave * 32;
