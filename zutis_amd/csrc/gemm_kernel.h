@@ -122,7 +122,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const int gfirst = gid * p.group_m;
   const int grows = min(p.nbm - gfirst, p.group_m);
   const int gl = trem - gid * gsz;
+#ifdef ZH_X_WALK_N                                      // developer A/B: consecutive ids walk the n-tiles of one m-tile
+  const int tm = gfirst + gl / p.nbn, tn = gl % p.nbn;
+#else
   const int tm = gfirst + gl % grows, tn = gl / grows;
+#endif
   const int m0 = tm * BM, n0 = tn * BN;
 
   const half_t* A = p.A + (long)batch * p.sA;
