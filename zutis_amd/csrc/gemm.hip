@@ -70,12 +70,13 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   // blocks to work; measured 19.6 -> 16.5 us (K = 768) and 32.7 -> 28.8 us (K = 2048) with the residual epilogue, while
   // N = 1536 / 2048 keep 128 x 128 (tools/gemm_dec_tiles.py)
   else if (pick == 128 && t128 <= 256 && N <= 768) pick = 64;
-  if (dev.tile) {
+  const int forced = dev.tile ? dev.tile : (M <= 4096 ? dev.tile_small : 0);
+  if (forced) {
     static const int known[] = {64, 128, 192, 256, 2064, 2128, 3064};
     bool okc = false;
-    for (int k : known) okc |= (k == dev.tile);
-    ZH_CHECK_ARG(okc, "zh_gemm_f16: ZH_GEMM_TILE=%d is not a tile code (64|128|192|256|2064|2128|3064)", dev.tile);
-    pick = dev.tile;
+    for (int k : known) okc |= (k == forced);
+    ZH_CHECK_ARG(okc, "zh_gemm_f16: ZH_GEMM_TILE(_SMALL)=%d is not a tile code (64|128|192|256|2064|2128|3064)", forced);
+    pick = forced;
   }
   // 16-byte row stores need 16-B aligned rows; an f16 residual is not supported (none on the hot path)
   const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&

@@ -595,12 +595,13 @@ static inline double tiling_cost(long M, long N, int batch, int BM, int BN, int 
 
 // Developer overrides, read ONCE per process (never per launch): ZH_GEMM_GROUP_M = super-tile height,
 // ZH_GEMM_TILE = forced tile code (validated by the caller; unknown codes are an argument error).
-struct GemmDevOverrides { int group_m; int tile; };
+struct GemmDevOverrides { int group_m; int tile; int tile_small; };   // tile_small: ZH_GEMM_TILE_SMALL, applied to M <= 4096 only
 static inline const GemmDevOverrides& gemm_dev_overrides() {
   static const GemmDevOverrides o = [] {
-    GemmDevOverrides v{GROUP_M, 0};
+    GemmDevOverrides v{GROUP_M, 0, 0};
     if (const char* g = getenv("ZH_GEMM_GROUP_M")) { const int x = atoi(g); if (x >= 1) v.group_m = x; }
     if (const char* t = getenv("ZH_GEMM_TILE")) v.tile = atoi(t);
+    if (const char* t = getenv("ZH_GEMM_TILE_SMALL")) v.tile_small = atoi(t);
     return v;
   }();
   return o;
