@@ -43,18 +43,27 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 #define ZH_ATTN_ABL 0      // developer ablations (tools/attn_ablate.py): 1 no exp, 2 no P.V, 4 no K.Q^T, 8 no tile traffic and no
 #endif                     // barriers, 16 no barriers, 32 barriers only, 64 no LDS stores.  0 in the product build.
 template <int DH, int NWAVE, int X3>
-__global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_f16_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NWAVE, X3 ? (DH == 64 ? 2 : 1) : (DH == 64 ? 3 : 2)) void attn_f16_kernel(AttnArgs p) {
   constexpr int NT = 64 * NWAVE;
   constexpr int KS = DH + 8;          // K row stride (halves)
   constexpr int NKS = DH / 16;        // k-steps of QK^T
   constexpr int NDT = DH / 32;        // 32-row d tiles of O^T
   constexpr int CPR = DH / 8;         // 16-byte chunks per K/V row
-  constexpr int NLD = (KT * CPR) / NT;
-  static_assert((KT * CPR) % NT == 0, "tile chunks must divide over the block");
-  __shared__ __attribute__((aligned(16))) half_t sKb[2][KT * KS];   // double-buffered: one barrier per key tile
-  __shared__ __attribute__((aligned(16))) half_t sKl[X3 ? 2 : 1][X3 ? KT * KS : 8];   // lo plane of K (X3)
-  __shared__ __attribute__((aligned(16))) half_t sVb[2][KT * VS];
-  __shared__ __attribute__((aligned(16))) half_t sVl[X3 ? 2 : 1][X3 ? KT * VS : 8];   // lo plane of V (X3)
+  // keys per tile: 64, except the split-pair dh = 64 kernel — its lo planes double the LDS tiles and its three-product
+  // accumulators the registers, so at 64 keys only one workgroup fits a CU (one wave per SIMD, nothing to overlap with);
+  // 32-key tiles halve both and two workgroups fit
+#ifdef ZH_ATTN_X3_KT64
+  constexpr int KTT = KT;
+#else
+  constexpr int KTT = (X3 && DH == 64) ? 32 : KT;
+#endif
+  constexpr int NU = KTT / 32;        // 32-key slot tiles per key tile
+  constexpr int NLD = (KTT * CPR) / NT;
+  static_assert((KTT * CPR) % NT == 0, "tile chunks must divide over the block");
+  __shared__ __attribute__((aligned(16))) half_t sKb[2][KTT * KS];   // double-buffered: one barrier per key tile
+  __shared__ __attribute__((aligned(16))) half_t sKl[X3 ? 2 : 1][X3 ? KTT * KS : 8];   // lo plane of K (X3)
+  __shared__ __attribute__((aligned(16))) half_t sVb[2][KTT * VS];
+  __shared__ __attribute__((aligned(16))) half_t sVl[X3 ? 2 : 1][X3 ? KTT * VS : 8];   // lo plane of V (X3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2, so the query
@@ -154,10 +163,10 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
   const int tr_row = 8 * hh + ((lane & 15) >> 2);
   const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
-  int ntiles = (p.Tk + KT - 1) / KT;
+  int ntiles = (p.Tk + KTT - 1) / KTT;
   if (p.causal) {                                           // key tiles entirely above this block's last query are skipped
     const int qlast = min(p.Tq, (qb + 1) * (32 * NWAVE)) - 1;
-    ntiles = min(ntiles, qlast / KT + 1);
+    ntiles = min(ntiles, qlast / KTT + 1);
   }
   const int qidx = q0 + ql;
   load_tile(0, ra);
@@ -165,15 +174,15 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
   __syncthreads();
 
   auto compute = [&](int t) {
-    const int kbase = t * KT;
+    const int kbase = t * KTT;
     const half_t* sK = sKb[t & 1];
     const half_t* sV = sVb[t & 1];
     // a wave whose 32 queries all lie beyond Tq (T = 442: two of the last block's four) only helps with the tile loads
     if (q0 < p.Tq) {
     // ---- S^T = K Q^T  (two 32-key slot tiles)
-    f32x16 s[2];
+    f32x16 s[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
       const half_t* kp = sK + (32 * u + krow) * KS + 8 * hh;
@@ -194,9 +203,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
     }
     // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
     float mx = -INFINITY;
-    if (kbase + KT > p.Tk || (p.causal && kbase + KT - 1 > q0)) {   // ragged last tile / tiles crossing the diagonal
+    if (kbase + KTT > p.Tk || (p.causal && kbase + KTT - 1 > q0)) {   // ragged last tile / tiles crossing the diagonal
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kbase + 32 * u + 16 * (r >> 3) + 8 * hh + (r & 7);
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
     {   // 32 scores per lane: four independent v_max3 chains instead of one 32-deep dependent chain
       float m4[4] = {mx, mx, mx, mx};
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; r += 8) {
           m4[0] = fmaxf(fmaxf(m4[0], s[u][r + 0]), s[u][r + 1]);
@@ -221,9 +230,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
     const float m_new = fmaxf(m_run, mx * p.scale_log2);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    half8_t pf[2][2], pl[X3 ? 2 : 1][2];
+    half8_t pf[NU][2], pl[X3 ? NU : 1][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
 #if ZH_ATTN_ABL & 1
@@ -247,11 +256,11 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
 
     // ---- O^T += V^T P^T
 #if ZH_ATTN_ABL & 2
-    oacc[0][0] += (float)pf[0][0][0] + (float)pf[1][1][7] + (float)pf[0][1][3] + (float)pf[1][0][5];
+    oacc[0][0] += (float)pf[0][0][0] + (float)pf[NU - 1][1][7] + (float)pf[0][1][3] + (float)pf[NU - 1][0][5];
     lacc[0] += 1.0f;
 #else
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[u][ks], lacc, 0, 0, 0);
@@ -287,11 +296,11 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
   for (int t = 0; t < ntiles; ++t) compute(t & 1);
 #elif ZH_ATTN_ABL & 16                                   // ablation: tile traffic kept, barriers removed (racy: timing only)
   for (int t = 0; t < ntiles; t += 2) {
-    if (t + 1 < ntiles) load_tile((t + 1) * KT, ra);
+    if (t + 1 < ntiles) load_tile((t + 1) * KTT, ra);
     compute(t);
     if (t + 1 < ntiles) store_tile(1, ra);
     if (t + 1 >= ntiles) break;
-    if (t + 2 < ntiles) load_tile((t + 2) * KT, ra);
+    if (t + 2 < ntiles) load_tile((t + 2) * KTT, ra);
     compute(t + 1);
     if (t + 2 < ntiles) store_tile(0, ra);
   }
@@ -299,19 +308,19 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 1 : (DH == 64 ? 3 : 2)) void attn_
   for (int t = 0; t < ntiles; ++t) { compute(t & 1); __syncthreads(); }
 #elif ZH_ATTN_ABL & 64                                   // ablation: global loads kept (consumed by a cheap op), no LDS stores
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) load_tile((t + 1) * KT, ra);
+    if (t + 1 < ntiles) load_tile((t + 1) * KTT, ra);
     compute(t & 1);
     if (t + 1 < ntiles) m_run += 1e-30f * (float)ra.k[0][0] * (float)ra.v[NLD - 1][7];
     __syncthreads();
   }
 #else
   for (int t = 0; t < ntiles; t += 2) {           // two tiles per trip: the LDS buffer index is a compile-time constant
-    if (t + 1 < ntiles) load_tile((t + 1) * KT, ra);
+    if (t + 1 < ntiles) load_tile((t + 1) * KTT, ra);
     compute(t);
     if (t + 1 < ntiles) store_tile(1, ra);
     __syncthreads();
     if (t + 1 >= ntiles) break;
-    if (t + 2 < ntiles) load_tile((t + 2) * KT, ra);
+    if (t + 2 < ntiles) load_tile((t + 2) * KTT, ra);
     compute(t + 1);
     if (t + 2 < ntiles) store_tile(0, ra);
     __syncthreads();
