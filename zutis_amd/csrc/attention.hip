@@ -43,23 +43,23 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 #define ZH_ATTN_ABL 0      // developer ablations (tools/attn_ablate.py): 1 no exp, 2 no P.V, 4 no K.Q^T, 8 no tile traffic and no
 #endif                     // barriers, 16 no barriers, 32 barriers only, 64 no LDS stores.  0 in the product build.
 template <int DH, int NWAVE, int X3>
-__global__ __launch_bounds__(64 * NWAVE, X3 ? (DH == 64 ? 2 : 1) : (DH == 64 ? 3 : 2)) void attn_f16_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_f16_kernel(AttnArgs p) {
   constexpr int NT = 64 * NWAVE;
   constexpr int KS = DH + 8;          // K row stride (halves)
   constexpr int NKS = DH / 16;        // k-steps of QK^T
   constexpr int NDT = DH / 32;        // 32-row d tiles of O^T
   constexpr int CPR = DH / 8;         // 16-byte chunks per K/V row
-  // keys per tile: 64, except the split-pair dh = 64 kernel — its lo planes double the LDS tiles and its three-product
+  // keys per tile: 64, except the split-pair kernels — their lo planes double the LDS tiles and their three-product
   // accumulators the registers, so at 64 keys only one workgroup fits a CU (one wave per SIMD, nothing to overlap with);
-  // 32-key tiles halve both and two workgroups fit
+  // 32-key tiles halve both and two or three workgroups fit
 #ifdef ZH_ATTN_X3_KT64
   constexpr int KTT = KT;
 #else
-  constexpr int KTT = (X3 && DH == 64) ? 32 : KT;
+  constexpr int KTT = X3 ? 32 : KT;
 #endif
   constexpr int NU = KTT / 32;        // 32-key slot tiles per key tile
-  constexpr int NLD = (KTT * CPR) / NT;
-  static_assert((KTT * CPR) % NT == 0, "tile chunks must divide over the block");
+  constexpr int NLD = (KTT * CPR + NT - 1) / NT;              // chunk passes per thread (the last may be partial: dh = 96 x 32 keys)
+  constexpr bool LDFULL = (KTT * CPR) % NT == 0;
   __shared__ __attribute__((aligned(16))) half_t sKb[2][KTT * KS];   // double-buffered: one barrier per key tile
   __shared__ __attribute__((aligned(16))) half_t sKl[X3 ? 2 : 1][X3 ? KTT * KS : 8];   // lo plane of K (X3)
   __shared__ __attribute__((aligned(16))) half_t sVb[2][KTT * VS];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? (DH == 64 ? 2 : 1) : (DH == 64 ? 3
       const int c = tid + i * NT;
       const int row = c / CPR, cc = c - row * CPR;
       const int key = kbase + row;
-      if (key < p.Tk) {
+      if (key < p.Tk && (LDFULL || c < KTT * CPR)) {
         r.k[i] = *(const half8_t*)(K + (long)key * p.ldk + cc * 8);
         r.v[i] = *(const half8_t*)(V + (long)key * p.ldv + cc * 8);
         if (X3) {
@@ -148,11 +148,13 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? (DH == 64 ? 2 : 1) : (DH == 64 ? 3
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
       const int row = c / CPR, cc = c - row * CPR;
-      *(half8_t*)(sKb[buf] + row * KS + cc * 8) = r.k[i];
-      *(half8_t*)(sVb[buf] + row * VS + cc * 8) = r.v[i];
-      if (X3) {
-        *(half8_t*)(sKl[buf] + row * KS + cc * 8) = r.kl[i];
-        *(half8_t*)(sVl[buf] + row * VS + cc * 8) = r.vl[i];
+      if (LDFULL || c < KTT * CPR) {
+        *(half8_t*)(sKb[buf] + row * KS + cc * 8) = r.k[i];
+        *(half8_t*)(sVb[buf] + row * VS + cc * 8) = r.v[i];
+        if (X3) {
+          *(half8_t*)(sKl[buf] + row * KS + cc * 8) = r.kl[i];
+          *(half8_t*)(sVl[buf] + row * VS + cc * 8) = r.vl[i];
+        }
       }
     }
   };
