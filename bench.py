@@ -18,7 +18,11 @@ streams by one C loop (zh_plan_run_multi), so one batch's kernel tails, launch g
 others' MFMA phases (measured: 1 -> 2 in flight +15 %, 2 -> 3 +2.7 %, 4 loses).  Every step still does all of its work inside the timed region; `--inflight 1` is the plain
 one-stream eager loop.
 
-Prints ONE JSON line on rank 0 (contract in the task brief) incl. `roofline` (dominant kernel = the fp16 MFMA
+The headline runs at `--precision exact`: every contraction in the f16x3 mode (fp16 split pairs, three MFMA products per
+accumulator, fp32-class), i.e. the reference's own fp32 arithmetic class; the narrower `fast` precision (north-star tolerance
+1e-3) is timed as `second_precision`.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) incl. `roofline` (dominant kernel = the f16x3 MFMA
 GEMM, measured with HIP events around every launch of an instrumented step) and `cpu_baseline` (the oracle = CPU
 port of the reference path, timed on the host cores on a bounded sample, rank 0, N=1 only).
 """
@@ -49,8 +53,9 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: 
 FLOPS_PER_IMAGE_C2 = 124.4e9 + 0.146e9  # forward + semantic predict
 
 
-def live_pmc_traffic(extra_args, timeout_s=240):
-    """HBM bytes per launch of the plain fp16-operand GEMM kernel, measured NOW: two child runs of this script under
+def live_pmc_traffic(extra_args, split: int, timeout_s=240):
+    """HBM bytes per launch of the dominant GEMM kernel family (split = 1: gemm_f16_kernel<..., SPLIT=1>, the f16x3 kernel;
+    0: the plain fp16-operand kernel), measured NOW: two child runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC block cannot hold both counters; --kernel-trace
     only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), corrected for gfx950 (FETCH_SIZE tallies 128-B requests at
     64 B: read bytes = 2 * FETCH_SIZE; WRITE_SIZE exact; both in KiB).  Returns (bytes_per_launch | None, note)."""
@@ -76,7 +81,7 @@ def live_pmc_traffic(extra_args, timeout_s=240):
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
                     k = r["Kernel_Name"]
-                    if "gemm_f16_kernel" in k and k.rstrip().endswith(", 0>(GemmArgs)") and r["Counter_Name"] == counter:
+                    if "gemm_f16_kernel" in k and k.rstrip().endswith(", %d>(GemmArgs)" % split) and r["Counter_Name"] == counter:
                         tot[counter] = tot.get(counter, 0.0) + float(r["Counter_Value"])
                         cnt[counter] = cnt.get(counter, 0) + 1
         except Exception as e:                                   # profiler unavailable / refused: report, never fail the bench
@@ -88,7 +93,7 @@ def live_pmc_traffic(extra_args, timeout_s=240):
     fetch = tot["FETCH_SIZE"] / cnt["FETCH_SIZE"] * 1024.0
     write = tot["WRITE_SIZE"] / cnt["WRITE_SIZE"] * 1024.0
     return round(2.0 * fetch + write), (f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --inflight 1 --steps 2` run by this "
-                                        f"bench ({cnt['FETCH_SIZE']} launches of the plain GEMM kernel): 2*FETCH_SIZE ({2 * fetch / 1e6:.1f} MB) + WRITE_SIZE "
+                                        f"bench ({cnt['FETCH_SIZE']} launches of gemm_f16_kernel<..., SPLIT={split}>): 2*FETCH_SIZE ({2 * fetch / 1e6:.1f} MB) + WRITE_SIZE "
                                         f"({write / 1e6:.1f} MB) per launch, gfx950 correction")
 
 
@@ -119,8 +124,15 @@ def gemm_roofline(ops, run_once, step_seconds):
     dom = "gemm_f16" if g1[2] >= g3[2] else "gemm_f16x3"               # the kernel family with the larger GPU time
     nl, flops_dom, tt = stats[dom]
     ach = flops_dom / tt / 1e12
-    roof = {"bound": "mfma", "kernel": "gemm_f16_kernel" + ("<SPLIT=1> (zh_gemm_f16x3)" if dom == "gemm_f16x3" else " (zh_gemm_f16)"),
-            "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+    # f16x3: every algorithmic product is three fp16 MFMAs (hi*hi + lo*hi + hi*lo), so the ceiling for ALGORITHMIC flops is a
+    # third of the dense fp16 MFMA peak; achieved / peak then equals (MFMA flops issued per second) / 2.5 PF
+    x3 = dom == "gemm_f16x3"
+    peak = MFMA_F16_DENSE_PEAK_TFLOPS / 3.0 if x3 else MFMA_F16_DENSE_PEAK_TFLOPS
+    roof = {"bound": "mfma", "kernel": "gemm_f16_kernel" + ("<SPLIT=1> (zh_gemm_f16x3)" if x3 else " (zh_gemm_f16)"),
+            "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "peak_note": ("algorithmic-flop ceiling of the f16x3 mode = 2500 TFLOP/s dense fp16 MFMA peak / 3 MFMA products per fp32-class "
+                          "product; frac == MFMA flops issued per second / 2500" if x3 else "dense fp16 MFMA peak (MI355X_MICROARCH.md)"),
+            "mfma_issue_tflops": round(ach * (3.0 if x3 else 1.0), 1),
             "traffic": None, "algorithmic_bytes_per_launch": round(algo_bytes.get(dom, 0.0)), "flops_per_launch": round(flops_dom / nl), "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
             "measured_on": "HIP events around every GEMM launch of an instrumented eager step on one stream (kernels not overlapped)",
             "gemm_share_of_step": round(tt / step_seconds, 3)}
@@ -131,7 +143,7 @@ def gemm_roofline(ops, run_once, step_seconds):
             e = by.setdefault(w[2], [0, 0.0, 0.0])
             e[0] += 1; e[1] += w[0]; e[2] += a.elapsed_time(b) * 1e-3
     roof["by_shape"] = [{"MxNxK": "x".join(str(d) for d in (k[:3] if k[3] == 1 else k)), "launches": v[0], "avg_us": round(v[2] / v[0] * 1e6, 1),
-                         "tflops": round(v[1] / v[2] / 1e12, 1), "frac": round(v[1] / v[2] / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 3),
+                         "tflops": round(v[1] / v[2] / 1e12, 1), "frac": round(v[1] / v[2] / 1e12 / peak, 3),
                          "share_of_kernel_time": round(v[2] / tt, 3)}
                         for k, v in sorted(by.items(), key=lambda kv: -kv[1][2])[:8]]
     oth = "gemm_f16x3" if dom == "gemm_f16" else "gemm_f16"
@@ -141,6 +153,9 @@ def gemm_roofline(ops, run_once, step_seconds):
                               "share_of_step": round(to / step_seconds, 3)}
     if g3[0]:
         roof["x3_note"] = "zh_gemm_f16x3 issues three MFMAs per algorithmic product: its MFMA-pipe rate is 3x its algorithmic TFLOP/s"
+    # flops the engine EXECUTES per step (sum of 2*M*N*K / 4*Tq*Tk*dh over the launches; the pack-time compositions of DESIGN 2a
+    # remove work the reference's 124.5 GFLOP / image counts)
+    roof["executed_algorithmic_flops_per_step"] = round(sum(v[1] for k, v in stats.items() if k.startswith(("gemm", "attention"))))
     for an in ("attention_f16", "attention_f16x3"):
         if an in stats:
             na, fa, ta = stats[an]
@@ -253,13 +268,17 @@ def main():
                          "(BASELINE config 4).  c5: CLIP ViT-L/14@336 image-embedding extraction, 256 / GPU / step (config 5)")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
-    ap.add_argument("--precision", default="fast", choices=["fast", "exact", "f16"],
-                    help="engine precision (zutis_amd/engine.py): fast = fp16 MFMA operands in the transformer bodies + the fp32-class "
-                         "x3 mode on the output-facing contractions (passes tests/test_precision_gpu.py at 1e-3); exact = x3 everywhere")
+    ap.add_argument("--precision", default="exact", choices=["fast", "exact", "f16"],
+                    help="engine precision (zutis_amd/engine.py): exact (default, the headline) = every contraction in the f16x3 mode, the "
+                         "reference's fp32 arithmetic class; fast = fp16 MFMA operands in the transformer bodies + x3 on the output-facing "
+                         "contractions (passes tests/test_precision_gpu.py at the north-star 1e-3; reported as second_precision)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--no-second-precision", action="store_true", help="skip the secondary timed run at the other precision (N = 1)")
     ap.add_argument("--h2d", action="store_true", help="developer: every step first copies its batch from pinned host memory (async, on the "
                     "step's stream) — the PCIe-inclusive rate quoted in DESIGN.md; the headline keeps inputs resident in HBM")
+    ap.add_argument("--d2h", action="store_true", help="developer: every step ends with its int64 label maps copied to pinned host memory on the "
+                    "step's stream (the reference's predict ends in .cpu().numpy(), networks/zutis.py:372)")
+    ap.add_argument("--no-io-rates", action="store_true", help="skip the short extra runs that report the PCIe-inclusive rates (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--torch-gpu-baseline", action="store_true", default=True,
@@ -306,17 +325,23 @@ def main():
     hw2 = (2 * ((S - cfg.patch) // cfg.patch + 1)) ** 2
     n_lanes = max(1, args.inflight)
 
-    def timed_run(precision: str, steps: int, warmup: int):
+    engines = {}
+
+    def timed_run(precision: str, steps: int, warmup: int, h2d: bool = False, d2h: bool = False):
         """Builds the engine for `precision`, one lane (engine fork + launch plan + stream + gather buffer) per step in
-        flight, and times `steps` steps through zutis_amd.distributed.StepPipeline.  Returns (engine, seconds)."""
-        eng = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
+        flight, and times `steps` steps through zutis_amd.distributed.StepPipeline.  Returns (engine, seconds).
+        h2d: every step first copies its batch from pinned host memory; d2h: every step ends with its label maps copied to
+        pinned host memory (both asynchronous, in stream order on the step's own stream)."""
+        eng = engines.get(precision)
+        if eng is None:
+            eng = engines[precision] = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
         lanes = []
-        host_x = x.cpu().pin_memory() if args.h2d else None
+        host_x = x.cpu().pin_memory() if h2d else None
         for li in range(n_lanes):
             e = eng if li == 0 else eng.fork()       # own activation buffers, shared packed weights
             e.forward(x)                             # eager warm-up: packs weights, sizes the buffer cache
             plan = None
-            xin = x.clone() if args.h2d else x       # --h2d: the lane's own input buffer, refilled from the host every step
+            xin = x.clone() if h2d else x            # h2d: the lane's own input buffer, refilled from the host every step
 
             def one_step(e=e, xin=xin):
                 out = e.forward(xin)
@@ -332,11 +357,12 @@ def main():
                 lo, labels = one_step()
             lanes.append(zd.Lane(lo.view(B, n, hw2), gathered=torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) if dist_on else None,
                                  stream=torch.cuda.Stream(device=dev) if n_lanes > 1 else None,
-                                 state={"eng": e, "plan": plan, "labels": labels, "step": one_step, "xin": xin}))
+                                 state={"eng": e, "plan": plan, "labels": labels, "step": one_step, "xin": xin,
+                                        "host_labels": torch.empty((B, S, S), dtype=torch.int64).pin_memory() if d2h else None}))
         torch.cuda.synchronize()
 
         def launch(grp, ids):
-            if args.h2d:         # the step's batch crosses PCIe first, in stream order before the step's kernels
+            if h2d:              # the step's batch crosses PCIe first, in stream order before the step's kernels
                 for ln in grp:
                     with torch.cuda.stream(ln.stream) if ln.stream is not None else contextlib.nullcontext():
                         ln.state["xin"].copy_(host_x, non_blocking=True)
@@ -346,6 +372,10 @@ def main():
                 for ln in grp:
                     lo, ln.state["labels"] = ln.state["step"]()
                     ln.payload = lo.view(B, n, hw2)
+            if d2h:              # networks/zutis.py:372 `.cpu().numpy()`: the label maps leave the device, in stream order
+                for ln in grp:
+                    with torch.cuda.stream(ln.stream) if ln.stream is not None else contextlib.nullcontext():
+                        ln.state["host_labels"].copy_(ln.state["labels"], non_blocking=True)
         pipe = zd.StepPipeline(lanes, launch, gather=dist_on)
         pipe.run(max(warmup, n_lanes))
         pipe.drain()
@@ -365,14 +395,26 @@ def main():
             dt = float(t.item())
         return eng, dt
 
-    eng, elapsed = timed_run(args.precision, args.steps, args.warmup)
-    # second line (N = 1 only, bounded): the same workload with every contraction in the reference-equivalent x3 mode
+    eng, elapsed = timed_run(args.precision, args.steps, args.warmup, h2d=args.h2d, d2h=args.d2h)
+    # second line (N = 1 only, bounded): the same workload at the other precision (default: "fast", narrower than the reference
+    # in the transformer bodies — reported, not the headline)
     other = None
     if world == 1 and not args.no_second_precision:
         oprec = "exact" if args.precision != "exact" else "fast"
-        osteps = max(3, args.steps // 2)
-        oeng, odt = timed_run(oprec, osteps, max(1, args.warmup // 2))
+        osteps = args.steps
+        oeng, odt = timed_run(oprec, osteps, max(1, args.warmup // 2), h2d=args.h2d, d2h=args.d2h)
         other = {"precision": oprec, "eng": oeng, "value": round(B * osteps / odt, 2), "ms_per_step": round(odt / osteps * 1e3, 3), "steps": osteps}
+    # PCIe-inclusive rates of the headline precision (N = 1, same number of steps): labels out, and batch in + labels out
+    io_rates = None
+    if world == 1 and not args.no_io_rates and not (args.h2d or args.d2h):
+        io_rates = {}
+        for key, kw in (("d2h", dict(d2h=True)), ("h2d_d2h", dict(h2d=True, d2h=True))):
+            _, idt = timed_run(args.precision, args.steps, max(1, args.warmup // 2), **kw)
+            io_rates[key] = {"value": round(B * args.steps / idt, 2), "ms_per_step": round(idt / args.steps * 1e3, 3)}
+        io_rates["what"] = ("same run with, per step, d2h: the int64 label maps [%d,%d,%d] (%.1f MB) copied to pinned host memory on the step's "
+                            "stream (networks/zutis.py:372 ends in .cpu().numpy()); h2d_d2h: additionally the fp32 batch (%.1f MB) copied in "
+                            "from pinned host memory first (trainer.py:328 image.to(device)); `value` of this line keeps both resident"
+                            % (B, S, S, B * S * S * 8 / 1e6, B * 3 * S * S * 4 / 1e6))
 
     # ---- roofline of the dominant kernel: HIP events (torch current stream == launch stream) around every launch
     roof = None
@@ -382,18 +424,12 @@ def main():
             eng.predict_semantic(out["patch_tokens"], text, (S, S))
         roof = gemm_roofline(ops, one_eager_step, elapsed / args.steps)
         if world == 1 and not args.no_live_traffic:
-            extra = ["--precision", args.precision, "--batch", str(B), "--size", str(S), "--classes", str(n)]
-            roof["traffic"], roof["traffic_source"] = live_pmc_traffic(extra)
-        if roof.get("traffic") is None:
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # recorded passes of the same command
-            if os.path.exists(pmc) and B == 32 and S == 336 and args.precision == "fast":
-                roof["traffic"] = json.load(open(pmc))["gemm_f16_kernel_all_variants"]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = (str(roof.get("traffic_source") or "") + "; fell back to profiles/r02_pmc_traffic.json (recorded, all "
-                                          "GEMM variants pooled)").lstrip("; ")
+            extra = ["--precision", args.precision, "--batch", str(B), "--size", str(S), "--classes", str(n), "--no-io-rates"]
+            roof["traffic"], roof["traffic_source"] = live_pmc_traffic(extra, 1 if "f16x3" in roof["kernel"] else 0)
         if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 2)
-        roof["measured_on"] += ("; rocprofv3 --stats of `bench.py --inflight 1` = profiles/r02_bench_kernel_stats.csv, of the default "
-                                "run with steps in flight = profiles/r02_bench_inflight_kernel_stats.csv")
+        roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r03_bench_%s_kernel_stats.csv"
+                                % args.precision)
 
     # ---- CPU baseline: the oracle (CPU port of the reference path) on a bounded sample, rank 0 at N=1 only
     cpu = None
@@ -448,22 +484,41 @@ def main():
                 o = O.zutis_forward(Pg, xi, cfg.patch, cfg.dec_heads)
                 lo = O.semantic_logits_lowres(o["patch_tokens"], text)
                 return F.interpolate(lo, size=(S, S), mode="bilinear", align_corners=False).argmax(dim=1)   # zutis.py:366-372
-        for _ in range(2):
-            gpu_pass(x)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            lab_t = gpu_pass(x)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / 5
+
+        def time_leg(sdpa: bool):
+            O.ENCODER_SDPA = sdpa
+            try:
+                for _ in range(2):
+                    gpu_pass(x)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    gpu_pass(x)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / 5
+            finally:
+                O.ENCODER_SDPA = False
+        # faithful leg: the encoder's nn.MultiheadAttention(need_weights=False) (clip_arch.py:314-316) reaches torch's fused
+        # F.scaled_dot_product_attention; the decoder's calls (transformer.py:272-286, need_weights left True) the explicit
+        # matmul-softmax-matmul.  Second leg: explicit attention everywhere (what rounds 1-2 timed).
+        try:
+            dt_sdpa = time_leg(True)
+        except Exception as e:                            # SDPA unavailable for fp32 on this build: say so, keep the explicit leg
+            dt_sdpa, sdpa_err = None, f"{type(e).__name__}: {e}"
+        dt_expl = time_leg(False)
+        dt = dt_sdpa if dt_sdpa is not None else dt_expl
         torch_gpu = {"value": round(B / dt, 1), "unit": "images/s", "kind": "port",
-                     "what": "oracle op sequence (F.conv2d / F.linear / softmax / F.interpolate / einsum) in stock PyTorch-ROCm fp32 eager "
-                             "on the same MI355X, batch %d, 5 timed passes after 2 warm-ups" % B}
+                     "encoder_attention": "F.scaled_dot_product_attention (fused)" if dt_sdpa is not None else "explicit (SDPA failed: %s)" % sdpa_err,
+                     "explicit_attention_everywhere": round(B / dt_expl, 1),
+                     "what": "the reference's op sequence (F.conv2d / F.linear / SDPA in the encoder as nn.MultiheadAttention(need_weights=False) "
+                             "dispatches, explicit softmax attention in the decoder / F.interpolate / einsum) in stock PyTorch-ROCm fp32 eager "
+                             "on the same MI355X, batch %d, 5 timed passes after 2 warm-ups per leg" % B}
 
     if rank == 0:
         total_images = world * B * args.steps
         line = {
-            "metric": f"images/sec, COCO2017-val-shaped ViT-B/16 dense semantic segmentation @{S}px (ZUTIS forward + semantic predict)",
+            "metric": f"images/sec, COCO2017-val-shaped ViT-B/16 dense semantic segmentation @{S}px (ZUTIS forward + semantic predict), "
+                      f"batches of {B} per GPU, {n_lanes} independent batch{'es' if n_lanes > 1 else ''} in flight",
             "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
@@ -478,8 +533,11 @@ def main():
                        "launch": ("native launch plans, interleaved on %d HIP streams" % n_lanes) if n_lanes > 1 else "eager, 1 stream",
                        "flops_per_image": FLOPS_PER_IMAGE_C2 if (S, n) == (336, 81) else None},
             "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1) if (S, n) == (336, 81) else None,
+            "model_tflops_note": "images/s x the REFERENCE model's 124.5 GFLOP per image (SURVEY 8d; MFU convention) per GPU — not executed flops: "
+                                 "the engine executes fewer (roofline.executed_algorithmic_flops_per_step, DESIGN 2a)",
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             **({"torch_gpu_baseline": torch_gpu} if torch_gpu else {}),
+            **({"io_inclusive": io_rates} if io_rates else {}),
         }
         if other is not None:       # the same workload at the other precision (same steps-in-flight setup, fewer steps)
             line["second_precision"] = {"mode": other["precision"], "dtype": PRECISION_DTYPE[other["precision"]],
@@ -487,6 +545,8 @@ def main():
                                         "ms_per_step": other["ms_per_step"], "steps": other["steps"], "parity": other.get("parity")}
         if torch_gpu:
             line["vs_torch_gpu_fp32_eager"] = round(line["value"] / torch_gpu["value"], 2)
+            if other is not None:
+                line["second_precision"]["vs_torch_gpu_fp32_eager"] = round(other["value"] / torch_gpu["value"], 2)
     if dist_on:
         dist.destroy_process_group()      # first: RCCL prints its version banner on stdout when the communicator goes away
     if rank == 0:

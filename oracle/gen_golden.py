@@ -342,6 +342,46 @@ def gen_a4():
     print("a4", d["arch"], {k: v.shape for k, v in d.items() if not k.startswith("fp_")}, len([k for k in d if k.startswith("fp_")]), "keys")
 
 
+E1_CASES = {"small": (detgen.ZutisConfig(width=128, layers=2, patch=14, grid=3, embed_dim=64), 3),
+            "l14_336": (detgen.ZutisConfig(width=1024, layers=2, patch=14, grid=24, embed_dim=768), 2)}   # ViT-L/14@336 geometry, 2 layers
+
+
+def gen_encode_image():
+    """E1 (utils/extract_image_embeddings.py:72-73): `model.encode_image(x)` = `self.visual(x)` (clip_arch.py:531-532) followed by
+    the L2 normalisation.  The third-party `clip` package is absent, but the reference's own VisionTransformer keeps CLIP's
+    ORIGINAL forward as a comment (clip_arch.py:413-431) next to the modified one — so the real submodules (conv1 / class_embedding /
+    positional_embedding / ln_pre / transformer / ln_post / proj, clip_arch.py:335-354) are run here in exactly that order.
+    Stores only the outputs: unit-norm embeddings for a small tower and for the ViT-L/14@336 geometry (24x24 grid, D = 1024,
+    2 layers); inputs / weights are regenerated from zutis_amd/detgen.py by the tests."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for m in [k for k in sys.modules if k.startswith("networks") or k.startswith("utils")]:
+        del sys.modules[m]
+    from networks.clip_arch import VisionTransformer
+    d = {}
+    for tag, (cfg, B) in E1_CASES.items():
+        R = cfg.patch * cfg.grid
+        vt = VisionTransformer(input_resolution=R, patch_size=cfg.patch, width=cfg.width, layers=cfg.layers, heads=cfg.width // 64,
+                               output_dim=cfg.embed_dim)
+        sd = {k[len("encoder."):]: torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items() if k.startswith("encoder.")}
+        vt.load_state_dict(sd, strict=True)
+        vt.eval().requires_grad_(False)
+        x = torch.from_numpy(detgen.images(B, R, R, seed=5))
+        with torch.no_grad():
+            t = vt.conv1(x)
+            t = t.reshape(t.shape[0], t.shape[1], -1).permute(0, 2, 1)
+            t = torch.cat([vt.class_embedding.to(t.dtype) + torch.zeros(t.shape[0], 1, t.shape[-1], dtype=t.dtype), t], dim=1)
+            t = t + vt.positional_embedding.to(t.dtype)
+            t = vt.ln_pre(t)
+            t = vt.transformer(t.permute(1, 0, 2)).permute(1, 0, 2)
+            e = vt.ln_post(t[:, 0, :]) @ vt.proj
+            e = e / torch.linalg.norm(e, ord=2, dim=1, keepdim=True)               # extract_image_embeddings.py:73
+        d[f"{tag}_shape"] = np.array([B, R, cfg.width, cfg.layers, cfg.patch, cfg.grid, cfg.embed_dim])
+        d[f"{tag}_embeddings"] = e.numpy()
+        print("encode_image", tag, e.shape, float(e.norm(dim=1).mean()))
+    np.savez_compressed(os.path.join(GOLD, "encode_image.npz"), **d)
+
+
 class _FakeCuda:
     """`clip.tokenize(texts).cuda()` in the reference loop: hand the CPU tensor back."""
     def __init__(self, t):
@@ -370,6 +410,9 @@ if __name__ == "__main__":
     if "--selfmask-only" in sys.argv:
         gen_selfmask()
         sys.exit(0)
+    if "--encode-image-only" in sys.argv:
+        gen_encode_image()
+        sys.exit(0)
     gen_ops()
     gen_selfmask()
     gen_bilateral()
@@ -379,3 +422,4 @@ if __name__ == "__main__":
     gen_e2e("vitb32_224", detgen.VIT_B32, b=1, H=224, W=224, n_cat=81, size=(224, 224), full=False)
     gen_c3()
     gen_a4()
+    gen_encode_image()

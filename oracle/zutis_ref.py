@@ -42,13 +42,20 @@ def layer_norm(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float =
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
+# bench.py's GPU-eager baseline leg only: route the encoder's attention (need_weights=False call sites) through
+# F.scaled_dot_product_attention — what nn.MultiheadAttention(batch_first=False, need_weights=False) dispatches to via
+# F.multi_head_attention_forward in this PyTorch (the fused SDPA kernel) — instead of the explicit matmul-softmax-matmul.
+ENCODER_SDPA = False
+
+
 def mha(q_in: Tensor, k_in: Tensor, v_in: Tensor, in_w: Tensor, in_b: Tensor,
-        out_w: Tensor, out_b: Tensor, n_heads: int, attn_mask: Optional[Tensor] = None) -> Tensor:
+        out_w: Tensor, out_b: Tensor, n_heads: int, attn_mask: Optional[Tensor] = None, need_weights: bool = True) -> Tensor:
     """nn.MultiheadAttention forward (packed in_proj rows = [Wq;Wk;Wv]), batch-first.
 
     Reference call sites: networks/clip_arch.py:314-316 (self-attention, need_weights=False)
-    and networks/transformer.py:272-286 (decoder self/cross attention).
+    and networks/transformer.py:272-286 (decoder self/cross attention, need_weights left at its default True).
     q_in [B,Tq,D], k_in/v_in [B,Tk,D] -> [B,Tq,D].  Scale 1/sqrt(dh), softmax over keys.
+    need_weights=False + ENCODER_SDPA: the same function through torch's fused SDPA (baseline timing leg only).
     """
     B, Tq, D = q_in.shape
     Tk = k_in.shape[1]
@@ -56,6 +63,9 @@ def mha(q_in: Tensor, k_in: Tensor, v_in: Tensor, in_w: Tensor, in_b: Tensor,
     q = F.linear(q_in, in_w[:D], in_b[:D]).view(B, Tq, n_heads, dh).transpose(1, 2)
     k = F.linear(k_in, in_w[D:2 * D], in_b[D:2 * D]).view(B, Tk, n_heads, dh).transpose(1, 2)
     v = F.linear(v_in, in_w[2 * D:], in_b[2 * D:]).view(B, Tk, n_heads, dh).transpose(1, 2)
+    if ENCODER_SDPA and not need_weights:
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask).transpose(1, 2).reshape(B, Tq, D)
+        return F.linear(o, out_w, out_b)
     s = torch.matmul(q * (1.0 / math.sqrt(dh)), k.transpose(-1, -2))
     if attn_mask is not None:                    # additive float mask [Tq,Tk] (clip_arch.py:525-531: -inf above the diagonal)
         s = s + attn_mask
@@ -89,7 +99,7 @@ def clip_vit_forward(P: Dict[str, Tensor], x: Tensor, patch: int, prefix: str = 
         p = f"{prefix}transformer.resblocks.{i}."
         y = layer_norm(t, P[p + "ln_1.weight"], P[p + "ln_1.bias"])
         t = t + mha(y, y, y, P[p + "attn.in_proj_weight"], P[p + "attn.in_proj_bias"],
-                    P[p + "attn.out_proj.weight"], P[p + "attn.out_proj.bias"], heads)
+                    P[p + "attn.out_proj.weight"], P[p + "attn.out_proj.bias"], heads, need_weights=False)
         y = layer_norm(t, P[p + "ln_2.weight"], P[p + "ln_2.bias"])
         y = F.linear(y, P[p + "mlp.c_fc.weight"], P[p + "mlp.c_fc.bias"])
         y = y * torch.sigmoid(1.702 * y)                                       # QuickGELU :295-297
@@ -100,7 +110,8 @@ def clip_vit_forward(P: Dict[str, Tensor], x: Tensor, patch: int, prefix: str = 
 
 def clip_encode_image(P: Dict[str, Tensor], x: Tensor, patch: int, prefix: str = "encoder.") -> Tensor:
     """Original CLIP CLS embedding (clip_arch.py:413-431 comments, :531-532): ln_post(x[:,0]) @ proj, fixed pos-embed,
-    then L2 normalise (utils/extract_image_embeddings.py:72-73).  PARITY UNPINNED by reference tests: `clip` is absent."""
+    then L2 normalise (utils/extract_image_embeddings.py:72-73).  Pinned: tests/golden/encode_image.npz holds the embeddings of
+    the reference's own VisionTransformer submodules run in the order of that original forward (gen_golden.py::gen_encode_image)."""
     B = x.shape[0]
     D = P[prefix + "class_embedding"].shape[0]
     heads = D // 64
@@ -114,7 +125,7 @@ def clip_encode_image(P: Dict[str, Tensor], x: Tensor, patch: int, prefix: str =
         p = f"{prefix}transformer.resblocks.{i}."
         y = layer_norm(t, P[p + "ln_1.weight"], P[p + "ln_1.bias"])
         t = t + mha(y, y, y, P[p + "attn.in_proj_weight"], P[p + "attn.in_proj_bias"],
-                    P[p + "attn.out_proj.weight"], P[p + "attn.out_proj.bias"], heads)
+                    P[p + "attn.out_proj.weight"], P[p + "attn.out_proj.bias"], heads, need_weights=False)
         y = layer_norm(t, P[p + "ln_2.weight"], P[p + "ln_2.bias"])
         y = F.linear(y, P[p + "mlp.c_fc.weight"], P[p + "mlp.c_fc.bias"])
         y = y * torch.sigmoid(1.702 * y)
@@ -290,11 +301,13 @@ def compute_iou(pred: np.ndarray, gt: np.ndarray, eps: float = 1e-7):
 def mask_nms(masks: np.ndarray, scores: np.ndarray, cats: np.ndarray, nms_type: str = "hard",
              nms_threshold: float = 0.3, sigma: float = 0.5, threshold: float = 0.001):
     """networks/zutis.py:211-299 greedy per-category mask NMS.  Returns list of (category_id, mask_index, score)
-    in the reference's emission order (categories in ascending id — set() iteration order of small ints —
-    then selection order).  Empty masks and category 0 dropped."""
+    in the reference's emission order: categories in the iteration order of `set(category_ids_per_image)` (:237-238, a set of
+    numpy int64 scalars: CPython's hash-slot order, ascending only while the ids are below the table size), then selection
+    order.  Empty masks and category 0 dropped."""
     assert nms_type in ("hard", "linear", "gaussian")
     out = []
-    for c in sorted(set(int(v) for v in cats)):
+    for c in set(np.asarray(cats, dtype=np.int64)):
+        c = int(c)
         if c == 0:
             continue
         idx = np.nonzero(cats == c)[0]

@@ -177,3 +177,22 @@ def test_c1_vitb32_224_batch4_vs_oracle(dev, precision, tol):
     assert np.abs(lo - lo_ref).max() < tol
     assert (lab == lab_ref).mean() > (0.9995 if precision == "exact" else 0.995)
     assert np.abs(out["mask_proposals"].cpu().numpy() - ref["mask_proposals"].numpy()).max() < (2e-4 if precision == "exact" else 1e-3)
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-6), ("fast", 1e-3)])
+@pytest.mark.parametrize("tag", ["small", "l14_336"])
+def test_encode_image_matches_reference_golden(dev, golden_dir, tag, precision, tol):
+    """E1 pin on the HIP path: ClipImageEncoder against the embeddings of the reference's own VisionTransformer submodules run
+    in the order of CLIP's original forward (tests/golden/encode_image.npz, oracle/gen_golden.py::gen_encode_image)."""
+    from zutis_amd import detgen
+    from zutis_amd.engine import ClipImageEncoder
+    g = np.load(f"{golden_dir}/encode_image.npz")
+    B, R, width, layers, patch, grid, embed = (int(v) for v in g[f"{tag}_shape"])
+    cfg = detgen.ZutisConfig(width=width, layers=layers, patch=patch, grid=grid, embed_dim=embed)
+    sd = {k.replace("encoder.", "visual."): torch.from_numpy(v).to(dev) for k, v in detgen.zutis_state_dict(cfg).items()
+          if k.startswith("encoder.")}
+    x = torch.from_numpy(detgen.images(B, R, R, seed=5)).to(dev)
+    got = ClipImageEncoder(sd, patch, precision=precision).encode_image(x).cpu().numpy()
+    err = np.abs(got - g[f"{tag}_embeddings"]).max()
+    print(f"encode_image {tag}[{precision}]: max err {err:.2e}")
+    assert err < tol, err

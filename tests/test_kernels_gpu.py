@@ -464,6 +464,10 @@ def test_device_mask_nms_matches_reference_control_flow(dev, nms_type):
     scores[:, 20] = 0.0009                                            # below the keep threshold once multiplied
     cats = rng.integers(0, 6, (B, Q)).astype(np.int64)                # class 0 = background: skipped
     cats[1] = 2                                                       # one image with a single crowded class
+    # COCO-range ids that wrap in CPython's 32-slot set table (33 -> slot 1, 40 -> slot 8): the reference iterates
+    # set(category_ids) (zutis.py:237-238), which is NOT ascending here — [40, 33, 2, 3] for {33, 2, 40, 3}
+    cats[2] = np.array([33, 2, 40, 3, 80, 65], np.int64)[rng.integers(0, 6, Q)]
+    assert [int(c) for c in set(cats[2])] != sorted(set(int(c) for c in cats[2]))
     eng_kept = ZutisEngine.instance_nms(None, torch.from_numpy(masks).to(dev), torch.from_numpy(scores).to(dev),
                                         torch.from_numpy(cats).to(dev), nms_type)
     ref = []

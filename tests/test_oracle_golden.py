@@ -220,3 +220,52 @@ def test_c3_oracle_matches_reference_at_native_resolution(golden_dir):
     assert np.abs(up[0][keep].reshape(keep.sum(), -1).sum(1) - g["480x640_all_area"]).max() <= 2
     sel = O.mask_nms(up[0], scores[0], cats[0], "hard")
     assert len(sel) == int(g["480x640_n"]) and [c for c, _, _ in sel] == list(g["480x640_cat"])
+
+
+def _e1_case(g, tag):
+    B, R, width, layers, patch, grid, embed = (int(v) for v in g[f"{tag}_shape"])
+    cfg = detgen.ZutisConfig(width=width, layers=layers, patch=patch, grid=grid, embed_dim=embed)
+    sd = {k: v for k, v in detgen.zutis_state_dict(cfg).items() if k.startswith("encoder.")}
+    return cfg, sd, torch.from_numpy(detgen.images(B, R, R, seed=5))
+
+
+@pytest.mark.parametrize("tag", ["small", "l14_336"])
+def test_oracle_encode_image_matches_reference(golden_dir, tag):
+    """E1 pin: O.clip_encode_image against embeddings produced by the reference's own VisionTransformer submodules run in the
+    order of CLIP's original forward (clip_arch.py:413-431) + the normalisation of utils/extract_image_embeddings.py:73
+    (oracle/gen_golden.py::gen_encode_image).  Second case: ViT-L/14@336 geometry (24x24 grid, D = 1024), 2 layers."""
+    g = np.load(f"{golden_dir}/encode_image.npz")
+    cfg, sd, x = _e1_case(g, tag)
+    with torch.no_grad():
+        e = O.clip_encode_image(O.to_torch_params(sd), x, cfg.patch).numpy()
+    ref = g[f"{tag}_embeddings"]
+    assert e.shape == ref.shape
+    assert np.abs(e - ref).max() < 5e-7, np.abs(e - ref).max()
+
+
+def test_oracle_nms_walks_categories_in_the_references_set_order():
+    """zutis.py:237-238 iterates set(category_ids_per_image): CPython's slot order for numpy int64 ids, not ascending once ids
+    wrap the table ({33, 2, 40, 3} -> 40, 33, 2, 3).  The oracle and the drop-in's host NMS must emit in that order."""
+    import os, sys
+    rng = np.random.default_rng(3)
+    Q, H, W = 24, 16, 16
+    masks = np.zeros((Q, H, W), bool)
+    for q in range(Q):
+        y0, x0 = rng.integers(0, H - 4), rng.integers(0, W - 4)
+        masks[q, y0:y0 + 4, x0:x0 + 4] = True
+    cats = np.array([33, 2, 40, 3], np.int64)[np.arange(Q) % 4]
+    scores = (rng.random(Q) * 0.9 + 0.05).astype(np.float32)
+    want = [int(c) for c in set(cats)]
+    assert want != sorted(want)
+    got = O.mask_nms(masks, scores, cats, "hard")
+    seen = []
+    for c, _, _ in got:
+        if c not in seen:
+            seen.append(c)
+    assert seen == want
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    from networks.zutis import ZUTIS
+    host = ZUTIS.non_maximum_suppression_indices(masks, scores, cats, "hard")
+    assert [(c, q) for c, q, _ in host] == [(c, q) for c, q, _ in got]

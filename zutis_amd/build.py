@@ -16,6 +16,9 @@ EXTRA_FLAGS = {"bilateral.hip": ["-ffp-contract=off"]}
 # the MFMA kernels live at the register budget of their occupancy: a spill is a 2-3x slowdown, so it is a build error
 NO_SCRATCH = {"gemm.hip", "gemm_x3.hip", "attention.hip"}
 MAX_SCRATCH = 0    # bytes per lane tolerated: the MFMA loops must not spill
+# waves per SIMD the design of a kernel relies on (mangled-name substring -> minimum), checked against the compiler's remarks
+MIN_OCCUPANCY = {"attn_f16_kernelILi64ELi4ELi1E": 3, "attn_f16_kernelILi64ELi4ELi0E": 3,
+                 "attn_f16_kernelILi96ELi4ELi1E": 2, "attn_f16_kernelILi96ELi4ELi0E": 2}
 SOURCES = ["capi.hip", "gemm.hip", "gemm_x3.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip", "text.hip", "plan.hip"]
 
 
@@ -74,6 +77,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
                       and int(ln.split("ScratchSize [bytes/lane]:")[1].split()[0]) > MAX_SCRATCH]
             if spills:
                 raise RuntimeError(f"{os.path.basename(src)}: a kernel spills to scratch (register budget exceeded): {spills[0].strip()}")
+            fn = None
+            for ln in err.splitlines():
+                if "Function Name:" in ln:
+                    fn = ln.split("Function Name:")[1].split()[0]
+                elif "Occupancy [waves/SIMD]:" in ln and fn:
+                    occ = int(ln.split("Occupancy [waves/SIMD]:")[1].split()[0])
+                    for key, need in MIN_OCCUPANCY.items():
+                        if key in fn and occ < need:
+                            raise RuntimeError(f"{os.path.basename(src)}: {fn} compiles to {occ} waves/SIMD, its design needs {need}")
         else:
             sys.stderr.write(err)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -38,7 +38,10 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 // S = Kh.Qh + Kl.Qh + Kh.Ql in fp32 — the softmax exponent sees fp32-class scores, which is where fp16 operand rounding is
 // amplified (|s| * 2^-11 absolute) — and the probabilities are split in registers, O += Vh.Ph + Vl.Ph + Vh.Pl, so short
 // key sets (decoder self-attention over 100 queries, small images) are not left with the 2^-11 rounding of single P / V
-// values.  One block per CU (the lo planes of K and V double the LDS tiles).
+// values.  32-key tiles (the lo planes of K and V double the LDS tiles and the three-product accumulators the registers):
+// three workgroups per CU at dh = 64, two at dh = 96.  The occupancy is checked at build time (build.py MIN_OCCUPANCY reads the
+// compiler's resource remarks): asking for 3 through __launch_bounds__ makes hipcc pick a 168-VGPR allocation WITH 16 bytes of
+// scratch, while the looser bound compiles to 165 VGPRs and none — so the bound stays loose and the build fails on a regression.
 #ifndef ZH_ATTN_ABL
 #define ZH_ATTN_ABL 0      // developer ablations (tools/attn_ablate.py): 1 no exp, 2 no P.V, 4 no K.Q^T, 8 no tile traffic and no
 #endif                     // barriers, 16 no barriers, 32 barriers only, 64 no LDS stores.  0 in the product build.

@@ -321,7 +321,8 @@ class ZUTIS(nn.Module):
         on boolean masks)."""
         assert nms_type in ["hard", "linear", "gaussian"]
         out = []
-        for c in sorted(set(int(v) for v in category_ids)):
+        for c in set(np.asarray(category_ids, dtype=np.int64)):     # the reference's own iteration order (zutis.py:237-238)
+            c = int(c)
             if c == 0:
                 continue
             cand = list(np.nonzero(category_ids == c)[0])

@@ -64,11 +64,16 @@ def resolve_precision(precision) -> frozenset:
     bad = sites - set(ALL_SITES)
     if bad:
         raise ZutisHipError(f"unknown precision sites {sorted(bad)} (known: {ALL_SITES})")
-    # a split-pair consumer needs the producer of its operand to write lo planes: close the set under those requirements
+    # a split-pair consumer needs the producer of its operand to write lo planes, and a buffer allocated as a pair must be
+    # filled as one: close the set under those requirements (each rule: consumer site => the x3 GEMM that produces its operand)
     if "attn" in sites:
-        sites.add("qkv")                      # Q / K lo planes come from the x3 QKV projection
+        sites.add("qkv")                      # Q / K / V lo planes come from the x3 QKV projection
+    if "proj" in sites:
+        sites.add("fc")                       # H16 (QuickGELU(c_fc)) is c_proj's operand: its lo plane comes from the x3 c_fc
     if sites & {"mask", "dec_kv"}:
         sites.add("ffn1")                     # their operand (ffn1's hidden layer, F2X) gets its lo plane from the x3 ffn1
+    if "dec" in sites and "dec_kv" in sites:
+        sites.add("ffn1")
     return frozenset(sites)
 
 
@@ -654,7 +659,18 @@ class ZutisEngine(_EngineBase):
         idx, sc, cat, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma,
                                          threshold)
         cnt_h, idx_h, sc_h, cat_h = cnt.cpu().numpy(), idx.cpu().numpy(), sc.cpu().numpy(), cat.cpu().numpy()
-        return [(b, int(cat_h[b, j]), int(idx_h[b, j]), float(sc_h[b, j])) for b in range(B) for j in range(int(cnt_h[b]))]
+        # The kernel walks the categories in ascending id; the reference walks `set(category_ids_per_image)` (zutis.py:237-238), i.e.
+        # CPython's iteration order of a set of numpy int64 scalars — ascending only while every id is below the hash table's
+        # size.  Re-create that very set on the host (Q ids per image) and order the per-category groups by it (stable: the
+        # selection order inside a category is the kernel's, which is the reference's).
+        all_cat = category_ids.cpu().numpy()
+        out = []
+        for b in range(B):
+            rank = {int(c): i for i, c in enumerate(set(all_cat[b]))}
+            rows = [(b, int(cat_h[b, j]), int(idx_h[b, j]), float(sc_h[b, j])) for j in range(int(cnt_h[b]))]
+            rows.sort(key=lambda r: rank[r[1]])
+            out += rows
+        return out
 
     def encode_masks(self, masks_u8: torch.Tensor, sel: np.ndarray, max_runs: int = 8192):
         """COCO RLE dicts, xyxy boxes and areas of the masks `sel` (flat indices into [n,H,W]) without moving the masks

@@ -155,6 +155,9 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
     """out = act(A @ W^T + bias + pos) + residual[m % res_rows].  A [M,K] f16, W [N,K] f16, out f32|f16 [M,N]; pos: see _pos().
     Act operands / outputs are read / written through their hi plane (plain fp16)."""
     L = _lib.load()
+    for t in (A, W):
+        if isinstance(t, Act) and t.out_scale != 1.0:   # a weight packed for the x3 mode is W * 2^s: its hi plane alone is not W
+            raise _lib.ZutisHipError("gemm: operand packed with out_scale != 1 (split_weight) reached the fp16-operand GEMM")
     A, W, out_ret = _hp(A)[0], _hp(W)[0], out
     if isinstance(out, Act):
         if out.plane:
