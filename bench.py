@@ -466,7 +466,13 @@ def main():
             lo = e.semantic_logits_lowres(out["patch_tokens"], text).cpu().numpy()
             lab = e.predict_semantic(out["patch_tokens"], text, (S, S)).cpu().numpy()
             hist = O.confusion_hist(lab_ref, lab, n)
-            return {"logit_max_abs_err": float(np.abs(lo - lo_ref).max()), "label_agreement": float((lab == lab_ref).mean()),
+            from oracle.parity import unexplained_label_mismatches
+            err = float(np.abs(lo - lo_ref).max())
+            n_mis, n_bad, worst = unexplained_label_mismatches(lab, lab_ref, lo_ref, err, (S, S))
+            return {"logit_max_abs_err": err, "label_agreement": float((lab == lab_ref).mean()),
+                    "label_mismatches": n_mis, "unexplained_label_mismatches": n_bad,
+                    "label_note": "a differing pixel is explained when the oracle's own full-resolution logits separate the two labels by "
+                                  "<= 2 x logit_max_abs_err (largest such margin: %.2e); the argmax kernel is bit-exact on equal logits" % worst,
                     "miou_vs_oracle_labels": float(O.scores_from_hist(hist)[0]["Mean IoU"]), "tolerance": 1e-3,
                     "against": "fp32 oracle (CPU restatement of the reference path) on the same %d images" % ns}
         parity = parity_of(eng)

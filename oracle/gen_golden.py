@@ -260,36 +260,52 @@ def gen_text():
 
 def gen_c3():
     """Config 3 at its own shape (coco20k_eval.py:241-268): ViT-B/16, batch 1, native-resolution COCO-like inputs, forward +
-    predict(mask_type="instance", size=image size, nms_type="hard").  Stores the per-prediction integers / scores / boxes,
-    the masks bit-packed, and sub-sampled forward tensors."""
+    predict(mask_type="instance", size=image size, nms_type="hard" | "linear" | None).  Stores the per-prediction integers /
+    scores / boxes, the masks bit-packed, and sub-sampled forward tensors.
+    Weights = detgen.c3_state_dict (queries that differ: at plain random init hard NMS leaves one survivor of one class),
+    threshold = detgen.C3_THRESHOLD, and text embeddings made orthogonal to the mean patch token of the first image (stored in
+    the fixture as an INPUT: with random text rows every region's average token picks the same class) -> ~9 categories and
+    12-17 hard-NMS survivors out of ~100 candidates per image, ids that wrap CPython's set table included."""
     cfg = detgen.VIT_B16
     net = build_reference_zutis(cfg, 81)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.c3_state_dict(cfg).items()}, strict=True)
+    thr = detgen.C3_THRESHOLD
     d = {}
     for (H, W) in ((480, 640), (427, 640)):
         tag = f"{H}x{W}"
         x = torch.from_numpy(detgen.images(1, H, W, seed=21))
         with torch.no_grad():
             out = net(x)
-            preds = net.predict(out, mask_type="instance", size=(H, W), image_ids=[7], nms_type="hard")
+            if "text" not in d:
+                t0 = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim))
+                mu = out["patch_tokens"].reshape(-1, cfg.embed_dim).mean(0)
+                mu = mu / mu.norm()
+                t = t0 - (t0 @ mu)[:, None] * mu[None]
+                d["text"] = (t / t.norm(dim=1, keepdim=True)).numpy()
+                net.text_embeddings = torch.from_numpy(d["text"])
             logits_lo = net.predict(out, mask_type="semantic", size=None, return_logits=True)
         d[f"{tag}_mask_proposals_last_sub"] = out["mask_proposals"].numpy()[:, -1, :, ::3, ::3]
         d[f"{tag}_patch_tokens_sub"] = out["patch_tokens"].numpy()[:, ::3, ::3, ::4]
         d[f"{tag}_logits_lo_sub"] = logits_lo.numpy()[:, :, ::2, ::2]
-        d[f"{tag}_n"] = len(preds)
-        if preds:
-            d[f"{tag}_masks"] = np.packbits(np.stack([p["segmentation"]["mask"] for p in preds]).astype(bool), axis=-1)
-            d[f"{tag}_score"] = np.array([p["score"] for p in preds], np.float64)
-            d[f"{tag}_cat"] = np.array([p["category_id"] for p in preds], np.int64)
-            d[f"{tag}_bbox"] = np.array([p["bbox"] for p in preds], np.float64)
-            d[f"{tag}_area"] = np.array([int(p["segmentation"]["mask"].sum()) for p in preds], np.int64)
+        for nms, key in (("hard", ""), ("linear", "linear_")):
+            with torch.no_grad():
+                preds = net.predict(out, mask_type="instance", threshold=thr, size=(H, W), image_ids=[7], nms_type=nms)
+            d[f"{tag}_{key}n"] = len(preds)
+            d[f"{tag}_{key}score"] = np.array([p["score"] for p in preds], np.float64)
+            d[f"{tag}_{key}cat"] = np.array([p["category_id"] for p in preds], np.int64)
+            d[f"{tag}_{key}area"] = np.array([int(p["segmentation"]["mask"].sum()) for p in preds], np.int64)
+            if nms == "hard":
+                d[f"{tag}_masks"] = np.packbits(np.stack([p["segmentation"]["mask"] for p in preds]).astype(bool), axis=-1)
+                d[f"{tag}_bbox"] = np.array([p["bbox"] for p in preds], np.float64)
+            print("c3", tag, nms, "preds", len(preds), "cats in emission order", [p["category_id"] for p in preds])
         with torch.no_grad():     # every candidate (no NMS): per-query class / score / area / box at the native resolution
-            allp = net.predict(out, mask_type="instance", size=(H, W), image_ids=[7], nms_type=None)
+            allp = net.predict(out, mask_type="instance", threshold=thr, size=(H, W), image_ids=[7], nms_type=None)
         d[f"{tag}_all_n"] = len(allp)
         d[f"{tag}_all_score"] = np.array([p["score"] for p in allp], np.float64)
         d[f"{tag}_all_cat"] = np.array([p["category_id"] for p in allp], np.int64)
         d[f"{tag}_all_bbox"] = np.array([p["bbox"] for p in allp], np.float64)
         d[f"{tag}_all_area"] = np.array([int(p["segmentation"]["mask"].sum()) for p in allp], np.int64)
-        print("c3", tag, "preds", len(preds), "cats", sorted(set(p["category_id"] for p in preds)), "no-NMS candidates", len(allp))
+        print("c3", tag, "no-NMS candidates", len(allp), "categories", sorted(set(int(c) for c in d[f"{tag}_all_cat"])))
     np.savez_compressed(os.path.join(GOLD, "c3_vitb16.npz"), **d)
 
 

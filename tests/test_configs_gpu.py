@@ -25,18 +25,21 @@ def _dropin():
         sys.path.insert(0, DROPIN)
 
 
-@pytest.mark.parametrize("precision,t_tok,t_mask,t_score,t_area", [("exact", 2e-5, 2e-4, 1e-4, 8), ("fast", 2.5e-4, 1e-3, 2e-3, 80)])
+@pytest.mark.parametrize("precision,t_tok,t_mask,t_score,t_area", [("exact", 2e-5, 2e-4, 1e-4, 8), ("fast", 2.5e-4, 1e-3, 2e-3, 160)])
 @pytest.mark.parametrize("H,W", [(480, 640), (427, 640)])
 def test_c3_native_resolution_instance_predict(dev, golden_dir, H, W, precision, t_tok, t_mask, t_score, t_area):
+    """Weights detgen.c3_state_dict + the fixture's text rows + threshold C3_THRESHOLD: 9 categories, 100 candidates, 17 / 12
+    hard-NMS survivors (57 / 46 linear) emitted in the reference's set() order.  exact: the prediction LISTS are identical
+    (count, categories, order).  fast (fp16 bodies, masks differ by tens of pixels): NMS decisions next to the IoU threshold
+    may legitimately flip, so the lists are compared as multisets of categories with a bounded difference."""
     from zutis_amd import detgen, rle
     _dropin()
     from networks.zutis import ZUTIS
     cfg = detgen.VIT_B16
     g = np.load(f"{golden_dir}/c3_vitb16.npz")
-    tag = f"{H}x{W}"
-    net = ZUTIS(categories=[f"c{i}" for i in range(81)], clip_arch="ViT-B/16", device=dev,
-                text_embeddings=torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim)))
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items()}, strict=True)
+    tag, thr = f"{H}x{W}", detgen.C3_THRESHOLD
+    net = ZUTIS(categories=[f"c{i}" for i in range(81)], clip_arch="ViT-B/16", device=dev, text_embeddings=torch.from_numpy(g["text"]))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.c3_state_dict(cfg).items()}, strict=True)
     net = net.to(dev).eval().requires_grad_(False)
     net.precision = precision
     x = torch.from_numpy(detgen.images(1, H, W, seed=21)).to(dev)
@@ -46,23 +49,40 @@ def test_c3_native_resolution_instance_predict(dev, golden_dir, H, W, precision,
     assert np.abs(pt[:, ::3, ::3, ::4] - g[f"{tag}_patch_tokens_sub"]).max() < t_tok
     lo = net.predict(out, mask_type="semantic", size=None, return_logits=True).cpu().numpy()
     assert np.abs(lo[:, :, ::2, ::2] - g[f"{tag}_logits_lo_sub"]).max() < t_tok
-    # every candidate, no NMS: class ids identical, scores / areas / boxes within what one threshold-crossing pixel can move
-    allp = net.predict(out, mask_type="instance", size=(H, W), image_ids=[7], nms_type=None)
+    # every candidate, no NMS: class ids identical, scores / areas / boxes within what threshold-crossing pixels can move
+    allp = net.predict(out, mask_type="instance", threshold=thr, size=(H, W), image_ids=[7], nms_type=None)
     assert len(allp) == int(g[f"{tag}_all_n"])
-    assert [p["category_id"] for p in allp] == list(g[f"{tag}_all_cat"])
+    same_cat = np.array([p["category_id"] for p in allp]) == g[f"{tag}_all_cat"]
+    assert same_cat.all() if precision == "exact" else same_cat.mean() >= 0.97
     assert np.abs(np.array([p["score"] for p in allp]) - g[f"{tag}_all_score"]).max() < t_score
     areas = np.array([int(rle.decode(p["segmentation"]).sum()) for p in allp])
     assert np.abs(areas - g[f"{tag}_all_area"]).max() <= t_area
-    assert np.abs(np.array([p["bbox"] for p in allp]) - g[f"{tag}_all_bbox"]).max() <= 2.0
-    # hard NMS, the evaluation's setting
-    preds = net.predict(out, mask_type="instance", size=(H, W), image_ids=[7], nms_type="hard")
-    assert len(preds) == int(g[f"{tag}_n"])
+    if precision == "exact":
+        assert np.abs(np.array([p["bbox"] for p in allp]) - g[f"{tag}_all_bbox"]).max() <= 2.0
+    # greedy NMS at the evaluation's setting (hard) and with the linear re-scoring
     ref_masks = np.unpackbits(g[f"{tag}_masks"], axis=-1)[..., :W].astype(bool)
-    for j, p in enumerate(preds):
-        assert p["category_id"] == g[f"{tag}_cat"][j] and p["image_id"] == 7 and tuple(p["image_size"]) == (H, W)
-        assert abs(p["score"] - g[f"{tag}_score"][j]) < t_score
-        m = rle.decode(p["segmentation"]).astype(bool)
-        assert (m != ref_masks[j]).sum() <= t_area
+    for nms, key in (("hard", ""), ("linear", "linear_")):
+        preds = net.predict(out, mask_type="instance", threshold=thr, size=(H, W), image_ids=[7], nms_type=nms)
+        ref_cat, ref_score = g[f"{tag}_{key}cat"], g[f"{tag}_{key}score"]
+        assert len(ref_cat) >= 5 and len(set(ref_cat.tolist())) >= 3          # the fixture exercises NMS (17 / 12 of 100 survive)
+        print(f"c3 {tag}[{precision}] {nms}: {len(preds)} predictions (reference {len(ref_cat)})")
+        if precision == "exact":
+            assert [p["category_id"] for p in preds] == list(ref_cat)         # same survivors, same emission order
+            assert np.abs(np.array([p["score"] for p in preds]) - ref_score).max() < t_score
+            for j, p in enumerate(preds):
+                assert p["image_id"] == 7 and tuple(p["image_size"]) == (H, W)
+                assert abs(int(rle.decode(p["segmentation"]).sum()) - int(g[f"{tag}_{key}area"][j])) <= t_area
+                if nms == "hard":
+                    assert (rle.decode(p["segmentation"]).astype(bool) != ref_masks[j]).sum() <= t_area
+        else:
+            from collections import Counter
+            diff = Counter(p["category_id"] for p in preds)
+            diff.subtract(Counter(ref_cat.tolist()))
+            assert sum(abs(v) for v in diff.values()) <= max(2, len(ref_cat) // 8), diff   # a few knife-edge IoU decisions at most
+            # categories come out in the reference's set() order whatever the counts
+            order = list(dict.fromkeys(p["category_id"] for p in preds))
+            ref_order = [c for c in dict.fromkeys(ref_cat.tolist()) if c in order]
+            assert [c for c in order if c in ref_order] == ref_order
 
 
 def test_a4_build_model_through_constructor(dev, golden_dir):

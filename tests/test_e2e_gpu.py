@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 # contraction in the reference-equivalent x3 mode) to fp32-reordering-class errors.
 LOGIT_TOL = 2.5e-4
 MASK_TOL = 1e-3
-TOLS = {"fast": (LOGIT_TOL, MASK_TOL, 0.995), "exact": (2e-5, 2e-4, 0.9995)}
+TOLS = {"fast": (LOGIT_TOL, MASK_TOL), "exact": (2e-5, 2e-4)}
+# Labels: no agreement threshold.  Every pixel whose label differs from the reference's must be EXPLAINED by the logit error
+# (oracle/parity.py: the reference's own top-1 / chosen-label margin at that pixel is <= 2 x the measured logit error).
 
 
 def _engine(cfg, dev, precision="fast"):
@@ -29,7 +31,7 @@ def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname, precision):
     g = np.load(f"{golden_dir}/e2e_{tag}.npz")
     b, H, W, n = int(g["b"]), int(g["H"]), int(g["W"]), int(g["n_cat"])
     eng = _engine(cfg, dev, precision)
-    LOGIT_TOL, MASK_TOL, MIN_AGREE = TOLS[precision]
+    LOGIT_TOL, MASK_TOL = TOLS[precision]
     x = torch.from_numpy(detgen.images(b, H, W)).to(dev)
     text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
     out = eng.forward(x)
@@ -38,7 +40,9 @@ def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname, precision):
     assert err < LOGIT_TOL, err
     labels = eng.predict_semantic(out["patch_tokens"], text, tuple(g["size"])).cpu().numpy()
     agree = (labels == g["labels"]).mean()
-    assert agree > MIN_AGREE, agree
+    from oracle.parity import unexplained_label_mismatches
+    n_mis, n_bad, worst = unexplained_label_mismatches(labels, g["labels"], g["logits_lo"], err, tuple(g["size"]))
+    assert n_bad == 0, (n_mis, n_bad, worst, err)
     mp, pt = out["mask_proposals"].cpu().numpy(), out["patch_tokens"].cpu().numpy()
     assert mp.min() >= 0 and mp.max() <= 1
     if "mask_proposals" in g:
@@ -49,7 +53,8 @@ def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname, precision):
     else:
         assert np.abs(mp[:, :, ::9, ::3, ::3] - g["mask_proposals_sub"]).max() < MASK_TOL
         assert np.abs(pt[:, ::3, ::3, ::4] - g["patch_tokens_sub"]).max() < LOGIT_TOL
-    print(f"{tag}[{precision}]: logits maxerr {err:.2e}, label agreement {agree:.5f}")
+    print(f"{tag}[{precision}]: logits maxerr {err:.2e}, label agreement {agree:.6f} ({n_mis} pixels differ, all with a reference "
+          f"top-2 margin <= 2 err; largest {worst:.2e})")
 
 
 def test_engine_vs_oracle_ragged_batch(dev):
@@ -124,9 +129,11 @@ def test_dropin_module_matches_reference_golden(dev, golden_dir, precision, t_sc
         out = net(x)
     labels = net.predict(out, mask_type="semantic", size=(H, W))
     assert labels.dtype == np.int64 and labels.shape == (b, H, W)
-    assert (labels == g["labels"]).mean() > 0.995
     logits = net.predict(out, mask_type="semantic", size=(H, W), return_logits=True)
-    assert np.abs(logits.cpu().numpy() - g["logits_full"]).max() < LOGIT_TOL
+    e_full = float(np.abs(logits.cpu().numpy() - g["logits_full"]).max())
+    assert e_full < LOGIT_TOL
+    from oracle.parity import unexplained_label_mismatches
+    assert unexplained_label_mismatches(labels, g["labels"], g["logits_lo"], e_full, (H, W))[1] == 0
     for nms in ("hard", "linear", "gaussian", None):
         key = str(nms).lower()
         preds = net.predict(out, mask_type="instance", size=(H, W), image_ids=list(range(b)), nms_type=nms)
@@ -192,6 +199,40 @@ def test_selfmask_engine_vs_reference_golden(dev, golden_dir, precision, t_obj, 
         got = inf["dts"].cpu().numpy().astype(bool)
         assert got.shape == (b, H, W)
         assert (got != ref).mean() <= t_dts, (got != ref).mean()
+
+
+@pytest.mark.parametrize("precision,t_obj,t_mask", [("exact", 2e-5, 4e-4), ("fast", 2e-3, 2e-2)])
+def test_selfmask_at_its_working_shape_512x683(dev, precision, t_obj, t_mask):
+    """SelfMask at the shape the pseudo-label pipeline runs it (datasets/index_dataset.py:189-204 resizes to 512 on the short
+    side: 512x683 -> 64x86 tokens padded to T = 5505 + cls, the flash-attention regime) against the CPU oracle, batch 1
+    (selfmask.py:204-237).  Mask pixels may differ from the oracle's only where the oracle's own upsampled probability is
+    within the measured mask error of the 0.5 threshold."""
+    from zutis_amd import detgen
+    from zutis_amd.engine import SelfMaskEngine
+    from oracle import selfmask_ref as S, zutis_ref as O
+    H, W = 512, 683
+    sd = detgen.selfmask_state_dict()
+    x = torch.from_numpy(detgen.images(1, H, W, seed=11))
+    with torch.no_grad():
+        ref = S.selfmask_forward(O.to_torch_params(sd), x)
+        dts_ref, idx_ref, up_ref = S.selfmask_inference(O.to_torch_params(sd), x)
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, precision=precision)
+    out = eng.forward(x.to(dev))
+    e_obj = float((out["objectness"].cpu() - ref["objectness"]).abs().max())
+    e_mask = float((out["mask_pred"].cpu() - ref["mask_pred"]).abs().max())
+    assert out["mask_pred"].shape == ref["mask_pred"].shape
+    assert e_obj < t_obj and e_mask < t_mask, (e_obj, e_mask)
+    inf = eng.forward(x.to(dev), inference=True)
+    got = inf["dts"].cpu().numpy().astype(bool)
+    assert got.shape == (1, H, W)
+    ol = ref["objectness_logits"][0].numpy()
+    srt = np.sort(ol)
+    if srt[-1] - srt[-2] > 4 * t_obj * 4:           # the winning query is unambiguous (sigmoid' <= 1/4): it must be the same one
+        diff = got[0] != dts_ref[0].astype(bool)
+        unexplained = int((diff & (np.abs(up_ref[0, idx_ref[0]] - 0.5) > e_mask + 2e-6)).sum())
+        print(f"selfmask 512x683[{precision}]: objectness {e_obj:.2e} mask_pred {e_mask:.2e}, {int(diff.sum())} of {H * W} mask pixels "
+              f"differ, unexplained {unexplained}")
+        assert unexplained == 0
 
 
 def test_selfmask_dropin_module(dev, golden_dir):
@@ -262,13 +303,15 @@ def test_running_score_dropin(dev, golden_dir):
     assert np.array_equal(rs.confusion_matrix, g["rs_hist"])
 
 
-def test_c4_geometry_518px_920_classes(dev):
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_c4_geometry_518px_920_classes(dev, precision):
     """BASELINE config 4 geometry: ViT-B/16 @518 px (conv floor => 32x32 grid, T=1025, M=4096), 920 classes, b=1,
-    against the CPU oracle; plus size-independent properties (unit-norm tokens, sigmoid range, argmax idempotence)."""
+    against the CPU oracle — logits AND the 920-class label map; plus size-independent properties (unit-norm tokens, sigmoid
+    range, argmax idempotence)."""
     from zutis_amd import detgen
     from oracle import zutis_ref as O
     cfg = detgen.VIT_B16
-    eng = _engine(cfg, dev)
+    eng = _engine(cfg, dev, precision)
     x = torch.from_numpy(detgen.images(1, 518, 518, seed=2))
     text = torch.from_numpy(detgen.text_embeddings(920, cfg.embed_dim))
     out = eng.forward(x.to(dev))
@@ -284,7 +327,20 @@ def test_c4_geometry_518px_920_classes(dev):
     with torch.no_grad():
         ref = O.zutis_forward(O.to_torch_params(detgen.zutis_state_dict(cfg)), x, cfg.patch, cfg.dec_heads)
         ref_lo = O.semantic_logits_lowres(ref["patch_tokens"], text).numpy()
-    assert np.abs(lo.cpu().numpy() - ref_lo).max() < LOGIT_TOL
+    err = float(np.abs(lo.cpu().numpy() - ref_lo).max())
+    assert err < TOLS[precision][0]
+    # the 920-class labels against the ORACLE's (zutis.py:366-372: F.interpolate(bilinear) -> argmax over 920 classes at 518x518)
+    from oracle import resample as R
+    from oracle.parity import unexplained_label_mismatches
+    lab_ref = R.bilinear_argmax_nchw(ref_lo, 518, 518)
+    n_mis, n_bad, worst = unexplained_label_mismatches(labels.cpu().numpy(), lab_ref, ref_lo, err, (518, 518))
+    print(f"c4[{precision}]: logits {err:.2e}; {n_mis} of {518 * 518} labels differ from the oracle's, unexplained {n_bad} (margin <= {worst:.2e})")
+    assert n_bad == 0, (n_mis, n_bad, worst, err)
+    # and bit-exact given the oracle's own low-res logits
+    lab2 = torch.empty((1, 518, 518), dtype=torch.int64, device=dev)
+    from zutis_amd import ops
+    ops.upsample_argmax(torch.from_numpy(ref_lo).to(dev), lab2, 1, 920, 64, 64, 518, 518)
+    assert np.array_equal(lab2.cpu().numpy(), lab_ref)
 
 
 def test_forward_graphed_matches_eager(dev):

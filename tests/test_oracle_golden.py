@@ -200,26 +200,34 @@ def test_a4_build_model_convert_weights_vs_reference(golden_dir):
 
 
 def test_c3_oracle_matches_reference_at_native_resolution(golden_dir):
-    """Config 3's shape (ViT-B/16, 480x640, batch 1): oracle forward + instance scoring vs the reference's outputs."""
+    """Config 3's shape (ViT-B/16, 480x640, batch 1; weights detgen.c3_state_dict, threshold C3_THRESHOLD, the fixture's text
+    rows): oracle forward + instance scoring + greedy NMS vs the reference's outputs — 9 categories, 100 candidates, 17 hard /
+    57 linear survivors, emitted in the reference's set() order (33, 2, 67, 73, 80, 50, 20, 54, 31: not ascending)."""
     cfg = detgen.VIT_B16
     g = np.load(f"{golden_dir}/c3_vitb16.npz")
-    H, W = 480, 640
-    P = O.to_torch_params(detgen.zutis_state_dict(cfg))
+    H, W, thr = 480, 640, detgen.C3_THRESHOLD
+    assert int(g["480x640_n"]) >= 5 and len(set(g["480x640_cat"].tolist())) >= 3
+    assert list(dict.fromkeys(g["480x640_cat"].tolist())) != sorted(set(g["480x640_cat"].tolist()))
+    P = O.to_torch_params(detgen.c3_state_dict(cfg))
     x = torch.from_numpy(detgen.images(1, H, W, seed=21))
-    text = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim))
+    text = torch.from_numpy(g["text"])
     with torch.no_grad():
         out = O.zutis_forward(P, x, cfg.patch, cfg.dec_heads)
     mp, pt = out["mask_proposals"].numpy(), out["patch_tokens"].numpy()
-    assert np.abs(mp[:, -1, :, ::3, ::3] - g["480x640_mask_proposals_last_sub"]).max() < 5e-6
+    assert np.abs(mp[:, -1, :, ::3, ::3] - g["480x640_mask_proposals_last_sub"]).max() < 2e-5   # sharpened decoder attention (c3_state_dict): fp32 reordering noise x4
     assert np.abs(pt[:, ::3, ::3, ::4] - g["480x640_patch_tokens_sub"]).max() < 2e-6
-    binary, cats, scores = O.instance_scores(out["mask_proposals"], out["patch_tokens"], text)
+    binary, cats, scores = O.instance_scores(out["mask_proposals"], out["patch_tokens"], text, threshold=thr)
     keep = cats[0] != 0
     assert list(cats[0][keep]) == list(g["480x640_all_cat"])
     assert np.abs(scores[0][keep] - g["480x640_all_score"]).max() < 1e-5
-    up = R.bilinear_nchw(mp[:, -1], H, W) > 0.5
-    assert np.abs(up[0][keep].reshape(keep.sum(), -1).sum(1) - g["480x640_all_area"]).max() <= 2
-    sel = O.mask_nms(up[0], scores[0], cats[0], "hard")
-    assert len(sel) == int(g["480x640_n"]) and [c for c, _, _ in sel] == list(g["480x640_cat"])
+    up = R.bilinear_nchw(mp[:, -1], H, W) > thr
+    assert np.abs(up[0][keep].reshape(keep.sum(), -1).sum(1) - g["480x640_all_area"]).max() <= 4
+    for nms, key in (("hard", ""), ("linear", "linear_")):
+        sel = O.mask_nms(up[0], scores[0], cats[0], nms)
+        assert len(sel) == int(g[f"480x640_{key}n"]) and [c for c, _, _ in sel] == list(g[f"480x640_{key}cat"])
+        # linear: every survivor's score carries products of (1 - IoU) of full-resolution masks that differ by a pixel or two
+        assert np.abs(np.array([s for _, _, s in sel]) - g[f"480x640_{key}score"]).max() < (1e-5 if nms == "hard" else 2e-4)
+        assert np.abs(np.array([up[0][q].sum() for _, q, _ in sel]) - g[f"480x640_{key}area"]).max() <= 4
 
 
 def _e1_case(g, tag):

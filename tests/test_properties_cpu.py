@@ -100,3 +100,25 @@ def test_confusion_hist_is_additive_and_scores_are_bounded(n, a, b, seed):
     if h.sum() > 0:
         sc, _ = ref.scores_from_hist(h)
         assert all(0.0 <= v <= 1.0 + 1e-12 for v in sc.values() if not np.isnan(v))
+
+
+def test_label_mismatch_explanation_helper():
+    """oracle/parity.py: labels computed from logits perturbed by <= err differ from the reference's only where the reference's
+    top-2 margin is <= 2 err (zero unexplained); a label flipped on a confident pixel is flagged."""
+    import numpy as np
+    from oracle import resample as R
+    from oracle.parity import unexplained_label_mismatches
+    rng = np.random.default_rng(0)
+    lo = (rng.standard_normal((2, 9, 10, 14)) * 0.05).astype(np.float32)     # near-ties everywhere: many flips
+    err = 0.02
+    lo2 = (lo + rng.uniform(-err, err, lo.shape)).astype(np.float32)
+    ref, got = R.bilinear_argmax_nchw(lo, 80, 112), R.bilinear_argmax_nchw(lo2, 80, 112)
+    e = float(np.abs(lo2 - lo).max())
+    n_mis, n_bad, worst = unexplained_label_mismatches(got, ref, lo, e, (80, 112))
+    assert n_mis > 100 and n_bad == 0 and worst <= 2 * e + 2e-6
+    full = R.bilinear_nchw(lo[:1], 80, 112)[0]
+    srt = np.sort(full, axis=0)
+    y, x = np.unravel_index(np.argmax(srt[-1] - srt[0]), srt[-1].shape)      # the pixel with the widest spread: flip it to its worst class
+    bad = ref.copy()
+    bad[0, y, x] = int(np.argmin(full[:, y, x]))
+    assert unexplained_label_mismatches(bad, ref, lo, 1e-4, (80, 112))[1] == 1

@@ -143,6 +143,27 @@ def zutis_state_dict(cfg: ZutisConfig, seed: int = 1234) -> "OrderedDict[str, np
                        for k, (shp, std, mean) in zutis_param_shapes(cfg).items())
 
 
+C3_THRESHOLD = 0.7      # mask threshold of the config-3 fixture (predict's `threshold` argument, zutis.py:345)
+
+
+def c3_state_dict(cfg: ZutisConfig, seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+    """zutis_state_dict() with a decoder that tells its queries apart, for the config-3 (instance + NMS) fixture: at random init
+    every query produces the same all-foreground mask of the same class (IoU 0.999 between any two: hard NMS leaves ONE
+    survivor).  Larger query embeddings, sharper decoder attention (q / k rows x8) and a wider ffn2 give masks with a mean
+    pairwise IoU of ~0.45 at threshold C3_THRESHOLD: ~9 categories, ~100 candidates -> 12-17 hard-NMS survivors per image."""
+    sd = zutis_state_dict(cfg, seed)
+    D = cfg.width
+    sd["query_embed"] = sd["query_embed"] * np.float32(20.0)
+    for i in range(cfg.dec_layers):
+        for att in ("multihead_attn", "self_attn"):
+            w = sd[f"decoder.layers.{i}.{att}.in_proj_weight"].copy()
+            w[:2 * D] *= np.float32(8.0)
+            sd[f"decoder.layers.{i}.{att}.in_proj_weight"] = w
+    for j in range(3):
+        sd[f"ffn2.layers.{j}.weight"] = sd[f"ffn2.layers.{j}.weight"] * np.float32(3.0)
+    return sd
+
+
 STRESS_FIXED_CHANNELS = (7, 300, 611)     # same large value at every token ("outlier feature dimensions")
 STRESS_TOKEN_CHANNEL = 123                # large, token-dependent value ("massive activations")
 

@@ -22,7 +22,7 @@ from zutis_amd.engine import ClipTextEncoder
 class HipClipText:
     """Duck-types the text half of `clip.model.CLIP` (clip_arch.py:534-547): `.encode_text(tokens) -> [n, embed]`."""
 
-    def __init__(self, state_dict: dict, device: torch.device = torch.device("cuda:0"), prefix: str = "", precision: str = "fast"):
+    def __init__(self, state_dict: dict, device: torch.device = torch.device("cuda:0"), prefix: str = "", precision: str = "exact"):
         keys = ("token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias", "text_projection")
         text = {k: v.detach().float().to(device) for k, v in state_dict.items()
                 if k.startswith(prefix + "transformer.resblocks.") or k in tuple(prefix + s for s in keys)}

@@ -95,7 +95,7 @@ class SelfMask(nn.Module):
         self.use_binary_classifier = use_binary_classifier
         self.scale_factor = scale_factor
         self._engine = None
-        self.precision: str = "fast"             # "fast" | "exact" | "f16" (zutis_amd.engine)
+        self.precision: str = "exact"             # "fast" | "exact" | "f16" (zutis_amd.engine)
 
     def _get_engine(self) -> SelfMaskEngine:
         if self._engine is not None and self._engine.precision != self.precision:

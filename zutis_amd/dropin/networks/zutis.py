@@ -203,7 +203,7 @@ class ZUTIS(nn.Module):
         self.encoder_type: str = encoder_type
         self._engine: Optional[ZutisEngine] = None
         # "fast" | "exact" | "f16" (zutis_amd.engine): exact = every contraction in the reference-equivalent f16x3 mode
-        self.precision: str = "fast"
+        self.precision: str = "exact"
         self.use_hip_graph: bool = False       # opt-in: forward() of batches <= 4 replays a hipGraph captured per input shape
 
     # ------------------------------------------------------------------ plumbing

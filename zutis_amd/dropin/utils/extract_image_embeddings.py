@@ -51,7 +51,7 @@ def extract_image_embeddings(
         n_workers: int = 16,
         *,
         state_dict: Optional[dict] = None,
-        precision: str = "fast",
+        precision: str = "exact",
 ) -> Dict[str, torch.Tensor]:
     if "ViT" not in model_name:
         raise NotImplementedError(f"{model_name}: only the CLIP-ViT towers are on the MI355X hot path")

@@ -87,7 +87,7 @@ class _EngineBase:
 
     params: Dict[str, torch.Tensor]
 
-    def _init_base(self, precision="fast"):
+    def _init_base(self, precision="exact"):
         self.x3_sites = resolve_precision(precision)
         self.precision = precision if isinstance(precision, str) else "custom"
         self._packed_key = None
@@ -355,7 +355,7 @@ class ZutisEngine(_EngineBase):
     """Inference engine for one ZUTIS network.  `params` maps reference state_dict keys to fp32 CUDA tensors
     (typically the nn.Parameters of the drop-in module, so load_state_dict() is picked up via version counters)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], patch: int, dec_heads: int = 8, precision="fast"):
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int, dec_heads: int = 8, precision="exact"):
         self.params = params
         self.patch = patch
         self.D = params["encoder.class_embedding"].shape[0]
@@ -703,7 +703,7 @@ class ClipImageEncoder(_EngineBase):
 
     _proj_site = "embed"
 
-    def __init__(self, params: Dict[str, torch.Tensor], patch: int, prefix: str = "visual.", precision="fast"):
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int, prefix: str = "visual.", precision="exact"):
         self.params, self.patch, self.prefix = params, patch, prefix
         self.D = params[prefix + "class_embedding"].shape[0]
         self.heads = self.D // 64
@@ -748,7 +748,7 @@ class ClipTextEncoder(_EngineBase):
     (token_embedding.weight, positional_embedding, transformer.resblocks.*, ln_final.*, text_projection);
     heads = width // 64 (clip_arch.py:606)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], prefix: str = "", chunk: int = 4096, precision="fast"):
+    def __init__(self, params: Dict[str, torch.Tensor], prefix: str = "", chunk: int = 4096, precision="exact"):
         self.params, self.prefix, self.chunk = params, prefix, chunk
         self.ctx, self.D = params[prefix + "positional_embedding"].shape
         self.vocab = params[prefix + "token_embedding.weight"].shape[0]
@@ -819,7 +819,7 @@ class SelfMaskEngine(_EngineBase):
 
     _dec_out_sites = ("mask", "ffn2")
 
-    def __init__(self, params: Dict[str, torch.Tensor], patch: int = 8, heads: int = 6, precision="fast"):
+    def __init__(self, params: Dict[str, torch.Tensor], patch: int = 8, heads: int = 6, precision="exact"):
         self.params = params
         self.patch, self.heads = patch, heads
         self.D = params["encoder.cls_token"].shape[-1]
