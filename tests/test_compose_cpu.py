@@ -80,3 +80,20 @@ def test_first_linear_commutes_with_the_x2_bilinear_upsample():
     a = F.linear(up(tok), W, b)
     c = up(F.linear(tok, W, b))
     assert float((a - c).abs().max()) < 1e-12
+
+
+def test_query_pos_row_tables():
+    """transformer.py:272-275,281-282: q = k = (tgt + query_pos) W^T + b, v = tgt Wv^T + bv and the cross-attention query
+    (tgt + query_pos) Wq^T + bq, for B images of Q queries, == projections of tgt alone + the row tables at row m % Q."""
+    B, Q, D = 3, 5, 16
+    tgt, qp = _rand((B * Q, D), 41).to(f64), _rand((Q, D), 42)
+    in_w, in_b = _rand((3 * D, D), 43, 0.3), _rand((3 * D,), 44, 0.2)
+    cw, cb = _rand((D, D), 45, 0.3), _rand((D,), 46, 0.2)
+    qin = tgt + qp.to(f64).repeat(B, 1)
+    ref_self = torch.cat([F.linear(qin, in_w[:2 * D].to(f64), in_b[:2 * D].to(f64)), F.linear(tgt, in_w[2 * D:].to(f64), in_b[2 * D:].to(f64))], 1)
+    ref_cross = F.linear(qin, cw.to(f64), cb.to(f64))
+    t_self, t_cross = compose.query_pos_tables(qp, in_w, in_b, cw, cb)
+    assert t_self.shape == (Q, 3 * D) and t_cross.shape == (Q, D) and t_self.dtype == torch.float32
+    m = torch.arange(B * Q) % Q
+    assert float((tgt @ in_w.to(f64).t() + t_self.to(f64)[m] - ref_self).abs().max()) < 1e-6
+    assert float((tgt @ cw.to(f64).t() + t_cross.to(f64)[m] - ref_cross).abs().max()) < 1e-6

@@ -8,6 +8,8 @@ Reference expressions:
   V_l =  decoder_input        @ Wv_l^T + bv_l                                                  (networks/transformer.py:284)
   masks = sigmoid(q . decoder_input[m])             mask proposals                             (networks/zutis.py:196-198,209)
   pos[y, x] = [py(y) | px(x)]                       sine positional embedding                  (networks/positional_embedding.py:47-52)
+  q = k = tgt + query_pos ; v = tgt                 decoder self-attention inputs              (networks/transformer.py:272-275)
+  q_cross = tgt + query_pos                         decoder cross-attention query input        (networks/transformer.py:281-282)
 """
 from __future__ import annotations
 
@@ -45,3 +47,17 @@ def mask_query_weight(W2: torch.Tensor, b2: torch.Tensor, FX: int) -> torch.Tens
     wq[:F] = W2.detach().t()
     wq[F] = b2.detach()
     return wq
+
+
+def query_pos_tables(query_pos: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor, cross_w: torch.Tensor,
+                     cross_b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Linear layers see `tgt + query_pos` (a parameter, the same Q rows for every image), so
+        (tgt + query_pos) @ W^T + b = tgt @ W^T + (query_pos @ W^T + b):
+    the projections run on tgt alone and start from a per-query row table.  query_pos [Q, D]; in_w [3D, D], in_b [3D] = the
+    packed self-attention in_proj (q | k | v rows; v sees tgt WITHOUT query_pos); cross_w [D, D], cross_b [D] = the q rows of
+    the cross-attention in_proj.  Returns (T_self [Q, 3D] = [qp Wq^T + bq | qp Wk^T + bk | bv], T_cross [Q, D]) in fp32."""
+    qp, in_w, in_b, cross_w, cross_b = (t.detach().to(f64) for t in (query_pos, in_w, in_b, cross_w, cross_b))
+    Q, D = qp.shape
+    t_self = torch.cat([qp @ in_w[:2 * D].t() + in_b[:2 * D], in_b[2 * D:].expand(Q, D)], dim=1)
+    t_cross = qp @ cross_w.t() + cross_b
+    return t_self.to(f32).contiguous(), t_cross.to(f32).contiguous()

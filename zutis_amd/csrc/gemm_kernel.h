@@ -334,11 +334,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       wslot = wslot + 1 == STAGES ? 0 : wslot + 1;
     };
     int kt = 0;
+#ifdef ZH_X3_NOFRAG                      // developer ablations (tools/gemm_x3_probe.sh): timing only, results are garbage
+    read_frags();
+#endif
     for (; kt + DISTX < nk; ++kt) {      // steady: branch-free body so the reads / DMA issues interleave with the MFMAs
+#ifndef ZH_X3_NOBAR
       wait_vmcnt_barrier<AHEADX * NP>();
+#endif
+#ifndef ZH_X3_NOFRAG
       read_frags();
+#endif
+#ifndef ZH_X3_NODMA
       issue_stage(wslot);
+#endif
+#ifndef ZH_X3_NOMFMA
       sweeps();
+#else
+      acc[0][0] += (f32x4){(float)fa[0][0], (float)fw[0][1], (float)fa[TM][2], (float)fw[TN][3]};
+#endif
       // hi fragments first, then 2 MFMAs per lo-fragment read / DMA issue
       __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll

@@ -175,20 +175,27 @@ class _EngineBase:
         c32 = self._c32
         h = lambda t: self._hw(t, "dec")
         kw, kb, vw, vb = [], [], [], []
+        qpos = P["query_embed"].detach()
         for i in range(n_layers):
             p, q = f"decoder.layers.{i}.", f"dec.{i}."
             sw, sb = P[p + "self_attn.in_proj_weight"].detach(), P[p + "self_attn.in_proj_bias"].detach()
-            w[q + "sa_qk_w"], w[q + "sa_qk_b"] = h(sw[:2 * D]), c32(sb[:2 * D])
-            w[q + "sa_v_w"], w[q + "sa_v_b"] = h(sw[2 * D:]), c32(sb[2 * D:])
-            w[q + "sa_o_w"], w[q + "sa_o_b"] = h(P[p + "self_attn.out_proj.weight"]), c32(P[p + "self_attn.out_proj.bias"])
             cw, cb = P[p + "multihead_attn.in_proj_weight"].detach(), P[p + "multihead_attn.in_proj_bias"].detach()
-            w[q + "ca_q_w"], w[q + "ca_q_b"] = h(cw[:D]), c32(cb[:D])
+            # q = k = tgt + query_pos, v = tgt (transformer.py:272-275) and the cross-attention query tgt + query_pos (:281-282):
+            # every projection runs on tgt alone — ONE N = 3D GEMM for the self-attention's q | k | v — and starts from a
+            # per-query row table that carries query_pos @ W^T + b (compose.query_pos_tables; fp64 products, stored fp32)
+            w[q + "sa_qkv_w"] = h(sw)
+            w[q + "sa_tab"], w[q + "ca_q_tab"] = compose.query_pos_tables(qpos, sw, sb, cw[:D], cb[:D])
+            w[q + "sa_o_w"], w[q + "sa_o_b"] = h(P[p + "self_attn.out_proj.weight"]), c32(P[p + "self_attn.out_proj.bias"])
+            w[q + "ca_q_w"] = h(cw[:D])
             kw.append(cw[D:2 * D]); kb.append(cb[D:2 * D]); vw.append(cw[2 * D:]); vb.append(cb[2 * D:])
             w[q + "ca_o_w"], w[q + "ca_o_b"] = h(P[p + "multihead_attn.out_proj.weight"]), c32(P[p + "multihead_attn.out_proj.bias"])
             w[q + "l1_w"], w[q + "l1_b"] = h(P[p + "linear1.weight"]), c32(P[p + "linear1.bias"])
             w[q + "l2_w"], w[q + "l2_b"] = h(P[p + "linear2.weight"]), c32(P[p + "linear2.bias"])
             for n in ("norm1", "norm2", "norm3"):
                 w[q + n + ".w"], w[q + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
+        # the `pos_y` half of a row-periodic table (pos_h = 1: one all-zero row; same row stride as the table it pairs with)
+        w["dec_tab_zero3"] = torch.zeros((1, 3 * D), dtype=f32, device=self._device())
+        w["dec_tab_zero1"] = torch.zeros((1, D), dtype=f32, device=self._device())
         kw, kb, vw, vb = (torch.cat(t, 0).detach() for t in (kw, kb, vw, vb))                        # [L*D, D], [L*D]
         if memory_linear is not None:
             w["ca_k_pos_w"] = c32(kw)
@@ -196,7 +203,6 @@ class _EngineBase:
         w["ca_k_w"], w["ca_k_b"] = self._hw(kw.to(f32), "dec_kv"), c32(kb)
         w["ca_v_w"], w["ca_v_b"] = self._hw(vw.to(f32), "dec_kv"), c32(vb)
         w["dec.norm.w"], w["dec.norm.b"] = c32(P["decoder.norm.weight"]), c32(P["decoder.norm.bias"])
-        w["query_embed"] = c32(P["query_embed"])
 
     def _pack_clip_visual(self, w, P, prefix: str, D: int, layers: int, patch: int):
         """CLIP VisionTransformer parameters (clip_arch.py:335-354) -> conv (K padded to 64), enc.{i}.*, ln_pre/ln_post."""
@@ -284,54 +290,46 @@ class _EngineBase:
         xd = self._x3("dec")
         Ff = P_shape0(W_["dec.0.l1_w"])
         xk = bool(KALL.plane)
-        qpos = W_["query_embed"]
         tgt = self._buf("tgt", (R, D), f32)
         t1 = self._buf("t1", (R, D), f32)
         tgt16 = self._abuf("tgt16", (R, D), xd)
-        qin16 = self._abuf("qin16", (R, D), xd)
-        qk16 = self._abuf("qk16", (R, 2 * D), xd)
-        v16 = self._abuf("v16", (R, D), xd)
+        qkv16 = self._abuf("dqkv16", (R, 3 * D), xd)
         qc16 = self._abuf("qc16", (R, D), xd)
         o16 = self._abuf("do16", (R, D), xd)
         ff16 = self._abuf("ff16", (R, Ff), xd)
         inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
         out32 = self._buf("dec_out32", (R, D), f32)
-        # tgt = zeros (zutis.py:164) and query_pos is a parameter, so layer 0's whole self-attention block — q/k/v projections
-        # of (0 + query_pos, 0), attention over the Q queries, out-projection, norm1 — does not depend on the image: its result
-        # (tgt after norm1 and f16(tgt + query_pos), [R, D] = the same Q rows for every image) is computed once per (batch rows,
-        # parameter version) with the same kernels and cached; layer 0 then starts at the cross-attention.
+        # `tgt + query_pos` never exists: the row tables of _pack_decoder enter the GEMMs as a row-periodic additive term (the
+        # `pos` form of zh_gemm with pos_h = 1, pos_w = Q: row m starts from table[m % Q]; added in fp32 before any rounding)
+        tab = lambda t: (W_["dec_tab_zero3" if t.shape[1] == 3 * D else "dec_tab_zero1"], t)
+
+        def self_attention_block(pp, src16, residual, norm_out32, norm_out16):
+            self._gemm("dec", src16, W_[pp + "sa_qkv_w"], qkv16, pos=tab(W_[pp + "sa_tab"]))    # q | k | v in ONE N = 3D GEMM
+            ops.attention(qkv16, qkv16.view(qkv16.hi[:, D:]), qkv16.view(qkv16.hi[:, 2 * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=Q,
+                          head_dim=dh, ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=Q * 3 * D, strideK=Q * 3 * D, strideV=Q * 3 * D,
+                          strideO=Q * D, x3=xd)
+            self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=residual)
+            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=norm_out32, out_f16=norm_out16)
+        # tgt = zeros (zutis.py:164) and query_pos is a parameter, so layer 0's whole self-attention block — projections of
+        # (0 + query_pos, 0), attention over the Q queries, out-projection, norm1 — does not depend on the image: its result
+        # (tgt after norm1, fp32 and fp16; [R, D] = the same Q rows for every image) is computed once per (batch rows, parameter
+        # version) with the same kernels and cached; layer 0 then starts at the cross-attention.
         ikey = ("dec_init", R, self._packed_key)
         init = self._geo.get(ikey)
         if init is None:
             dev = self._device()
-            z = torch.zeros((R, D), dtype=f32, device=dev)
             z16 = Act(torch.zeros((2 if xd else 1, R, D), dtype=f16, device=dev))
-            q0 = Act.empty((R, D), xd, dev)
-            ops.cast_f16(z, q0, R, D, add=qpos, add_rows=Q)
-            pp = "dec.0."
-            self._gemm("dec", q0, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])        # q = k = 0 + query_pos
-            self._gemm("dec", z16, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])          # v = 0 (the bias row)
-            ops.attention(qk16, qk16.view(qk16.hi[:, D:]), v16, o16, batch=B, heads=heads, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D,
-                          ldk=2 * D, ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D, x3=xd)
-            self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"])           # + tgt (= 0)
-            init = {"tgt0": torch.empty((R, D), dtype=f32, device=dev), "qin0": Act.empty((R, D), xd, dev)}
-            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=init["tgt0"], out_f16_plus=init["qin0"],
-                          add=qpos, add_rows=Q)
+            init = {"tgt0": torch.empty((R, D), dtype=f32, device=dev), "tgt0_16": Act.empty((R, D), xd, dev)}
+            self_attention_block("dec.0.", z16, None, init["tgt0"], init["tgt0_16"])      # q = k = query_pos, v = 0, + tgt (= 0)
             self._geo_put(ikey, init)
         for l in range(L):
             pp = f"dec.{l}."
             if l == 0:
-                tgt_in, qin_in = init["tgt0"], init["qin0"]
+                tgt_in, tgt_in16 = init["tgt0"], init["tgt0_16"]
             else:
-                self._gemm("dec", qin16, W_[pp + "sa_qk_w"], qk16, bias=W_[pp + "sa_qk_b"])     # q = k = tgt + query_pos
-                self._gemm("dec", tgt16, W_[pp + "sa_v_w"], v16, bias=W_[pp + "sa_v_b"])        # v = tgt
-                ops.attention(qk16, qk16.view(qk16.hi[:, D:]), v16, o16, batch=B, heads=heads, Tq=Q, Tk=Q, head_dim=dh, ldq=2 * D,
-                              ldk=2 * D, ldv=D, ldo=D, strideQ=Q * 2 * D, strideK=Q * 2 * D, strideV=Q * D, strideO=Q * D, x3=xd)
-                self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=tgt)
-                ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=tgt, out_f16_plus=qin16,
-                              add=qpos, add_rows=Q)
-                tgt_in, qin_in = tgt, qin16
-            self._gemm("dec", qin_in, W_[pp + "ca_q_w"], qc16, bias=W_[pp + "ca_q_b"])
+                self_attention_block(pp, tgt16, tgt, tgt, tgt16)                            # transformer.py:272-278
+                tgt_in, tgt_in16 = tgt, tgt16
+            self._gemm("dec", tgt_in16, W_[pp + "ca_q_w"], qc16, pos=tab(W_[pp + "ca_q_tab"]))   # :281-282 query projection
             ops.attention(qc16, KALL.view(KALL.hi[:, l * D:]), VALL.view(VALL.hi[:, l * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=M,
                           head_dim=dh, ldq=D, ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D,
                           strideO=Q * D, x3=xk)
@@ -339,8 +337,7 @@ class _EngineBase:
             ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
             self._gemm("dec", tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
             self._gemm("dec", ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
-            ops.layernorm(t1, W_[pp + "norm3.w"], W_[pp + "norm3.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16,
-                          out_f16_plus=qin16, add=qpos, add_rows=Q)
+            ops.layernorm(t1, W_[pp + "norm3.w"], W_[pp + "norm3.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
             if stack_all:                                                                   # :140-150, stacked [B,L,Q,D]
                 ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16,
                               out_group_rows=Q, out_group_stride=L * Q, out_offset=l * Q)
