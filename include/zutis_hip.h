@@ -43,10 +43,16 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 210 /* 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 211 /* 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
+
+/* DEVELOPER entry (tests / tools, not part of the reference's surface): force the GEMM tile variant for the calls that follow.
+ * group_m = super-tile height (0 = default 4); tile = tile code for zh_gemm_f16 (64|128|192|256|2064|2128|3064) and
+ * zh_gemm_f16x3 (64|192|256|512), 0 = the cost model's choice; tile_small = the same, applied to M <= 4096 only.  Process-wide;
+ * the initial values come from ZH_GEMM_GROUP_M / ZH_GEMM_TILE / ZH_GEMM_TILE_SMALL, read once. */
+int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small);
 
 /* C[b][m][n] = act(sum_k A[b][m][k]*W[b][n][k] + bias[n] + pos[m][n]) + residual[b][m % res_rows][n]
  * A [M,K] f16 (lda), W [N,K] f16 (ldw) — torch Linear layout; C f32 or f16 (out_f16); bias/residual f32 or NULL.

@@ -29,7 +29,10 @@ def _dropin():
 # |scores| in the hundreds) and fast keeps the decoder body on fp16 operands, whose 2^-11 rounding such scores amplify — measured
 # 0.11 on the mask proposals (round 3).  That is outside fast's stated envelope (DESIGN.md "Precision"); the default / headline
 # precision is exact.  fast's instance path is covered by test_dropin_module_matches_reference_golden (tiny config).
-@pytest.mark.parametrize("precision,t_tok,t_mask,t_score,t_area", [("exact", 2e-5, 2e-4, 1e-4, 8)])
+# t_score: a candidate's confidence is the mean proposal value inside its low-res mask (54x80 / 60x80 pixels, areas of a few
+# hundred): ONE pixel whose value sits within 1e-6 of the 0.7 threshold changes it by ~ 0.05 / area ~ 2e-4 (seen: 1.7e-4 on one
+# of 100 candidates); the kernel itself is held to 1e-6 on identical inputs by test_instance_kernels_vs_oracle_exact_inputs.
+@pytest.mark.parametrize("precision,t_tok,t_mask,t_score,t_area", [("exact", 2e-5, 2e-4, 5e-4, 8)])
 @pytest.mark.parametrize("H,W", [(480, 640), (427, 640)])
 def test_c3_native_resolution_instance_predict(dev, golden_dir, H, W, precision, t_tok, t_mask, t_score, t_area):
     """Weights detgen.c3_state_dict + the fixture's text rows + threshold C3_THRESHOLD: 9 categories, 100 candidates, 17 / 12

@@ -122,22 +122,43 @@ def test_gemm_race_screen_bitwise_repeatable(dev):
 
 
 @pytest.mark.parametrize("tile", ["256", "192", "128", "64", "2128", "2064", "3064"])
-def test_gemm_every_tile_variant_every_ring_phase(dev, tile, monkeypatch):
-    """Each tile / ring-depth variant (ZH_GEMM_TILE developer override) over K = 64 .. 1024: every prologue / steady / tail
-    combination of the 4- and 8-deep LDS-DMA rings, ragged M and N, repeated launches bitwise identical."""
-    from zutis_amd import ops
-    monkeypatch.setenv("ZH_GEMM_TILE", tile)
-    M, N = 333, 328
-    for K in (64, 128, 192, 256, 320, 448, 512, 576, 640, 1024):
-        A, W = _randn((M, K), 300 + K, 0.5).to(f16).to(dev), _randn((N, K), 400 + K, 0.5).to(f16).to(dev)
-        ref = A.float() @ W.float().t()
-        outs = []
-        for _ in range(3):
-            out = torch.empty((M, N), dtype=f32, device=dev)
+def test_gemm_every_tile_variant_every_ring_phase(dev, tile):
+    """Each tile / ring-depth variant (forced through the developer entry zh_dev_set_gemm_overrides: the environment is read
+    once per process) over K = 64 .. 1024: every prologue / steady / tail combination of the 4- and 8-deep LDS-DMA rings,
+    ragged M and N, repeated launches bitwise identical."""
+    from zutis_amd import ops, _lib
+    L = _lib.load(raw=True)
+    _lib.check(L.zh_dev_set_gemm_overrides(0, int(tile), 0), "zh_dev_set_gemm_overrides")
+    try:
+        M, N = 333, 328
+        for K in (64, 128, 192, 256, 320, 448, 512, 576, 640, 1024):
+            A, W = _randn((M, K), 300 + K, 0.5).to(f16).to(dev), _randn((N, K), 400 + K, 0.5).to(f16).to(dev)
+            ref = A.float() @ W.float().t()
+            outs = []
+            for _ in range(3):
+                out = torch.empty((M, N), dtype=f32, device=dev)
+                ops.gemm(A, W, out)
+                outs.append(out)
+            assert torch.allclose(outs[0], ref, atol=1e-3 * math.sqrt(K / 64), rtol=1e-3), (tile, K)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (tile, K)
+    finally:
+        L.zh_dev_set_gemm_overrides(0, 0, 0)
+
+
+def test_gemm_forced_tile_is_really_forced(dev):
+    """The override reaches the launcher: an unknown tile code is an argument error (it would be ignored if the setter did
+    nothing), and clearing it restores the cost model."""
+    from zutis_amd import ops, _lib
+    L = _lib.load(raw=True)
+    A, W = torch.zeros((64, 64), dtype=f16, device=dev), torch.zeros((64, 64), dtype=f16, device=dev)
+    out = torch.empty((64, 64), dtype=f32, device=dev)
+    L.zh_dev_set_gemm_overrides(0, 777, 0)
+    try:
+        with pytest.raises(_lib.ZutisHipError, match="not a tile code"):
             ops.gemm(A, W, out)
-            outs.append(out)
-        assert torch.allclose(outs[0], ref, atol=1e-3 * math.sqrt(K / 64), rtol=1e-3), (tile, K)
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (tile, K)
+    finally:
+        L.zh_dev_set_gemm_overrides(0, 0, 0)
+    ops.gemm(A, W, out)
 
 
 def test_gemm_rejects_bad_k(dev):

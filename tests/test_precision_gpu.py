@@ -147,6 +147,40 @@ def test_gemm_x3_race_screen_bitwise_repeatable(dev):
         assert float((outs[0].double() - ref).abs().max()) < 1e-4 * math.sqrt(K / 64)
 
 
+@pytest.mark.parametrize("tile", [64, 192, 256, 512])
+def test_gemm_x3_every_tile_variant(dev, tile):
+    """Every x3 tile (128x64, 192x128, 256x128 on the 3-slot ring; 256x256 on the two-slot ring with the SGPR-base LDS-DMA and
+    the in-place A lo fragments), forced through zh_dev_set_gemm_overrides, over K = 64 .. 1024 (every prologue / steady / tail
+    phase), ragged M and N, f32 / split-pair outputs with bias, activation and residual: fp32-class against float64 and bitwise
+    repeatable."""
+    from zutis_amd import ops, _lib
+    from zutis_amd.ops import Act
+    L = _lib.load(raw=True)
+    _lib.check(L.zh_dev_set_gemm_overrides(0, tile, 0), "zh_dev_set_gemm_overrides")
+    try:
+        for (M, N) in ((333, 328), (700, 520)):
+            for K in (64, 128, 192, 256, 320, 448, 512, 1024):
+                A32, W32 = _randn((M, K), 300 + K, 0.5), _randn((N, K), 400 + K, 0.05)
+                bias, res = _randn((N,), 5), _randn((M, N), 6)
+                A, W = _split_act(A32, dev), ops.split_weight(W32.to(dev))
+                ref = A32.double() @ W32.double().t() + bias.double()
+                bound = float((A32.abs().double() @ W32.abs().double().t()).max())
+                outs = []
+                for _ in range(3):
+                    o = torch.empty((M, N), dtype=f32, device=dev)
+                    ops.gemm_x3(A, W, o, bias=bias.to(dev), residual=res.to(dev))
+                    outs.append(o)
+                assert float((outs[0].cpu().double() - (ref + res.double())).abs().max()) < 2e-6 * bound + 1e-6, (tile, M, N, K)
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (tile, M, N, K)
+                sp = Act.empty((M, N), True, dev)
+                ops.gemm_x3(A, W, sp, bias=bias.to(dev), act=ops.ACT_RELU)
+                got = sp.t[0].float().cpu().double() + sp.t[1].float().cpu().double()
+                want = torch.relu(ref)
+                assert float((got - want).abs().max()) < 2e-6 * bound + 2e-6 * float(want.abs().max()) + 1e-6, (tile, M, N, K)
+    finally:
+        L.zh_dev_set_gemm_overrides(0, 0, 0)
+
+
 def test_split_producers_write_hi_plus_lo(dev):
     """Every producer with a lo_plane argument: hi plane == the plain fp16 output, hi + lo == the fp32 value to ~2^-22."""
     from zutis_amd import ops

@@ -17,6 +17,10 @@ def t(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
 tag = os.environ.get("ZUTIS_HIP_LIB", "product")
+if os.environ.get("ZH_X3_TILE"):                      # forced x3 tile code (64 | 192 | 256 | 512) for every shape
+    from zutis_amd import _lib
+    _lib.load(raw=True).zh_dev_set_gemm_overrides(0, int(os.environ["ZH_X3_TILE"]), 0)
+    tag += "-tile" + os.environ["ZH_X3_TILE"]
 for M, N, K, name, kind in shapes:
     row = f"[{os.path.basename(tag)}] {name:7s} {M}x{N}x{K} out={kind:5s}"
     for data in ("zeros", "model"):
@@ -30,7 +34,7 @@ for M, N, K, name, kind in shapes:
         res = None if kind != "f32" else out
         dt3 = t(lambda: ops.gemm_x3(A, W, out, residual=res))
         row += f" | {data}: x3 {dt3*1e6:7.1f} us {2*M*N*K/dt3/1e12:6.1f} TF (pipe {3*2*M*N*K/dt3/1e15:4.2f} PF)"
-        if "NO" not in tag:
+        if "NO" not in tag and "tile" not in tag:
             o2 = out if kind == "f32" else Act.empty((M, N), False, dev)
             dt1 = t(lambda: ops.gemm(A.hi, W.hi, o2, residual=res))
             row += f" f16 {dt1*1e6:6.1f} us {2*M*N*K/dt1/1e12:6.1f} TF"

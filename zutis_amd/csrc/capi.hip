@@ -16,6 +16,30 @@ extern "C" const char* zh_last_error(void) { return g_err; }
 extern "C" int zh_version(void) { return ZH_ABI_VERSION; }   // include/zutis_hip.h
 extern "C" const char* zh_arch(void) { return "gfx950"; }
 
+// ---- developer overrides of the GEMM tile choice (gemm_kernel.h): one process-wide instance, initialised from the environment
+//      once, changed only through zh_dev_set_gemm_overrides (tests force every tile variant with it)
+#include <stdlib.h>
+struct GemmDevOverrides { int group_m; int tile; int tile_small; };
+static GemmDevOverrides& gemm_dev_state() {
+  static GemmDevOverrides o = [] {
+    GemmDevOverrides v{4, 0, 0};
+    if (const char* g = getenv("ZH_GEMM_GROUP_M")) { const int x = atoi(g); if (x >= 1) v.group_m = x; }
+    if (const char* t = getenv("ZH_GEMM_TILE")) v.tile = atoi(t);
+    if (const char* t = getenv("ZH_GEMM_TILE_SMALL")) v.tile_small = atoi(t);
+    return v;
+  }();
+  return o;
+}
+const GemmDevOverrides& gemm_dev_overrides() { return gemm_dev_state(); }
+extern "C" int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small) {
+  ZH_CHECK_ARG(group_m >= 0 && tile >= 0 && tile_small >= 0, "zh_dev_set_gemm_overrides: negative argument");
+  GemmDevOverrides& o = gemm_dev_state();
+  o.group_m = group_m >= 1 ? group_m : 4;
+  o.tile = tile;
+  o.tile_small = tile_small;
+  return ZH_OK;
+}
+
 // ---- host-side COCO RLE (pycocotools maskApi.c rleEncode + rleToString restated): the reference encodes every kept
 //      instance mask with pycocotools.mask.encode(np.asfortranarray(m)) (networks/zutis.py:290,448).  HOST pointers.
 //      mask u8 [H,W] row-major; runs are taken in column-major order starting with the zeros run.  Returns the string

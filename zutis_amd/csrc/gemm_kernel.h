@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   constexpr int ROWS = NPL * (BM + BN);     // LDS rows per stage (A planes then W planes), 64 B each
   constexpr int PIECES = ROWS / 16;         // 1-KiB DMA pieces per stage
   constexpr int NP = (PIECES + NW - 1) / NW;  // DMA issues per wave per stage (duplicates pad uneven splits)
-  static_assert(NP >= 2 && NP <= 8 && STAGES >= 3 && STAGES <= 8, "unsupported pieces-per-wave count / ring depth");
+  static_assert(NP >= 2 && NP <= 8 && STAGES >= (SPLIT ? 2 : 3) && STAGES <= 8, "unsupported pieces-per-wave count / ring depth");
   // Prefetch distance: slice kt+STAGES-1 goes into the slot whose fragments were consumed before the current barrier.
   constexpr int DIST = STAGES - 1;
   constexpr int AHEAD = SPLIT ? 1 : DIST - 2; // whole stages that may still be in flight at a steady-state barrier
@@ -294,7 +294,99 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const half_t* rdA = smem + (wr * TM * 16) * BK + foff;
   const half_t* rdW = smem + (NPL * BM + wc * TN * 16) * BK + foff;
 
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT && STAGES == 2) {
+    // ---- f16x3 loop, big tile (256 x 256, 8 waves of 128 x 64), TWO 64-KiB slots.  Ablations of the 3-slot 256 x 128 loop
+    // (tools/gemm_x3_probe.sh, round 3; QKV shape, model-shaped operands): all 160 us; MFMAs removed 116 us; operand
+    // movement removed (no DMA, no fragment reads) 119 us — the LDS-DMA stream (48 KiB per slice and CU, at its request-rate
+    // limit) is as long a leg as the MFMAs, and the two overlap poorly.  A 256 x 256 tile moves 64 KiB per slice for TWICE
+    // the MFMAs (-33 % bytes and -25 % fragment reads per MFMA).  Its ring has room for two slots only, but a slice now
+    // carries 96 MFMAs per wave (~1.5 us at two waves per SIMD): one slice of prefetch covers the load latency.
+    // Per slice: barrier (slice kt landed everywhere, everyone is done with the other slot) -> DMA of slice kt+1 into the other
+    // slot -> fragments hi planes first -> three sweeps (hi*hi, lo_w*hi_a, hi_w*lo_a).
+    // LDS-DMA issue with a wave-uniform 64-bit base in SGPRs and a constant 32-bit per-lane BYTE offset (the `saddr` form of
+    // global_load_lds, from inline asm): the builtin's flat-pointer form made hipcc keep eight 64-bit per-lane addresses in
+    // VGPRs and re-derive them with 64-bit VALU adds per issue — 16+ registers this tile does not have (it spilled).
+    const half_t* sbase[NP];
+    unsigned goffb[NP], ldsb[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      sbase[i] = gbase[i];
+      goffb[i] = goff[i] * 2u;                                   // host check: operands below 2^31 elements for this tile
+      ldsb[i] = (unsigned)(uintptr_t)smem + (unsigned)lds_piece[i] * 2u;
+    }
+    auto issue2 = [&](int slot) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(ldsb[i] + (unsigned)(slot * STAGE_HALVES * 2)), "v"(goffb[i]), "s"(sbase[i]) : "memory");
+        sbase[i] += BK;
+      }
+    };
+    pos_before_prologue();
+    issue2(0);
+    pos_after_prologue();
+    // Registers: 128 accumulators + A hi (32) + W hi (16) + W lo (16); a fourth fragment set does not fit (the build fails on
+    // scratch).  The A lo fragments therefore REPLACE the A hi ones: the second sweep walks the A fragments in order and, as
+    // soon as fragment mt has fed its TN MFMAs, its lo plane is read into the same registers — TM - 1 groups of MFMAs ahead
+    // of the third sweep's first use.
+    half8_t fa[TM], fw[2 * TN];
+    auto read_hi = [&](int slot) {
+      const int so = slot * STAGE_HALVES;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) fa[t] = *(const half8_t*)(rdA + so + (t * 16) * BK);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) fw[t] = *(const half8_t*)(rdW + so + (t * 16) * BK);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) fw[TN + t] = *(const half8_t*)(rdW + so + (BN + t * 16) * BK);
+    };
+    auto body = [&](int slot, bool prefetch) {
+      const int so = slot * STAGE_HALVES;
+#ifndef ZH_X3_NOBAR
+      // lgkmcnt(0) too: hipcc moves the last MFMAs of the previous slice (register-only) below this point and with them the
+      // wait for the fragment reads they consume — every read of the slot the DMA below overwrites must have RETURNED first
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#ifndef ZH_X3_NOFRAG
+      read_hi(slot);
+#endif
+#ifndef ZH_X3_NODMA
+      if (prefetch) issue2(slot ^ 1);
+#endif
+#ifndef ZH_X3_NOMFMA
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt)                  // hi_w * hi_a
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) {                // lo_w * hi_a, then this A fragment's lo plane takes its place
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[TN + nt], fa[mt], acc[nt][mt], 0, 0, 0);
+#ifndef ZH_X3_NOFRAG
+        fa[mt] = *(const half8_t*)(rdA + so + (BM + mt * 16) * BK);
+#endif
+      }
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)                  // hi_w * lo_a
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+#else
+      acc[0][0] += (f32x4){(float)fa[0][0], (float)fw[0][1], (float)fa[TM - 1][2], (float)fw[TN][3]};
+#endif
+    };
+#ifdef ZH_X3_NOFRAG
+    read_hi(0);
+#endif
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {       // nk is even: two slices per trip keep the slot index a compile-time constant
+      body(0, true);
+      body(1, true);
+    }
+    body(0, true);
+    body(1, false);
+  } else if constexpr (SPLIT) {
     // ---- f16x3 loop.  Fragments are single-buffered (hi + lo of both operands = 64 registers at 64x64 per wave; a second
     // set does not fit next to the accumulators at two waves per SIMD): slice kt's fragments are read right after the
     // barrier of iteration kt, hi planes first, and the first sweep of MFMAs (hi*hi) starts as soon as those arrive while
@@ -606,16 +698,8 @@ static inline double tiling_cost(long M, long N, int batch, int BM, int BN, int 
   return (double)rounds * BM * BN * bpc / eff;
 }
 
-// Developer overrides, read ONCE per process (never per launch): ZH_GEMM_GROUP_M = super-tile height,
-// ZH_GEMM_TILE = forced tile code (validated by the caller; unknown codes are an argument error).
-struct GemmDevOverrides { int group_m; int tile; int tile_small; };   // tile_small: ZH_GEMM_TILE_SMALL, applied to M <= 4096 only
-static inline const GemmDevOverrides& gemm_dev_overrides() {
-  static const GemmDevOverrides o = [] {
-    GemmDevOverrides v{GROUP_M, 0, 0};
-    if (const char* g = getenv("ZH_GEMM_GROUP_M")) { const int x = atoi(g); if (x >= 1) v.group_m = x; }
-    if (const char* t = getenv("ZH_GEMM_TILE")) v.tile = atoi(t);
-    if (const char* t = getenv("ZH_GEMM_TILE_SMALL")) v.tile_small = atoi(t);
-    return v;
-  }();
-  return o;
-}
+// Developer overrides (defined once, in capi.hip): initialised ONCE per process from ZH_GEMM_GROUP_M (super-tile height),
+// ZH_GEMM_TILE (forced tile code; unknown codes are an argument error) and ZH_GEMM_TILE_SMALL (applied to M <= 4096 only) —
+// never read per launch — and settable at run time through zh_dev_set_gemm_overrides() (tests / tools).
+struct GemmDevOverrides { int group_m; int tile; int tile_small; };
+const GemmDevOverrides& gemm_dev_overrides();

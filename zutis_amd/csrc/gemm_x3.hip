@@ -74,15 +74,22 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
                        (out_kind == 1 ? (N % 8 == 0) : true) && (out_kind != 2 || (ldc % 8 == 0 && planeC % 8 == 0 && N % 8 == 0));
   // 256 x 128 or 192 x 128 (8 waves, 144 / 120 KiB ring, one block per CU; the 192-row tile quantises N = 768 GEMMs into
   // 1.73 rounds of the chip instead of 1.31) or 128 x 64 (4 waves, two blocks per CU) for small problems
+  // ... or 256 x 256 (8 waves of 128 x 64, two 64-KiB slots): a third fewer staged bytes per MFMA, for GEMMs wide enough to fill
+  // the chip with such tiles (QKV, c_fc, the K / V projections)
   const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
   const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
   const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
+  const double cbig = tiling_cost(M, N, batch, 256, 256, 1, 1.25);
   int pick = (c64 < c256 && c64 < c192) ? 64 : (c192 < c256 ? 192 : 256);
+  if (cbig < c256 && cbig < c192 && cbig < c64 && N >= 1024) pick = 512;
   const int forced = gemm_dev_overrides().tile;
-  if (forced == 64 || forced == 192 || forced == 256) pick = forced;
+  if (forced == 64 || forced == 192 || forced == 256 || forced == 512) pick = forced;
+  // the 256 x 256 tile addresses operand rows as SGPR base + 32-bit per-lane BYTE offset
+  if (pick == 512 && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
   bool ok;
   if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
   else if (!wide_ok) ok = launch_x3<2, 2, 4, 2, 3, 1>(p, batch, out_kind, stream);
+  else if (pick == 512) ok = launch_x3<2, 4, 8, 4, 2, 2>(p, batch, out_kind, stream);
   else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
