@@ -147,7 +147,36 @@ def test_gemm_x3_race_screen_bitwise_repeatable(dev):
         assert float((outs[0].double() - ref).abs().max()) < 1e-4 * math.sqrt(K / 64)
 
 
-@pytest.mark.parametrize("tile", [64, 192, 256, 512])
+@pytest.mark.parametrize("kind", ["split", "f16", "f32"])
+def test_gemm_x3_row_periodic_table_before_rounding(dev, kind):
+    """The decoder's query_pos terms (transformer.py:272-275,281-282 by linearity): out[m] = A[m] W^T + table[m % Q] with a table
+    that DWARFS the products (queries x20: |table| ~ 500 against products of O(1)).  The table must join the finished fp32
+    accumulator once (fp32-class: |err| <= a few ulp of the table), for f32, fp16 and split-pair outputs."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    B, Q, N, K = 5, 100, 2304, 768
+    M = B * Q
+    A32, W32 = _randn((M, K), 1), _randn((N, K), 2, 0.03)
+    T = _randn((Q, N), 3, 150.0)
+    ref = A32.double() @ W32.double().t() + T.double().repeat(B, 1)
+    A, W = _split_act(A32, dev), ops.split_weight(W32.to(dev))
+    if kind == "f32":
+        out = torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm_x3(A, W, out, residual=T.to(dev), res_rows=Q)
+        got, tol = out.cpu().double(), 6e-5                      # one fp32 rounding at |out| <= ~700: ulp 6e-5
+    elif kind == "split":
+        out = Act.empty((M, N), True, dev)
+        ops.gemm_x3(A, W, out, residual=T.to(dev), res_rows=Q)
+        got, tol = out.t[0].float().cpu().double() + out.t[1].float().cpu().double(), 2.5e-4   # 22 bits of ~700
+    else:
+        out = Act.empty((M, N), False, dev)
+        ops.gemm_x3(A, W, out, residual=T.to(dev), res_rows=Q)
+        got, tol = out.hi.float().cpu().double(), 0.3            # fp16 of ~700: ulp 0.5
+        assert torch.equal(out.hi.cpu(), ref.to(torch.float32).to(f16)) or float((got - ref).abs().max()) <= 0.5
+    assert float((got - ref).abs().max()) < tol, float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("tile", [64, 192, 256, 512, 448])
 def test_gemm_x3_every_tile_variant(dev, tile):
     """Every x3 tile (128x64, 192x128, 256x128 on the 3-slot ring; 256x256 on the two-slot ring with the SGPR-base LDS-DMA and
     the in-place A lo fragments), forced through zh_dev_set_gemm_overrides, over K = 64 .. 1024 (every prologue / steady / tail

@@ -41,8 +41,13 @@ names = {0: "full", 1: "-exp", 2: "-PV(+softmax DCE)", 4: "-S", 8: "-tiles-barri
 for name, B, H, dh, Tq, Tk in [("enc", 32, 12, 64, 442, 442), ("cross", 32, 8, 96, 100, 1764), ("c4enc", 8, 12, 64, 1025, 1025), ("c5enc", 256, 16, 64, 577, 577),
                               ("selfmask", 1, 6, 64, 5505, 5505)]:
     D = H * dh
-    q = torch.randn(B, Tq, D, device=dev).half(); k = torch.randn(B, Tk, D, device=dev).half(); v = torch.randn(B, Tk, D, device=dev).half()
-    o = torch.empty(B, Tq, D, device=dev, dtype=torch.float16)
+    X3 = "--x3" in sys.argv                    # split-pair kernels: [2, B, T, D] tensors, plane offset = B*T*D
+    P = 2 if X3 else 1
+    q = torch.randn(P, B, Tq, D, device=dev).half(); k = torch.randn(P, B, Tk, D, device=dev).half(); v = torch.randn(P, B, Tk, D, device=dev).half()
+    if X3:
+        q[1] *= 2 ** -11; k[1] *= 2 ** -11; v[1] *= 2 ** -11
+    o = torch.empty(P, B, Tq, D, device=dev, dtype=torch.float16)
+    pq, pk, po = (B * Tq * D, B * Tk * D, B * Tq * D) if X3 else (0, 0, 0)
     fns = {}
     for m in MASKS:
         L = C.CDLL(os.path.join(HERE, "_abl", f"libattn_{m}.so"))
@@ -50,7 +55,7 @@ for name, B, H, dh, Tq, Tk in [("enc", 32, 12, 64, 442, 442), ("cross", 32, 8, 9
         L.zh_attention_f16.argtypes = [vp, l, l, vp, l, l, vp, l, l, vp, l, l, i, i, i, i, i, f, l, l, l, l, vp]
         s = torch.cuda.current_stream().cuda_stream
         fns[m] = (lambda L=L: L.zh_attention_f16(q.data_ptr(), D, Tq * D, k.data_ptr(), D, Tk * D, v.data_ptr(), D, Tk * D, o.data_ptr(), D, Tq * D,
-                                                 B, H, Tq, Tk, dh, dh ** -0.5, 0, 0, 0, 0, s))
+                                                 B, H, Tq, Tk, dh, dh ** -0.5, pq, pk, pk, po, s))
         assert fns[m]() == 0
     if "--ab" in sys.argv:                                            # variants must agree with the first one
         outs = {}

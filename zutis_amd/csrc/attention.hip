@@ -235,20 +235,40 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     const float m_new = fmaxf(m_run, mx * p.scale_log2);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
+    // P as packed fp16 pairs: register (r >> 1) & 3 of fragment r >> 3 holds scores r, r + 1 — the MFMA B operand as is
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 pfu[NU][2], plu[X3 ? NU : 1][2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+#if ZH_ATTN_ABL & 1
+        const float e0 = __builtin_fmaf(s[u][r], p.scale_log2, -m_new), e1 = __builtin_fmaf(s[u][r + 1], p.scale_log2, -m_new);
+#else
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r + 1], p.scale_log2, -m_new));
+#endif
+        const half2_t eh2 = {(half_t)e0, (half_t)e1};      // one v_cvt_pk_f16_f32
+        unsigned eh = __builtin_bit_cast(unsigned, eh2);
+        if (X3) {
+          // lo = f16(e - hi) from the very bits that are used as hi (cf. zh_store_h4, common.h), ONE instruction per value:
+          // v_fma_mix{lo,hi}_f16 reads hi as fp16, forms e - hi exactly in fp32 and rounds once (the plain expression costs
+          // v_cvt_f32_f16 + v_sub_f32 + half a v_cvt_pk per value: of the softmax's ~26 VALU issue cycles per score, 6 go)
+          unsigned el;
+          asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+              "v_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+              : "=&v"(el) : "v"(eh), "v"(e0), "v"(e1));
+          plu[u][r >> 3][(r >> 1) & 3] = el;
+        }
+        pfu[u][r >> 3][(r >> 1) & 3] = eh;
+      }
     half8_t pf[NU][2], pl[X3 ? NU : 1][2];
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#if ZH_ATTN_ABL & 1
-        const float e = __builtin_fmaf(s[u][r], p.scale_log2, -m_new);
-#else
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
-#endif
-        half_t eh = (half_t)e;
-        if (X3) asm volatile("" : "+v"(eh));      // one conversion only: see zh_store_h4 (common.h)
-        pf[u][r >> 3][r & 7] = eh;
-        if (X3) pl[u][r >> 3][r & 7] = (half_t)(e - (float)eh);
+      for (int k = 0; k < 2; ++k) {
+        pf[u][k] = __builtin_bit_cast(half8_t, pfu[u][k]);
+        if (X3) pl[u][k] = __builtin_bit_cast(half8_t, plu[u][k]);
       }
     if (__any(alpha != 1.0f)) {
 #pragma unroll

@@ -602,7 +602,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         const int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
         f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
         if (m < p.M && n < p.N) {
-          if (OUT == 0 && R) d += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
+          // f32 and split-pair outputs: the slab holds fp32, the (row-periodic) residual joins before the one rounding
+          if (OUT != 1 && R) d += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
           if (OUT == 1) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
           else if (OUT == 0) *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
           else {

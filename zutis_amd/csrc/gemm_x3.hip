@@ -49,7 +49,10 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
                "zh_gemm_f16x3: an operand exceeds 2^32 elements per batch item (M=%d lda=%ld N=%d ldw=%ld)", M, lda, N, ldw);
   ZH_CHECK_ARG(out_kind >= 0 && out_kind <= 2, "zh_gemm_f16x3: out_kind %d not in {0 f32, 1 f16, 2 split pair}", out_kind);
   ZH_CHECK_ARG(out_kind != 2 || (planeC != 0 && planeC % 4 == 0), "zh_gemm_f16x3: split output needs planeC (multiple of 4)");
-  ZH_CHECK_ARG(!residual || (res_rows > 0 && out_kind == 0), "zh_gemm_f16x3: residual needs res_rows > 0 and an f32 output");
+  // residual[m % res_rows] is added in fp32 after the activation; for fp16 / split-pair outputs (a row-periodic additive table:
+  // the decoder's query_pos terms) that is BEFORE the one rounding, and only without an activation
+  ZH_CHECK_ARG(!residual || (res_rows > 0 && (out_kind == 0 || act == ZH_ACT_NONE)),
+               "zh_gemm_f16x3: residual needs res_rows > 0 and, for fp16 / split outputs, no activation");
   ZH_CHECK_ARG(zh_pos_tables_ok(pos_y, pos_x, ld_pos, pos_h, pos_w, N), "zh_gemm_f16x3: pos tables need both pointers 16-byte aligned, "
                "pos_h, pos_w > 0, ld_pos %% 8 == 0 and N %% 4 == 0");
   ZH_CHECK_ARG(out_scale > 0.0f, "zh_gemm_f16x3: out_scale must be positive");
@@ -71,25 +74,34 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   ZH_CHECK_ARG((long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch < (1L << 31), "zh_gemm_f16x3: grid too large");
   // the LDS-staged epilogue reads the slab in 16-byte chunks: f32 / split rows need N % 4 == 0 (vec_ok), f16 rows N % 8 == 0
   const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&
-                       (out_kind == 1 ? (N % 8 == 0) : true) && (out_kind != 2 || (ldc % 8 == 0 && planeC % 8 == 0 && N % 8 == 0));
+                       (out_kind == 1 ? (N % 8 == 0 && !residual) : true) &&      // fp16 slab: a residual takes the direct-store path
+                       (out_kind != 2 || (ldc % 8 == 0 && planeC % 8 == 0 && N % 8 == 0));
   // 256 x 128 or 192 x 128 (8 waves, 144 / 120 KiB ring, one block per CU; the 192-row tile quantises N = 768 GEMMs into
   // 1.73 rounds of the chip instead of 1.31) or 128 x 64 (4 waves, two blocks per CU) for small problems
-  // ... or 256 x 256 (8 waves of 128 x 64, two 64-KiB slots): a third fewer staged bytes per MFMA, for GEMMs wide enough to fill
-  // the chip with such tiles (QKV, c_fc, the K / V projections)
+  // ... or, for M >= 4096 rows, the two-slot big tiles (8 waves, 2 x 4): 256 x 256 (waves of 128 x 64, 64 KiB per K slice) and
+  // 192 x 256 (waves of 96 x 64, 56 KiB) — a third fewer staged bytes per MFMA than 256 x 128, which is what bounds the 3-slot
+  // loop (tools/gemm_x3_probe.sh).  256 x 256 serves the wide GEMMs (QKV, c_fc, the K / V projections); 192 x 256 turns the
+  // N = 768 ones (out_proj, c_proj) into ONE round of 222 tiles where 192 x 128 needs two rounds of 444.
   const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
   const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
   const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
-  const double cbig = tiling_cost(M, N, batch, 256, 256, 1, 1.25);
   int pick = (c64 < c256 && c64 < c192) ? 64 : (c192 < c256 ? 192 : 256);
-  if (cbig < c256 && cbig < c192 && cbig < c64 && N >= 1024) pick = 512;
+  if (M >= 4096) {
+    const double cbig = tiling_cost(M, N, batch, 256, 256, 1, 1.25);
+    const double c448 = tiling_cost(M, N, batch, 192, 256, 1, 1.2);
+    const double cur = pick == 64 ? c64 : (pick == 192 ? c192 : c256);
+    if (cbig < cur && cbig <= c448) pick = 512;
+    else if (c448 < cur) pick = 448;
+  }
   const int forced = gemm_dev_overrides().tile;
-  if (forced == 64 || forced == 192 || forced == 256 || forced == 512) pick = forced;
-  // the 256 x 256 tile addresses operand rows as SGPR base + 32-bit per-lane BYTE offset
-  if (pick == 512 && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
+  if (forced == 64 || forced == 192 || forced == 256 || forced == 512 || forced == 448) pick = forced;
+  // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
+  if ((pick == 512 || pick == 448) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
   bool ok;
   if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
   else if (!wide_ok) ok = launch_x3<2, 2, 4, 2, 3, 1>(p, batch, out_kind, stream);
   else if (pick == 512) ok = launch_x3<2, 4, 8, 4, 2, 2>(p, batch, out_kind, stream);
+  else if (pick == 448) ok = launch_x3<2, 4, 6, 4, 2, 2>(p, batch, out_kind, stream);
   else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);

@@ -193,9 +193,6 @@ class _EngineBase:
             w[q + "l2_w"], w[q + "l2_b"] = h(P[p + "linear2.weight"]), c32(P[p + "linear2.bias"])
             for n in ("norm1", "norm2", "norm3"):
                 w[q + n + ".w"], w[q + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
-        # the `pos_y` half of a row-periodic table (pos_h = 1: one all-zero row; same row stride as the table it pairs with)
-        w["dec_tab_zero3"] = torch.zeros((1, 3 * D), dtype=f32, device=self._device())
-        w["dec_tab_zero1"] = torch.zeros((1, D), dtype=f32, device=self._device())
         kw, kb, vw, vb = (torch.cat(t, 0).detach() for t in (kw, kb, vw, vb))                        # [L*D, D], [L*D]
         if memory_linear is not None:
             w["ca_k_pos_w"] = c32(kw)
@@ -299,12 +296,13 @@ class _EngineBase:
         ff16 = self._abuf("ff16", (R, Ff), xd)
         inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
         out32 = self._buf("dec_out32", (R, D), f32)
-        # `tgt + query_pos` never exists: the row tables of _pack_decoder enter the GEMMs as a row-periodic additive term (the
-        # `pos` form of zh_gemm with pos_h = 1, pos_w = Q: row m starts from table[m % Q]; added in fp32 before any rounding)
-        tab = lambda t: (W_["dec_tab_zero3" if t.shape[1] == 3 * D else "dec_tab_zero1"], t)
+        # `tgt + query_pos` never exists: the row tables of _pack_decoder enter the GEMMs as a row-periodic residual (row m gets
+        # table[m % Q], added in fp32 to the finished accumulator, before the one rounding to fp16 / a split pair).  NOT as an
+        # accumulator start value (the `pos` form): with large query embeddings the table dwarfs the products and every MFMA
+        # then accumulates at the table's ulp — measured 0.05 on the mask proposals of the config-3 fixture (queries x20)
 
         def self_attention_block(pp, src16, residual, norm_out32, norm_out16):
-            self._gemm("dec", src16, W_[pp + "sa_qkv_w"], qkv16, pos=tab(W_[pp + "sa_tab"]))    # q | k | v in ONE N = 3D GEMM
+            self._gemm("dec", src16, W_[pp + "sa_qkv_w"], qkv16, residual=W_[pp + "sa_tab"], res_rows=Q)   # q | k | v in ONE N = 3D GEMM
             ops.attention(qkv16, qkv16.view(qkv16.hi[:, D:]), qkv16.view(qkv16.hi[:, 2 * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=Q,
                           head_dim=dh, ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=Q * 3 * D, strideK=Q * 3 * D, strideV=Q * 3 * D,
                           strideO=Q * D, x3=xd)
@@ -329,7 +327,7 @@ class _EngineBase:
             else:
                 self_attention_block(pp, tgt16, tgt, tgt, tgt16)                            # transformer.py:272-278
                 tgt_in, tgt_in16 = tgt, tgt16
-            self._gemm("dec", tgt_in16, W_[pp + "ca_q_w"], qc16, pos=tab(W_[pp + "ca_q_tab"]))   # :281-282 query projection
+            self._gemm("dec", tgt_in16, W_[pp + "ca_q_w"], qc16, residual=W_[pp + "ca_q_tab"], res_rows=Q)   # :281-282 query projection
             ops.attention(qc16, KALL.view(KALL.hi[:, l * D:]), VALL.view(VALL.hi[:, l * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=M,
                           head_dim=dh, ldq=D, ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D,
                           strideO=Q * D, x3=xk)

@@ -121,8 +121,9 @@ def _pos(pos, N):
 def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, act: int = ACT_NONE, *, M=None, N=None, K=None,
             lda=None, ldw=None, ldc=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None,
             strideR: int = 0, pos=None):
-    """out = act((A @ W^T) * W.out_scale + bias + pos) + residual at the reference's fp32-class precision: A and W are split
-    pairs (Act with plane != 0); out is an f32 tensor, an fp16 tensor / plain Act, or a split Act.  pos: see _pos()."""
+    """out = act((A @ W^T) * W.out_scale + bias + pos) + residual[m % res_rows] at the reference's fp32-class precision: A and W
+    are split pairs (Act with plane != 0); out is an f32 tensor, an fp16 tensor / plain Act, or a split Act (then the residual is
+    added in fp32 before the one rounding, act must be none).  pos: see _pos()."""
     L = _lib.load()
     if not (isinstance(A, Act) and isinstance(W, Act) and A.plane and W.plane):
         raise _lib.ZutisHipError("gemm_x3: both operands must be split pairs")
@@ -136,7 +137,7 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
     kind = 0 if o.dtype == f32 else (2 if planeC else 1)
     ldc = o.stride(-2) if ldc is None else ldc
     if residual is not None:
-        assert residual.dtype == f32 and kind == 0
+        assert residual.dtype == f32 and (kind == 0 or act == ACT_NONE)
         ldr = residual.stride(-2) if ldr is None else ldr
         res_rows = res_rows or M
     if bias is not None:
