@@ -73,13 +73,23 @@ def test_c3_native_resolution_instance_predict(dev, golden_dir, H, W, precision,
         assert len(ref_cat) >= 5 and len(set(ref_cat.tolist())) >= 3          # the fixture exercises NMS (17 / 12 of 100 survive)
         print(f"c3 {tag}[{precision}] {nms}: {len(preds)} predictions (reference {len(ref_cat)})")
         if precision == "exact":
-            assert [p["category_id"] for p in preds] == list(ref_cat)         # same survivors, same emission order
+            assert [p["category_id"] for p in preds] == list(ref_cat)         # same survivors per category, same category order
             assert np.abs(np.array([p["score"] for p in preds]) - ref_score).max() < t_score
+            areas = [int(rle.decode(p["segmentation"]).sum()) for p in preds]
+            ref_area = g[f"{tag}_{key}area"]
+            # inside a category the greedy loop emits by descending (re-weighted) score; the 100 candidates' scores sit within
+            # 0.39 +- 0.01 of each other, so neighbours closer than the score tolerance may swap places: match one-to-one
+            # inside the category (area within t_area, score within 2 t_score) instead of by position
+            used = set()
             for j, p in enumerate(preds):
                 assert p["image_id"] == 7 and tuple(p["image_size"]) == (H, W)
-                assert abs(int(rle.decode(p["segmentation"]).sum()) - int(g[f"{tag}_{key}area"][j])) <= t_area
+                cand = [i for i in range(len(ref_cat)) if i not in used and ref_cat[i] == p["category_id"]
+                        and abs(areas[j] - int(ref_area[i])) <= t_area and abs(p["score"] - ref_score[i]) < 2 * t_score]
+                assert cand, (nms, j, p["category_id"], areas[j], p["score"])
+                i = min(cand, key=lambda i: abs(i - j))
+                used.add(i)
                 if nms == "hard":
-                    assert (rle.decode(p["segmentation"]).astype(bool) != ref_masks[j]).sum() <= t_area
+                    assert (rle.decode(p["segmentation"]).astype(bool) != ref_masks[i]).sum() <= t_area
         else:
             from collections import Counter
             diff = Counter(p["category_id"] for p in preds)

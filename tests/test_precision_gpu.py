@@ -118,6 +118,32 @@ def test_gemm_x3_pos_tables(dev, N):
     assert float((both.cpu().double() - ref).abs().max()) < tol
 
 
+@pytest.mark.parametrize("tile", [64, 192, 256, 448, 512])
+@pytest.mark.parametrize("hh,ww", [(12, 20), (52, 80)])
+def test_gemm_x3_pos_tables_every_tile(dev, tile, hh, ww):
+    """The pos tables under every x3 tile, on both table paths: the slice staged through the free ring slot (small images)
+    and straight from global memory (slices wider than the slot: 52 x 80 is the decoder memory of a 427 x 640 image)."""
+    from zutis_amd import ops, _lib
+    from zutis_amd.ops import Act
+    L = _lib.load(raw=True)
+    N, K, B = 520, 256, 2
+    M = B * hh * ww - 5
+    A, W = _randn((M, K), 41, 0.5), _randn((N, K), 42, 0.2)
+    bias, Ty, Tx = _randn((N,), 43), _randn((hh, N), 44), _randn((ww, N), 45)
+    m = torch.arange(M)
+    ref = A.double() @ W.double().t() + bias.double() + Ty.double()[(m % (hh * ww)) // ww] + Tx.double()[m % ww]
+    Ad, Wd = _split_act(A, dev), ops.split_weight(W.to(dev))
+    _lib.check(L.zh_dev_set_gemm_overrides(0, tile, 0), "zh_dev_set_gemm_overrides")
+    try:
+        osp = Act.empty((M, N), True, dev)
+        ops.gemm_x3(Ad, Wd, osp, bias=bias.to(dev), pos=(Ty.to(dev), Tx.to(dev)))
+        both = osp.t[0].float() + osp.t[1].float()
+        err = float((both.cpu().double() - ref).abs().max())
+        assert err < 1e-6 * max(1.0, float(ref.abs().max())), (tile, hh, ww, err)
+    finally:
+        L.zh_dev_set_gemm_overrides(0, 0, 0)
+
+
 def test_gemm_x3_batched_activation_operands(dev):
     """The mask einsum form (zutis.py:196-198): both operands are activations (split pairs, scale 1), batched."""
     from zutis_amd import ops

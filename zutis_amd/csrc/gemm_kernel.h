@@ -247,7 +247,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     typedef decltype(tag) T;                                    // float or half_t table elements
     typedef T T4 __attribute__((ext_vector_type(4)));
     const float isc = SPLIT ? 1.0f / p.out_scale : 1.0f;
-    constexpr int G = TM * TN > 16 ? (16 / TN > 0 ? 16 / TN : 1) : TM;    // rows of subtiles per batch: <= 32 loads in flight
+    // rows of subtiles per batch: the largest DIVISOR of TM with G * TN <= 16 (<= 32 loads in flight).  (16 / TN is not a
+    // divisor of TM = 6: the 192 x 256 tile then wrote accumulators 6 and 7 of 6 — found by test_gemm_x3_pos_tables_every_tile)
+    constexpr int G = TM * TN <= 16 ? TM : (TM % 4 == 0 && 4 * TN <= 16 ? 4 : (TM % 3 == 0 && 3 * TN <= 16 ? 3 : (TM % 2 == 0 && 2 * TN <= 16 ? 2 : 1)));
+    static_assert(TM % G == 0, "pos_direct_t: the batch height must divide TM");
 #pragma unroll
     for (int g = 0; g < TM; g += G) {
       T4 ry[G][TN], rx[G][TN];
