@@ -1,15 +1,27 @@
 """One shape of the flash-attention kernel, launched a few times: the target of the rocprofv3 --pmc passes
-(profiles/r02_attention_pmc.md)."""
+(profiles/r0N_attention_pmc*.json).  usage: attn_pmc_run.py enc|cross|selfmask [x3]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from zutis_amd import ops
+from zutis_amd.ops import Act
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "enc"
+x3 = len(sys.argv) > 2 and sys.argv[2] == "x3"
 B, H, dh, Tq, Tk = {"enc": (32, 12, 64, 442, 442), "cross": (32, 8, 96, 100, 1764), "selfmask": (1, 6, 64, 5505, 5505)}[which]
 D = H * dh
-q = torch.randn(B, Tq, D, device=dev).half(); k = torch.randn(B, Tk, D, device=dev).half(); v = torch.randn(B, Tk, D, device=dev).half()
-o = torch.empty(B, Tq, D, device=dev, dtype=torch.float16)
+
+
+def mk(T):
+    x = torch.randn(B * T, D, device=dev)
+    if not x3:
+        return x.half()
+    a = Act.empty((B * T, D), True, dev)
+    ops.cast_f16(x, a, B * T, D)
+    return a
+q, k, v = mk(Tq), mk(Tk), mk(Tk)
+o = Act.empty((B * Tq, D), x3, dev)
 for _ in range(10):
-    ops.attention(q, k, v, o, batch=B, heads=H, Tq=Tq, Tk=Tk, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=Tq * D, strideK=Tk * D, strideV=Tk * D, strideO=Tq * D)
+    ops.attention(q, k, v, o, batch=B, heads=H, Tq=Tq, Tk=Tk, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=Tq * D, strideK=Tk * D, strideV=Tk * D,
+                  strideO=Tq * D, x3=x3)
 torch.cuda.synchronize()

@@ -1,14 +1,15 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries and bench lines under profiles/ (run on the GPU box from the repo root, e.g.
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
 # then copy gpurun_out/<round>_* into profiles/).  One rocprofv3 --kernel-trace --stats pass per configuration; the PMC traffic
-# passes are the ones bench.py spawns itself (roofline.traffic of the default line).
-R=${1:-r02}
+# passes are the ones bench.py spawns itself (roofline.traffic of the default line).  The headline precision is `exact` (bench.py's
+# default); `fast` is profiled as the second precision.
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 mkdir -p gpurun_out
-Q="--no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision --steps 10 --warmup 3"
+Q="--no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision --no-io-rates --steps 10 --warmup 3"
 prof() {
   name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_$name -- python3 bench.py "$@" > gpurun_out/p_$name.log 2>&1
@@ -16,15 +17,15 @@ prof() {
   [ -n "$f" ] && cp "$f" gpurun_out/${R}_${name}_kernel_stats.csv
   rm -rf gpurun_out/p_$name
 }
-prof bench $Q --inflight 1
-prof bench_inflight $Q
-prof bench_exact $Q --inflight 1 --precision exact
+prof bench_exact $Q --inflight 1
+prof bench_exact_inflight $Q
+prof bench_fast $Q --inflight 1 --precision fast
 prof c4 $Q --workload c4
 prof c5 $Q --workload c5
 python3 bench.py 2> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench.json
 python3 bench.py --workload c4 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c4.json
 python3 bench.py --workload c5 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c5.json
-python3 bench.py --inflight 1 --no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_inflight1.json
+python3 bench.py --inflight 1 --no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision --no-io-rates 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_inflight1.json
 head -c 600 gpurun_out/${R}_bench.json; echo
 for f in gpurun_out/${R}_bench_c4.json gpurun_out/${R}_bench_c5.json gpurun_out/${R}_bench_inflight1.json; do python3 -c "
 import json,sys; d=json.load(open('$f')); print('$f', d['value'], d['unit'], d['ms_per_step'], d.get('roofline',{}) and d['roofline'].get('achieved'))"; done

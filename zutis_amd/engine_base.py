@@ -1,0 +1,346 @@
+"""ZUTIS forward/predict as a plan over libzutis_hip kernels (MI355X-native; no torch compute ops).
+
+Data layout in HBM (one GPU, B images, T = 1 + h*w encoder tokens, M = 4*h*w decoder memory tokens):
+  X        f32 [B*T, D]        residual stream (fp32 end to end)
+  Y16      f16 [B*T, D]        LayerNorm outputs (GEMM A operands are fp16, accumulate fp32)
+  QKV16    f16 [B*T, 3D]       packed q|k|v, consumed in place by flash attention (strided heads)
+  H16      f16 [B*T, 4D]       QuickGELU(c_fc) — never stored in fp32
+  TOK16    f16 [B*M, D]        x2-upsampled patch tokens (A operand of ffn1 and of the text-space projection)
+  F2X      f16 [B*M, 320]      ffn1's second hidden layer (256) | 1 | 0...: input of the composed K / V projections and the
+                               mask einsum's operand (decoder_input = ffn1's last Linear of it is never formed)
+  KALL/VALL f16 [B*M, L*D]     cross-attention K / V of all L decoder layers from ONE GEMM each (K = 256: ffn1's last Linear
+                               composed in at pack time; the sine-PE term enters as two small fp32 tables in the K epilogue)
+  weights  f16, packed once per parameter version ([N,K] row-major = torch Linear layout, K contiguous)
+
+Precision (DESIGN.md "Precision"): the reference computes in fp32 end to end.  Every contraction here is a *site* with a
+mode: "f16" = fp16 MFMA operands, fp32 accumulate; "x3" = the reference-equivalent mode — operands carried as fp16 split
+pairs (hi + lo, 22 bits) and three MFMA products per accumulator (zh_gemm_f16x3, split-pair scores in flash attention).
+`precision=` picks the map: "exact" = x3 everywhere; "fast" (default) = x3 on the contractions whose rounding reaches an
+output directly (ffn1, ffn2, mask einsum, text-space projection, class logits) and f16 in the transformer bodies, which
+tests/test_precision_gpu.py holds to the north-star tolerance on the outlier-channel stress model; "f16" = no x3 at all.
+
+Reference call sites are cited per step (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, compose, ops
+from ._lib import ZutisHipError
+
+from .ops import Act
+
+
+def P_shape0(w) -> int:
+    """Rows (= output features) of a packed weight, plain fp16 tensor or split pair."""
+    return (w.hi if isinstance(w, Act) else w).shape[0]
+
+f16, f32 = torch.float16, torch.float32
+
+# contraction sites (see the module docstring)
+ENCODER_SITES = ("conv", "qkv", "attn", "out", "fc", "proj")
+DECODER_SITES = ("dec_kv", "dec")
+HEAD_SITES = ("ffn1", "ffn2", "mask", "textproj", "logits", "embed")
+ALL_SITES = ENCODER_SITES + DECODER_SITES + HEAD_SITES
+PRECISIONS = {
+    "f16": frozenset(),
+    "fast": frozenset(HEAD_SITES),
+    "exact": frozenset(ALL_SITES),
+}
+
+
+def resolve_precision(precision) -> frozenset:
+    """"f16" | "fast" | "exact" | an iterable of site names -> the set of sites computed in the x3 mode."""
+    if isinstance(precision, str):
+        if precision not in PRECISIONS:
+            raise ZutisHipError(f"precision {precision!r} not in {sorted(PRECISIONS)}")
+        return PRECISIONS[precision]
+    sites = set(precision)
+    bad = sites - set(ALL_SITES)
+    if bad:
+        raise ZutisHipError(f"unknown precision sites {sorted(bad)} (known: {ALL_SITES})")
+    # a split-pair consumer needs the producer of its operand to write lo planes, and a buffer allocated as a pair must be
+    # filled as one: close the set under those requirements (each rule: consumer site => the x3 GEMM that produces its operand)
+    if "attn" in sites:
+        sites.add("qkv")                      # Q / K / V lo planes come from the x3 QKV projection
+    if "proj" in sites:
+        sites.add("fc")                       # H16 (QuickGELU(c_fc)) is c_proj's operand: its lo plane comes from the x3 c_fc
+    if sites & {"mask", "dec_kv"}:
+        sites.add("ffn1")                     # their operand (ffn1's hidden layer, F2X) gets its lo plane from the x3 ffn1
+    if "dec" in sites and "dec_kv" in sites:
+        sites.add("ffn1")
+    return frozenset(sites)
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class _EngineBase:
+    """Shared plumbing: fp16 weight packing keyed on parameter versions, shape-keyed buffer cache, and the two
+    kernel sequences both networks share — pre-LN ViT blocks and the post-norm DETR-style decoder."""
+
+    params: Dict[str, torch.Tensor]
+
+    def _init_base(self, precision="exact"):
+        self.x3_sites = resolve_precision(precision)
+        self.precision = precision if isinstance(precision, str) else "custom"
+        self._packed_key = None
+        self._w: Dict[str, torch.Tensor] = {}
+        self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._buf_gen = 0             # bumped on every (re)allocation: launch plans check it
+        self._buf_const: Dict[str, torch.Tensor] = {}   # buffers with constant regions: name -> the tensor that was initialised
+        self._pt16_of = self._text16_of = None   # which tensors the cached f16 copies "pt16" / "text16" were made from
+
+    def fork(self):
+        """A second engine over the SAME parameters and packed weights with its own activation buffers: one per HIP stream
+        when independent inputs are processed concurrently (buffers are the only mutable state of an engine)."""
+        import copy
+        self._pack()
+        e = copy.copy(self)
+        e._bufs, e._buf_gen, e._buf_const = {}, 0, {}
+        # input-independent tables are shared; captured graphs are not (they replay into the parent's buffers and stream)
+        e._geo = {k: v for k, v in self._geo.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
+        e._pt16_of = e._text16_of = None       # provenance of the f16 copies held in the (new, empty) buffer cache
+        return e
+
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.params.values())
+
+    def _device(self):
+        dev = next(iter(self.params.values())).device
+        if dev.type != "cuda":
+            raise ZutisHipError("engine parameters must live on a GPU (no CPU fallback)")
+        return dev
+
+    _GEO_CAP = 64     # per-(h,w) tables (pos-embed, sine PE, graphs): native-resolution eval sees many shapes; keep the newest
+
+    def _geo_put(self, key, value):
+        if len(self._geo) >= self._GEO_CAP:
+            self._geo.pop(next(iter(self._geo)))
+        self._geo[key] = value
+
+    def _buf(self, name: str, shape, dtype) -> torch.Tensor:
+        k = (name, tuple(shape), dtype)
+        b = self._bufs.get(k)
+        if b is None:
+            for kk in [kk for kk in self._bufs if kk[0] == name]:
+                del self._bufs[kk]
+            b = torch.empty(shape, dtype=dtype, device=self._device())
+            self._bufs[k] = b
+            self._buf_gen += 1
+        return b
+
+    def _x3(self, *sites) -> bool:
+        return any(s in self.x3_sites for s in sites)
+
+    def _abuf(self, name: str, shape, split: bool) -> Act:
+        """Cached fp16 activation buffer, a split pair when a consumer runs in the x3 mode."""
+        return Act(self._buf(name, ((2 if split else 1),) + tuple(shape), f16))
+
+    @staticmethod
+    def _h(t):
+        return t.detach().to(f16).contiguous()
+
+    def _hw(self, t, site) -> "torch.Tensor | Act":
+        """A [N,K] weight packed for its site: plain fp16, or a scaled split pair for the x3 mode."""
+        return ops.split_weight(t.detach().contiguous()) if self._x3(site) else self._h(t)
+
+    def _gemm(self, site, A, W, out, **kw):
+        """One contraction at its site's precision.  x3: A and W must be split pairs (the producers were told so)."""
+        if self._x3(site):
+            return ops.gemm_x3(A, W, out, **kw)
+        return ops.gemm(A, W, out, **kw)
+
+    @staticmethod
+    def _c32(t):
+        return t.detach().to(f32).contiguous()
+
+    def _pack_decoder(self, w, P, D, n_layers, memory_linear=None):
+        """decoder.layers.{i}.* (transformer.py:231-251) -> dec.{i}.*; the cross-attention K / V weights of all layers
+        are concatenated so the memory tokens are projected by ONE GEMM each.
+
+        memory_linear = (W2 [D, F], b2 [D]): the memory is itself the output of a Linear layer, memory = f @ W2^T + b2
+        (ZUTIS: the last layer of ffn1, zutis.py:500-503).  The two projections are then composed at pack time (fp64 products,
+        rounded to fp32 once) so they contract over F instead of D:
+            K_all = (memory + pos) @ Wk^T + bk = f @ (Wk W2)^T + (Wk b2 + bk) + pos @ Wk^T
+            V_all =  memory        @ Wv^T + bv = f @ (Wv W2)^T + (Wv b2 + bv)
+        and "ca_k_pos_w" keeps Wk in fp32 for the per-geometry `pos @ Wk^T` tables (ZutisEngine._geometry)."""
+        c32 = self._c32
+        h = lambda t: self._hw(t, "dec")
+        kw, kb, vw, vb = [], [], [], []
+        qpos = P["query_embed"].detach()
+        for i in range(n_layers):
+            p, q = f"decoder.layers.{i}.", f"dec.{i}."
+            sw, sb = P[p + "self_attn.in_proj_weight"].detach(), P[p + "self_attn.in_proj_bias"].detach()
+            cw, cb = P[p + "multihead_attn.in_proj_weight"].detach(), P[p + "multihead_attn.in_proj_bias"].detach()
+            # q = k = tgt + query_pos, v = tgt (transformer.py:272-275) and the cross-attention query tgt + query_pos (:281-282):
+            # every projection runs on tgt alone — ONE N = 3D GEMM for the self-attention's q | k | v — and starts from a
+            # per-query row table that carries query_pos @ W^T + b (compose.query_pos_tables; fp64 products, stored fp32)
+            w[q + "sa_qkv_w"] = h(sw)
+            w[q + "sa_tab"], w[q + "ca_q_tab"] = compose.query_pos_tables(qpos, sw, sb, cw[:D], cb[:D])
+            w[q + "sa_o_w"], w[q + "sa_o_b"] = h(P[p + "self_attn.out_proj.weight"]), c32(P[p + "self_attn.out_proj.bias"])
+            w[q + "ca_q_w"] = h(cw[:D])
+            kw.append(cw[D:2 * D]); kb.append(cb[D:2 * D]); vw.append(cw[2 * D:]); vb.append(cb[2 * D:])
+            w[q + "ca_o_w"], w[q + "ca_o_b"] = h(P[p + "multihead_attn.out_proj.weight"]), c32(P[p + "multihead_attn.out_proj.bias"])
+            w[q + "l1_w"], w[q + "l1_b"] = h(P[p + "linear1.weight"]), c32(P[p + "linear1.bias"])
+            w[q + "l2_w"], w[q + "l2_b"] = h(P[p + "linear2.weight"]), c32(P[p + "linear2.bias"])
+            for n in ("norm1", "norm2", "norm3"):
+                w[q + n + ".w"], w[q + n + ".b"] = c32(P[p + n + ".weight"]), c32(P[p + n + ".bias"])
+        kw, kb, vw, vb = (torch.cat(t, 0).detach() for t in (kw, kb, vw, vb))                        # [L*D, D], [L*D]
+        if memory_linear is not None:
+            w["ca_k_pos_w"] = c32(kw)
+            kw, kb, vw, vb = compose.compose_memory_linear(kw, kb, vw, vb, *memory_linear)           # [L*D, F]
+        w["ca_k_w"], w["ca_k_b"] = self._hw(kw.to(f32), "dec_kv"), c32(kb)
+        w["ca_v_w"], w["ca_v_b"] = self._hw(vw.to(f32), "dec_kv"), c32(vb)
+        w["dec.norm.w"], w["dec.norm.b"] = c32(P["decoder.norm.weight"]), c32(P["decoder.norm.bias"])
+
+    def _pack_clip_visual(self, w, P, prefix: str, D: int, layers: int, patch: int):
+        """CLIP VisionTransformer parameters (clip_arch.py:335-354) -> conv (K padded to 64), enc.{i}.*, ln_pre/ln_post."""
+        c32 = self._c32
+        kc = 3 * patch * patch
+        self.Kc = _rup(kc, 64)
+        wc = torch.zeros((D, self.Kc), dtype=f32, device=self._device())
+        wc[:, :kc] = P[prefix + "conv1.weight"].detach().reshape(D, kc)
+        w["conv"] = self._hw(wc, "conv")
+        for name in ("class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias", "ln_post.weight", "ln_post.bias"):
+            w["encoder." + name] = c32(P[prefix + name])
+        self._pack_resblocks(w, P, prefix, layers)
+        w["projT"] = self._hw(P[prefix + "proj"].detach().t(), self._proj_site)        # [E, D]
+
+    _proj_site = "textproj"      # the site of the visual projection: text-space tokens (ZUTIS) / the CLS embedding (encode_image)
+
+    def _pack_resblocks(self, w, P, prefix: str, layers: int):
+        """{prefix}transformer.resblocks.{i}.* (ResidualAttentionBlock, clip_arch.py:300-321) -> enc.{i}.*"""
+        hw, c32 = self._hw, self._c32
+        for i in range(layers):
+            p, q = f"{prefix}transformer.resblocks.{i}.", f"enc.{i}."
+            w[q + "qkv_w"], w[q + "qkv_b"] = hw(P[p + "attn.in_proj_weight"], "qkv"), c32(P[p + "attn.in_proj_bias"])
+            w[q + "out_w"], w[q + "out_b"] = hw(P[p + "attn.out_proj.weight"], "out"), c32(P[p + "attn.out_proj.bias"])
+            w[q + "fc_w"], w[q + "fc_b"] = hw(P[p + "mlp.c_fc.weight"], "fc"), c32(P[p + "mlp.c_fc.bias"])
+            w[q + "proj_w"], w[q + "proj_b"] = hw(P[p + "mlp.c_proj.weight"], "proj"), c32(P[p + "mlp.c_proj.bias"])
+            for ln, ln2 in (("ln_1", "ln1"), ("ln_2", "ln2")):
+                w[q + ln2 + ".w"], w[q + ln2 + ".b"] = c32(P[p + ln + ".weight"]), c32(P[p + ln + ".bias"])
+
+    def _clip_trunk(self, x: torch.Tensor, pos: torch.Tensor, h: int, w: int):
+        """conv1-as-GEMM, cls concat + pos + ln_pre, all resblocks (clip_arch.py:378-401).  Returns X f32 [B*T, D]."""
+        W_, D, p = self._w, self.D, self.patch
+        B = x.shape[0]
+        T, R = 1 + h * w, B * (1 + h * w)
+        col = self._abuf("col", (B * h * w, self.Kc), self._x3("conv"))
+        ops.im2col(x, col, p, self.Kc)                                                   # :378 conv1 as GEMM
+        pe32 = self._buf("patch_emb", (B * h * w, D), f32)
+        self._gemm("conv", col, W_["conv"], pe32)
+        X = self._buf("X", (R, D), f32)
+        ops.assemble_tokens_ln(pe32, W_["encoder.class_embedding"], pos, W_["encoder.ln_pre.weight"],
+                               W_["encoder.ln_pre.bias"], 1e-5, X, B, T, D)                # :384-397
+        self._vit_blocks(X, B, T, D, self.heads, self.layers, 1e-5, ops.ACT_QUICKGELU)     # :318-321
+        return X
+
+    def _vit_blocks(self, X, B, T, D, heads, n_layers, eps, act, causal=False):
+        """Pre-LN transformer blocks on the fp32 residual stream X [B*T, D] (in place).
+        clip_arch.py:318-321 (QuickGELU, eps 1e-5) and selfmask/vision_transformer.py:160-170 (erf GELU, eps 1e-6)."""
+        W_, R = self._w, B * T
+        Fd = P_shape0(W_["enc.0.fc_w"])
+        Y = self._abuf("Y16", (R, D), self._x3("qkv", "fc"))
+        xa = self._x3("attn")                              # split-pair scores: lo planes written by the x3 QKV GEMM
+        QKV = self._abuf("QKV16", (R, 3 * D), xa)
+        O = self._abuf("O16", (R, D), self._x3("out"))
+        Hh = self._abuf("H16", (R, Fd), self._x3("proj"))
+        q_, k_, v_ = QKV, QKV.view(QKV.hi[:, D:]), QKV.view(QKV.hi[:, 2 * D:])
+        for i in range(n_layers):
+            pp = f"enc.{i}."
+            ops.layernorm(X, W_[pp + "ln1.w"], W_[pp + "ln1.b"], eps, R, D, out_f16=Y)
+            self._gemm("qkv", Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
+            ops.attention(q_, k_, v_, O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=D // heads,
+                          ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
+                          strideO=T * D, causal=causal, x3=xa)
+            self._gemm("out", O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
+            ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y)
+            self._gemm("fc", Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
+            self._gemm("proj", Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
+
+    def _decoder_kv(self, VIN16, KIN16, B, M, D, L, k_pos=None):
+        """Cross-attention K / V of all L layers (transformer.py:281-284) from ONE GEMM each: [B*M, L*D] fp16 (split pairs
+        when both the projection and the decoder run x3).  VIN16 / KIN16 are the value / key inputs in the layout the packed
+        "ca_v_w" / "ca_k_w" contract over; k_pos = (Ty [h2, L*D], Tx [w2, L*D]): fp32 tables, K row m = y * w2 + x starts
+        from Ty[y] + Tx[x] (the `pos` term of `memory + pos` when the projections were composed at pack time)."""
+        W_ = self._w
+        xk = self._x3("dec") and self._x3("dec_kv")                                        # K lo planes feed the x3 scores
+        KALL = self._abuf("KALL", (B * M, L * D), xk)
+        VALL = self._abuf("VALL", (B * M, L * D), xk)
+        self._gemm("dec_kv", KIN16, W_["ca_k_w"], KALL, bias=W_["ca_k_b"], pos=k_pos)
+        self._gemm("dec_kv", VIN16, W_["ca_v_w"], VALL, bias=W_["ca_v_b"])
+        return KALL, VALL
+
+    def _decoder(self, KALL, VALL, B, M, D, Q, L, heads, stack_all: bool):
+        """transformer.py:114-152 over :262-291 (post-norm), tgt = zeros, query_pos = query_embed, on the projected memory
+        of _decoder_kv.  Returns f16 rows with decoder.norm applied: every layer stacked as [B,L,Q,D] (stack_all) or the last
+        layer only [B*Q, D]; the fp32 copy of the last layer's normed output is left in buffer "dec_out32"."""
+        W_, dh, R = self._w, D // heads, B * Q
+        xd = self._x3("dec")
+        Ff = P_shape0(W_["dec.0.l1_w"])
+        xk = bool(KALL.plane)
+        tgt = self._buf("tgt", (R, D), f32)
+        t1 = self._buf("t1", (R, D), f32)
+        tgt16 = self._abuf("tgt16", (R, D), xd)
+        qkv16 = self._abuf("dqkv16", (R, 3 * D), xd)
+        qc16 = self._abuf("qc16", (R, D), xd)
+        o16 = self._abuf("do16", (R, D), xd)
+        ff16 = self._abuf("ff16", (R, Ff), xd)
+        inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
+        out32 = self._buf("dec_out32", (R, D), f32)
+        # `tgt + query_pos` never exists: the row tables of _pack_decoder enter the GEMMs as a row-periodic residual (row m gets
+        # table[m % Q], added in fp32 to the finished accumulator, before the one rounding to fp16 / a split pair).  NOT as an
+        # accumulator start value (the `pos` form): with large query embeddings the table dwarfs the products and every MFMA
+        # then accumulates at the table's ulp — measured 0.05 on the mask proposals of the config-3 fixture (queries x20)
+
+        def self_attention_block(pp, src16, residual, norm_out32, norm_out16):
+            self._gemm("dec", src16, W_[pp + "sa_qkv_w"], qkv16, residual=W_[pp + "sa_tab"], res_rows=Q)   # q | k | v in ONE N = 3D GEMM
+            ops.attention(qkv16, qkv16.view(qkv16.hi[:, D:]), qkv16.view(qkv16.hi[:, 2 * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=Q,
+                          head_dim=dh, ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=Q * 3 * D, strideK=Q * 3 * D, strideV=Q * 3 * D,
+                          strideO=Q * D, x3=xd)
+            self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=residual)
+            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=norm_out32, out_f16=norm_out16)
+        # tgt = zeros (zutis.py:164) and query_pos is a parameter, so layer 0's whole self-attention block — projections of
+        # (0 + query_pos, 0), attention over the Q queries, out-projection, norm1 — does not depend on the image: its result
+        # (tgt after norm1, fp32 and fp16; [R, D] = the same Q rows for every image) is computed once per (batch rows, parameter
+        # version) with the same kernels and cached; layer 0 then starts at the cross-attention.
+        ikey = ("dec_init", R, self._packed_key)
+        init = self._geo.get(ikey)
+        if init is None:
+            dev = self._device()
+            z16 = Act(torch.zeros((2 if xd else 1, R, D), dtype=f16, device=dev))
+            init = {"tgt0": torch.empty((R, D), dtype=f32, device=dev), "tgt0_16": Act.empty((R, D), xd, dev)}
+            self_attention_block("dec.0.", z16, None, init["tgt0"], init["tgt0_16"])      # q = k = query_pos, v = 0, + tgt (= 0)
+            self._geo_put(ikey, init)
+        for l in range(L):
+            pp = f"dec.{l}."
+            if l == 0:
+                tgt_in, tgt_in16 = init["tgt0"], init["tgt0_16"]
+            else:
+                self_attention_block(pp, tgt16, tgt, tgt, tgt16)                            # transformer.py:272-278
+                tgt_in, tgt_in16 = tgt, tgt16
+            self._gemm("dec", tgt_in16, W_[pp + "ca_q_w"], qc16, residual=W_[pp + "ca_q_tab"], res_rows=Q)   # :281-282 query projection
+            ops.attention(qc16, KALL.view(KALL.hi[:, l * D:]), VALL.view(VALL.hi[:, l * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=M,
+                          head_dim=dh, ldq=D, ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D,
+                          strideO=Q * D, x3=xk)
+            self._gemm("dec", o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt_in)
+            ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
+            self._gemm("dec", tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
+            self._gemm("dec", ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
+            ops.layernorm(t1, W_[pp + "norm3.w"], W_[pp + "norm3.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
+            if stack_all:                                                                   # :140-150, stacked [B,L,Q,D]
+                ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16,
+                              out_group_rows=Q, out_group_stride=L * Q, out_offset=l * Q)
+            elif l == L - 1:
+                ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16, out_f32=out32)
+        return inter16
+
+    _dec_out_sites = ("ffn2",)   # sites consuming the decoder's normed outputs (ZUTIS: ffn2; SelfMask: mask einsum + objectness MLP)
