@@ -19,6 +19,7 @@
 // Batching: every kernel takes blockIdx.y = image; the B images of a call (same H x W) have their own workspace slices, so
 // the ~110 launches of a solve — launch/latency-bound for one image — are shared by the whole batch.
 #include "common.h"
+#include <stdlib.h>
 
 typedef unsigned long long u64;
 
@@ -413,30 +414,26 @@ __global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c0, BgBatch bt) {  
   const double bb = sum_partials(c.part_pq, cg_active_blocks(c), red);
   if (threadIdx.x == 0) { c.sc[2] = c.rtol * sqrt(bb); c.sc[3] = 0.0; c.sc[4] = 0.0; }
 }
-__global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c0, int it, BgBatch bt) {
-  __shared__ double red[4];
-  const CgPtrs c = cg_img(c0, bt);
-  const int nb = cg_active_blocks(c);
-  if ((int)blockIdx.x >= nb) return;
-  // every block re-derives the convergence decision from the same partials (deterministic) -> no intra-kernel flag race;
-  // once converged the partials are frozen, so the decision repeats for all later iterations
-  const double rho = sum_partials(c.part_rz, nb, red);
+// The three phases of one PCG iteration as device functions: the per-phase kernels below and the persistent kernel run the SAME
+// code in the same order, so both paths give bitwise the same iterates.
+// phase 1: convergence test at the top of iteration `it` (every block re-derives it from the same partials: deterministic, no flag
+// race), then p = z + beta p.  Returns false when converged (||r|| < atol).
+__device__ __forceinline__ bool cg_phase_p(const CgPtrs& c, int it, int nb, double rho_prev, double& rho, double* red) {
+  rho = sum_partials(c.part_rz, nb, red);
   const double rr = sum_partials(c.part_rr, nb, red);
-  if (sqrt(rr) < c.sc[2]) {                                               // ||r|| < atol at the top of iteration `it`
+  if (sqrt(rr) < c.sc[2]) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && c.sc[3] == 0.0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
-    return;
+    return false;
   }
-  const double beta = it == 0 ? 0.0 : rho / c.sc[(it - 1) & 1];
+  const double beta = it == 0 ? 0.0 : rho / rho_prev;
   FOR_VERTEX_BLOCKS(vb, c.nv) {
     const int v = vb * 256 + threadIdx.x;
     if (v < *c.nv) c.p[v] = it == 0 ? c.z[v] : c.z[v] + beta * c.p[v];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;
+  return true;
 }
-__global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c0, BgBatch bt) {
-  __shared__ double red[4];
-  const CgPtrs c = cg_img(c0, bt);
-  if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
+// phase 2: q = A p, per-block partials of p.q
+__device__ __forceinline__ void cg_phase_q(const CgPtrs& c, double* red) {
   FOR_VERTEX_BLOCKS(vb, c.nv) {
     const int v = vb * 256 + threadIdx.x;
     double pq = 0.0;
@@ -445,14 +442,10 @@ __global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c0, BgBatch bt) {
     if (threadIdx.x == 0) c.part_pq[vb] = s;
   }
 }
-__global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBatch bt) {
-  __shared__ double red[4];
-  const CgPtrs c = cg_img(c0, bt);
-  const int nb = cg_active_blocks(c);
-  if ((int)blockIdx.x >= nb) return;
-  if (c.sc[3] != 0.0) return;
+// phase 3: x += alpha p, r -= alpha q, z = M^-1 r, per-block partials of r.z and r.r
+__device__ __forceinline__ void cg_phase_x(const CgPtrs& c, int nb, double rho, double* red) {
   const double pq = sum_partials(c.part_pq, nb, red);
-  const double alpha = c.sc[it & 1] / pq;
+  const double alpha = rho / pq;
   FOR_VERTEX_BLOCKS(vb, c.nv) {
     const int v = vb * 256 + threadIdx.x;
     double rz = 0.0, rr = 0.0;
@@ -468,12 +461,85 @@ __global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBat
     if (threadIdx.x == 0) { c.part_rz[vb] = s1; c.part_rr[vb] = s2; }
   }
 }
+
+__global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c0, int it, BgBatch bt) {
+  __shared__ double red[4];
+  const CgPtrs c = cg_img(c0, bt);
+  const int nb = cg_active_blocks(c);
+  if ((int)blockIdx.x >= nb) return;
+  double rho;
+  if (!cg_phase_p(c, it, nb, it == 0 ? 1.0 : c.sc[(it - 1) & 1], rho, red)) return;   // once converged the partials are frozen: the
+  if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;                          // decision repeats for all later iterations
+}
+__global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c0, BgBatch bt) {
+  __shared__ double red[4];
+  const CgPtrs c = cg_img(c0, bt);
+  if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
+  cg_phase_q(c, red);
+}
+__global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBatch bt) {
+  __shared__ double red[4];
+  const CgPtrs c = cg_img(c0, bt);
+  const int nb = cg_active_blocks(c);
+  if ((int)blockIdx.x >= nb) return;
+  if (c.sc[3] != 0.0) return;
+  cg_phase_x(c, nb, c.sc[it & 1], red);
+}
+
+// ---- persistent PCG: ALL iterations of a batch in ONE launch (the per-phase form is 3 launches per iteration = 75 per solve at
+// the dispatch floor of 5-8 us each: 57 % of a batched solve, profiles/r02_bilateral_b8_kernel_stats.csv).  The blocks of one
+// image (gridDim.x of them; blockIdx.y = image) meet at an image-local barrier between the phases: a monotonic counter in global
+// memory, one agent-scope release add + acquire poll by thread 0 of every block (the same scheme as cooperative-groups grid sync;
+// the fences carry the L1 / cross-XCD L2 maintenance the hand-off of p, q and the partials needs).  The host sizes the grid to at
+// most ONE block per CU in total, so every block is resident even with several solves in flight on other streams (the pseudo-label
+// pipeline) and a barrier can always complete; the poll is nevertheless BOUNDED: on expiry the block raises `*err` and leaves.
+#define CG_SPIN_LIMIT (1 << 21)      // x (s_sleep + one L2 atomic) ~ seconds: far beyond any legitimate wait
+__device__ __forceinline__ bool img_barrier(unsigned* cnt, unsigned& epoch, int* err) {
+  __syncthreads();
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    epoch += 1;
+    const unsigned target = epoch * gridDim.x;
+    __threadfence();
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int good = 1;
+    for (int spins = 0; __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+      if (spins > CG_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { good = 0; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!good) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    ok = good;
+  }
+  __syncthreads();
+  return ok != 0;
+}
+__global__ __launch_bounds__(256) void cg_persistent_kernel(CgPtrs c0, int maxiter, unsigned* bar, int* err, BgBatch bt) {
+  __shared__ double red[4];
+  const CgPtrs c = cg_img(c0, bt);
+  unsigned* cnt = ws_img(bar, bt);                                         // a line of the image's own scalar block (zeroed per call)
+  unsigned epoch = 0;
+  const int nb = cg_active_blocks(c);
+  double rho_prev = 1.0;
+  for (int it = 0; it < maxiter; ++it) {
+    double rho;
+    if (!cg_phase_p(c, it, nb, rho_prev, rho, red)) break;                 // every block of the image takes the same decision
+    if (!img_barrier(cnt, epoch, err)) return;                             // p complete before any neighbour gathers it
+    cg_phase_q(c, red);
+    if (!img_barrier(cnt, epoch, err)) return;                             // all p.q partials written
+    cg_phase_x(c, nb, rho, red);
+    if (!img_barrier(cnt, epoch, err)) return;                             // all r.z / r.r partials written
+    rho_prev = rho;
+  }
+}
+
 __global__ void cg_finish_kernel(CgPtrs c0, int maxiter, int* stats, const double* n_src, const double* m_src, double* n_out, double* m_out,
-                                 BgBatch bt) {
+                                 const int* err, BgBatch bt) {
   const CgPtrs c = cg_img(c0, bt);
   if (threadIdx.x == 0) {
     if (c.sc[3] == 0.0) c.sc[4] = (double)maxiter;
-    if (stats) { stats[2 * blockIdx.y] = *c.nv; stats[2 * blockIdx.y + 1] = (int)c.sc[4]; }
+    // err != 0: a barrier of the persistent PCG kernel timed out — the iterates are unfinished: iterations = -1 (callers raise)
+    if (stats) { stats[2 * blockIdx.y] = *c.nv; stats[2 * blockIdx.y + 1] = (err && *err) ? -1 : (int)c.sc[4]; }
   }
   if (n_out || m_out) {                                                       // debug copies of the bistochastisation vectors
     n_src = ws_img(n_src, bt); m_src = ws_img(m_src, bt);
@@ -550,6 +616,33 @@ extern "C" int zh_bgrid_coords(const unsigned char* rgb, int H, int W, double si
 // [B,H,W] (target_f64), exactly one non-NULL; out_soft f64 [B,H,W].  stats (device, may be NULL): int32 [B,2] = {nvertices,
 // cg iterations}.  Optional debug outputs (device, may be NULL): n_out / m_out f64 [B, H*W] (first nvertices entries of
 // each row).  workspace: B * zh_bilateral_workspace_size(H, W, ...) bytes.
+// Blocks per image of the persistent PCG kernel: the whole batch gets at most ONE block per CU (so that, with up to 8 solves in
+// flight on other streams, every block is still resident and the image barriers cannot starve); 0 = use the per-phase launches.
+// ZH_BILATERAL_PERSISTENT=0 (read once) or zh_dev_set_bilateral_persistent(0) forces the per-phase form (A/B, tests).
+static int& bg_persistent_mode() {
+  static int mode = [] { const char* e = getenv("ZH_BILATERAL_PERSISTENT"); return e ? atoi(e) : 1; }();
+  return mode;
+}
+extern "C" int zh_dev_set_bilateral_persistent(int on) { bg_persistent_mode() = on ? 1 : 0; return ZH_OK; }
+static int bg_persistent_blocks(int B, int nblocks) {
+  const int mode = bg_persistent_mode();
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  if (!mode || cus <= 0 || B > cus) return 0;
+  const int g = cus / B;
+  return g < nblocks ? g : nblocks;
+}
+__global__ __launch_bounds__(256) void bg_zero_kernel(u64* a, long na, u64* b, long nb, u64* c, long nc, BgBatch bt) {
+  a = ws_img(a, bt); b = ws_img(b, bt); c = ws_img(c, bt);
+  const long stride = (long)gridDim.x * 256, i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  for (long i = i0; i < na; i += stride) a[i] = 0;
+  for (long i = i0; i < nb; i += stride) b[i] = 0;
+  for (long i = i0; i < nc; i += stride) c[i] = 0;
+}
+
 extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned char* target_u8, const double* target_f64, int B, int H,
                                         int W, double sigma_spatial, double sigma_luma, double sigma_chroma, double confidence,
                                         double lam, double a_diag_min, double cg_tol, int cg_maxiter, double* out_soft, int* stats,
@@ -586,13 +679,11 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
   double* sc = (double*)(ws + L.sc);
   int* nv = (int*)(ws + L.nv);
 
-  for (int b = 0; b < B; ++b) {                                                  // bitmaps, integer splats, scalars
-    char* wb = ws + (size_t)b * L.total;
-    (void)hipMemsetAsync(wb + L.bitmap, 0, (size_t)L.nwords * 8, stream);
-    (void)hipMemsetAsync(wb + L.ints, 0, 2 * istride + 256, stream);
-    (void)hipMemsetAsync(wb + L.sc, 0, 256, stream);
-  }
   const dim3 blk(256), gN(zh_cdiv(N, 256), B), gV(L.nblocks < VGRID ? L.nblocks : VGRID, B), g1(1, B);
+  // bitmaps, integer splats, scalars (+ the barrier counter / error flag of the persistent PCG): ONE launch for the whole batch
+  // (it was three hipMemsetAsync per image: 120 fill kernels per 5 batched calls, 7.5 % of the GPU time in the round-2 profile)
+  hipLaunchKernelGGL(bg_zero_kernel, dim3(64, B), blk, 0, stream, (u64*)(ws + L.bitmap), L.nwords, (u64*)(ws + L.ints), (long)((2 * istride + 256) / 8),
+                     (u64*)(ws + L.sc), 32L, bt);
   hipLaunchKernelGGL(bg_cells_kernel, gN, blk, 0, stream, rgb, H, W, sigma_spatial, sigma_luma, sigma_chroma, d, cell, bitmap, (int*)nullptr, bt);
   hipLaunchKernelGGL(bg_scan_block_sums, dim3(L.nscan, B), blk, 0, stream, bitmap, L.nwords, blocksum, bt);
   hipLaunchKernelGGL(bg_scan_top, g1, blk, 0, stream, blocksum, L.nscan, nv, bt);
@@ -619,13 +710,20 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
   hipLaunchKernelGGL(cg_y0_kernel, gV, blk, 0, stream, c, bt);
   hipLaunchKernelGGL(cg_init_kernel, gV, blk, 0, stream, c, bt);
   hipLaunchKernelGGL(cg_atol_kernel, g1, blk, 0, stream, c, bt);
-  for (int it = 0; it < cg_maxiter; ++it) {
-    hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it, bt);
-    hipLaunchKernelGGL(cg_matvec_kernel, gV, blk, 0, stream, c, bt);
-    hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it, bt);
+  // all iterations in ONE launch when the batch fits one block per CU in total (see cg_persistent_kernel); else 3 launches per iteration
+  int* err = (int*)(ws + L.sc + 192);                                            // image 0's scalar line: one flag for the batch
+  const int per_image = bg_persistent_blocks(B, L.nblocks);
+  if (per_image > 0 && cg_maxiter > 0) {
+    hipLaunchKernelGGL(cg_persistent_kernel, dim3(per_image, B), blk, 0, stream, c, cg_maxiter, (unsigned*)(ws + L.sc + 128), err, bt);
+  } else {
+    for (int it = 0; it < cg_maxiter; ++it) {
+      hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it, bt);
+      hipLaunchKernelGGL(cg_matvec_kernel, gV, blk, 0, stream, c, bt);
+      hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it, bt);
+    }
   }
   hipLaunchKernelGGL(bg_slice_kernel, gN, blk, 0, stream, c.x, pix2v, N, out_soft, bt);
-  hipLaunchKernelGGL(cg_finish_kernel, g1, blk, 0, stream, c, cg_maxiter, stats, ncur, m, n_out, m_out, bt);
+  hipLaunchKernelGGL(cg_finish_kernel, g1, blk, 0, stream, c, cg_maxiter, stats, ncur, m, n_out, m_out, err, bt);
   ZH_CHECK_LAUNCH("zh_bilateral_solve");
   return ZH_OK;
 }
