@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void bg_assign_kernel(const int* cell, const u
 // a typical image fills ~6 % of them — the idle blocks were most of the dispatch cost of every launch.
 #define VGRID 192
 #define FOR_VERTEX_BLOCKS(vb, nvp) for (int vb = blockIdx.x, vb##_n = (*(nvp) + 255) >> 8; vb < vb##_n; vb += gridDim.x)
+#define FOR_VERTEX_BLOCKS_G(vb, nvp, g, G) for (int vb = (g), vb##_n = (*(nvp) + 255) >> 8; vb < vb##_n; vb += (G))
 
 // ---- K4/K5: vertex -> cell, neighbour table (get_valid_idx, bilateral_solver.py:29-37,69-81)
 __global__ __launch_bounds__(256) void bg_vertices_kernel(const u64* bitmap, const unsigned* wprefix, long nwords, int* vcell, BgBatch bt) {
@@ -418,23 +419,23 @@ __global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c0, BgBatch bt) {  
 // code in the same order, so both paths give bitwise the same iterates.
 // phase 1: convergence test at the top of iteration `it` (every block re-derives it from the same partials: deterministic, no flag
 // race), then p = z + beta p.  Returns false when converged (||r|| < atol).
-__device__ __forceinline__ bool cg_phase_p(const CgPtrs& c, int it, int nb, double rho_prev, double& rho, double* red) {
+__device__ __forceinline__ bool cg_phase_p(const CgPtrs& c, int it, int nb, double rho_prev, double& rho, double* red, int g, int G) {
   rho = sum_partials(c.part_rz, nb, red);
   const double rr = sum_partials(c.part_rr, nb, red);
   if (sqrt(rr) < c.sc[2]) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && c.sc[3] == 0.0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
+    if (g == 0 && threadIdx.x == 0 && c.sc[3] == 0.0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
     return false;
   }
   const double beta = it == 0 ? 0.0 : rho / rho_prev;
-  FOR_VERTEX_BLOCKS(vb, c.nv) {
+  FOR_VERTEX_BLOCKS_G(vb, c.nv, g, G) {
     const int v = vb * 256 + threadIdx.x;
     if (v < *c.nv) c.p[v] = it == 0 ? c.z[v] : c.z[v] + beta * c.p[v];
   }
   return true;
 }
 // phase 2: q = A p, per-block partials of p.q
-__device__ __forceinline__ void cg_phase_q(const CgPtrs& c, double* red) {
-  FOR_VERTEX_BLOCKS(vb, c.nv) {
+__device__ __forceinline__ void cg_phase_q(const CgPtrs& c, double* red, int g, int G) {
+  FOR_VERTEX_BLOCKS_G(vb, c.nv, g, G) {
     const int v = vb * 256 + threadIdx.x;
     double pq = 0.0;
     if (v < *c.nv) { const double q = matvec_row(c, c.p, v); c.q[v] = q; pq = c.p[v] * q; }
@@ -443,10 +444,10 @@ __device__ __forceinline__ void cg_phase_q(const CgPtrs& c, double* red) {
   }
 }
 // phase 3: x += alpha p, r -= alpha q, z = M^-1 r, per-block partials of r.z and r.r
-__device__ __forceinline__ void cg_phase_x(const CgPtrs& c, int nb, double rho, double* red) {
+__device__ __forceinline__ void cg_phase_x(const CgPtrs& c, int nb, double rho, double* red, int g, int G) {
   const double pq = sum_partials(c.part_pq, nb, red);
   const double alpha = rho / pq;
-  FOR_VERTEX_BLOCKS(vb, c.nv) {
+  FOR_VERTEX_BLOCKS_G(vb, c.nv, g, G) {
     const int v = vb * 256 + threadIdx.x;
     double rz = 0.0, rr = 0.0;
     if (v < *c.nv) {
@@ -468,14 +469,14 @@ __global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c0, int it, BgBa
   const int nb = cg_active_blocks(c);
   if ((int)blockIdx.x >= nb) return;
   double rho;
-  if (!cg_phase_p(c, it, nb, it == 0 ? 1.0 : c.sc[(it - 1) & 1], rho, red)) return;   // once converged the partials are frozen: the
+  if (!cg_phase_p(c, it, nb, it == 0 ? 1.0 : c.sc[(it - 1) & 1], rho, red, blockIdx.x, gridDim.x)) return;   // once converged the partials are frozen: the
   if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;                          // decision repeats for all later iterations
 }
 __global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c0, BgBatch bt) {
   __shared__ double red[4];
   const CgPtrs c = cg_img(c0, bt);
   if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
-  cg_phase_q(c, red);
+  cg_phase_q(c, red, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBatch bt) {
   __shared__ double red[4];
@@ -483,54 +484,108 @@ __global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBat
   const int nb = cg_active_blocks(c);
   if ((int)blockIdx.x >= nb) return;
   if (c.sc[3] != 0.0) return;
-  cg_phase_x(c, nb, c.sc[it & 1], red);
+  cg_phase_x(c, nb, c.sc[it & 1], red, blockIdx.x, gridDim.x);
 }
 
 // ---- persistent PCG: ALL iterations of a batch in ONE launch (the per-phase form is 3 launches per iteration = 75 per solve at
-// the dispatch floor of 5-8 us each: 57 % of a batched solve, profiles/r02_bilateral_b8_kernel_stats.csv).  The blocks of one
-// image (gridDim.x of them; blockIdx.y = image) meet at an image-local barrier between the phases: a monotonic counter in global
-// memory, one agent-scope release add + acquire poll by thread 0 of every block (the same scheme as cooperative-groups grid sync;
-// the fences carry the L1 / cross-XCD L2 maintenance the hand-off of p, q and the partials needs).  The host sizes the grid to at
-// most ONE block per CU in total, so every block is resident even with several solves in flight on other streams (the pseudo-label
-// pipeline) and a barrier can always complete; the poll is nevertheless BOUNDED: on expiry the block raises `*err` and leaves.
-#define CG_SPIN_LIMIT (1 << 21)      // x (s_sleep + one L2 atomic) ~ seconds: far beyond any legitimate wait
-__device__ __forceinline__ bool img_barrier(unsigned* cnt, unsigned& epoch, int* err) {
+// the dispatch floor of 5-8 us each: 57 % of a batched solve, profiles/r02_bilateral_b8_kernel_stats.csv).
+//
+// One image per XCD.  A 512x683 image has ~20 k vertices: its PCG vectors (~2 MB) live in ONE XCD's 4 MiB L2, and the L2 is the
+// coherence point of that XCD's 32 CUs.  Workgroups are dealt to the XCDs round-robin (linear id % 8), so the launch is 1-D and
+// block b works on image (b % 8) + 8 * ((b / 8) / G) as block (b / 8) % G of G: every block of an image lands on the same XCD, up
+// to one block per CU.  Between the three phases of an iteration the image's blocks meet at an XCD-LOCAL barrier:
+//     every wave:  s_waitcnt vmcnt(0)            its stores (write-through L1) have reached the L2
+//     thread 0:    global_atomic_add (sc0)        executed AT the L2; polled with add 0 until all G blocks arrived
+//                  buffer_inv sc0                 drop this CU's L1 lines: the loads that follow come from the L2
+// — no agent-scope release / acquire, i.e. no L2 write-back + invalidate.  (A first version used the portable agent-scope
+// fences, as cooperative-groups grid sync does: 26 us per barrier on this 8-XCD part, 2.15 ms per solve against 0.49 ms for the
+// 75 separate launches — measured, tools/bilateral_bench.py, round 3.)
+// The placement is VERIFIED, not assumed: every block publishes its HW_REG_XCC_ID before the first barrier, which is a portable
+// agent-scope one; only if all blocks of the image report the same XCD do they switch to the XCD-local barrier — otherwise the
+// image keeps the portable barrier (slow, still correct).  Every poll is bounded: on expiry the block raises `*err` and leaves
+// (cg_finish_kernel then reports iterations = -1 and the Python side raises).  At most one block per CU in total, so all blocks
+// are resident even with several solves in flight on other streams.
+#define CG_SPIN_LIMIT (1 << 21)      // polls (each an L2 or memory round trip): seconds, far beyond any legitimate wait
+__device__ __forceinline__ unsigned l2_atomic_add(unsigned* p, unsigned v) {   // executes at the XCD's L2, returns the old value
+  unsigned old;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
+  return old;
+}
+struct ImgBarrier { unsigned* cnt; unsigned epoch; unsigned G; int* err; bool local; };
+__device__ __forceinline__ bool img_barrier(ImgBarrier& bar) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __shared__ int ok;
   if (threadIdx.x == 0) {
-    epoch += 1;
-    const unsigned target = epoch * gridDim.x;
-    __threadfence();
-    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    bar.epoch += 1;
+    const unsigned target = bar.epoch * bar.G;
     int good = 1;
-    for (int spins = 0; __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
-      if (spins > CG_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { good = 0; break; }
-      __builtin_amdgcn_s_sleep(2);
+    if (bar.local) {
+      l2_atomic_add(bar.cnt, 1u);
+      for (int spins = 0; l2_atomic_add(bar.cnt, 0u) < target; ++spins)
+        if (spins > CG_SPIN_LIMIT) { good = 0; break; }
+      asm volatile("buffer_inv sc0" ::: "memory");
+    } else {
+      __threadfence();
+      __hip_atomic_fetch_add(bar.cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spins = 0; __hip_atomic_load(bar.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+        if (spins > CG_SPIN_LIMIT || __hip_atomic_load(bar.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { good = 0; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __threadfence();
     }
-    if (!good) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
+    if (!good) __hip_atomic_store(bar.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ok = good;
   }
   __syncthreads();
   return ok != 0;
 }
-__global__ __launch_bounds__(256) void cg_persistent_kernel(CgPtrs c0, int maxiter, unsigned* bar, int* err, BgBatch bt) {
+__global__ __launch_bounds__(256) void cg_persistent_kernel(CgPtrs c0, int maxiter, int B, int G, int* err, BgBatch bt) {
   __shared__ double red[4];
-  const CgPtrs c = cg_img(c0, bt);
-  unsigned* cnt = ws_img(bar, bt);                                         // a line of the image's own scalar block (zeroed per call)
-  unsigned epoch = 0;
+  __shared__ int s_local;
+  const int b = blockIdx.x, slot = b >> 3, img = (b & 7) + 8 * (slot / G), g = slot % G;
+  if (img >= B) return;
+  CgPtrs c = c0;
+  {   // per-image pointers (cg_img uses blockIdx.y: this grid is 1-D)
+    const size_t off = (size_t)img * bt.ws;
+    auto at = [&](auto* p) { return (decltype(p))((char*)p + off); };
+    c.n = at(c.n); c.m = at(c.m); c.wsplat = at(c.wsplat); c.b = at(c.b); c.nbr = at(c.nbr); c.nv = at(c.nv); c.minv = at(c.minv);
+    c.x = at(c.x); c.r = at(c.r); c.z = at(c.z); c.p = at(c.p); c.q = at(c.q); c.part_rz = at(c.part_rz); c.part_rr = at(c.part_rr);
+    c.part_pq = at(c.part_pq); c.sc = at(c.sc);
+  }
+  // the image's scalar block (zeroed per call), bytes: [128] portable barrier counter, [132] max (XCC id + 1), [136] max (16 - XCC id),
+  // [144] XCD-local barrier counter (its own word: only ever touched by L2-executed atomics)
+  unsigned* line = (unsigned*)((char*)c.sc + 128);
+  ImgBarrier bar{line, 0u, (unsigned)G, err, false};
+  if (threadIdx.x == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    id &= 15u;
+    __hip_atomic_fetch_max(line + 1, id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // max of (id + 1)
+    __hip_atomic_fetch_max(line + 2, 16u - id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // max of (16 - id) = 16 - min id
+  }
+  if (!img_barrier(bar)) return;                                           // portable barrier: everybody's id is published
+  if (threadIdx.x == 0) {
+    const unsigned mx = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned mn = __hip_atomic_load(line + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_local = (mx - 1u) == (16u - mn);                                     // max id == min id: the whole image sits on one XCD
+  }
+  __syncthreads();
+  bar.local = s_local != 0;
+  if (bar.local) { bar.cnt = line + 4; bar.epoch = 0; }
   const int nb = cg_active_blocks(c);
   double rho_prev = 1.0;
   for (int it = 0; it < maxiter; ++it) {
     double rho;
-    if (!cg_phase_p(c, it, nb, rho_prev, rho, red)) break;                 // every block of the image takes the same decision
-    if (!img_barrier(cnt, epoch, err)) return;                             // p complete before any neighbour gathers it
-    cg_phase_q(c, red);
-    if (!img_barrier(cnt, epoch, err)) return;                             // all p.q partials written
-    cg_phase_x(c, nb, rho, red);
-    if (!img_barrier(cnt, epoch, err)) return;                             // all r.z / r.r partials written
+    if (!cg_phase_p(c, it, nb, rho_prev, rho, red, g, G)) break;           // every block of the image takes the same decision
+    if (!img_barrier(bar)) return;                                         // p complete before any neighbour gathers it
+    cg_phase_q(c, red, g, G);
+    if (!img_barrier(bar)) return;                                         // all p.q partials written
+    cg_phase_x(c, nb, rho, red, g, G);
+    if (!img_barrier(bar)) return;                                         // all r.z / r.r partials written
     rho_prev = rho;
   }
+  if (g == 0 && threadIdx.x == 0) c.sc[5] = bar.local ? 1.0 : 2.0;         // which barrier ran (tests / tools read it through stats)
 }
 
 __global__ void cg_finish_kernel(CgPtrs c0, int maxiter, int* stats, const double* n_src, const double* m_src, double* n_out, double* m_out,
@@ -631,8 +686,9 @@ static int bg_persistent_blocks(int B, int nblocks) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
     return n;
   }();
-  if (!mode || cus <= 0 || B > cus) return 0;
-  const int g = cus / B;
+  const int groups = (B + 7) / 8;                      // images per XCD; the grid is 8 * G * groups blocks <= one per CU
+  if (!mode || cus < 8 || groups * 8 > cus) return 0;
+  const int g = cus / (8 * groups);
   return g < nblocks ? g : nblocks;
 }
 __global__ __launch_bounds__(256) void bg_zero_kernel(u64* a, long na, u64* b, long nb, u64* c, long nc, BgBatch bt) {
@@ -714,7 +770,8 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
   int* err = (int*)(ws + L.sc + 192);                                            // image 0's scalar line: one flag for the batch
   const int per_image = bg_persistent_blocks(B, L.nblocks);
   if (per_image > 0 && cg_maxiter > 0) {
-    hipLaunchKernelGGL(cg_persistent_kernel, dim3(per_image, B), blk, 0, stream, c, cg_maxiter, (unsigned*)(ws + L.sc + 128), err, bt);
+    const int groups = (B + 7) / 8;                                              // images per XCD
+    hipLaunchKernelGGL(cg_persistent_kernel, dim3(8 * per_image * groups), blk, 0, stream, c, cg_maxiter, B, per_image, err, bt);
   } else {
     for (int it = 0; it < cg_maxiter; ++it) {
       hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it, bt);
