@@ -53,9 +53,6 @@ const char* zh_last_error(void);
  * zh_gemm_f16x3 (64|192|256|448|512), 0 = the cost model's choice; tile_small = the same, applied to M <= 4096 only.  Process-wide;
  * the initial values come from ZH_GEMM_GROUP_M / ZH_GEMM_TILE / ZH_GEMM_TILE_SMALL, read once. */
 int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small);
-/* DEVELOPER entry: 0 = the bilateral solver runs its PCG iterations as 3 launches each (round-2 form), 1 (default) = all iterations
- * of a batch in one persistent launch when the batch fits one block per CU.  Both give bitwise the same result (tests). */
-int zh_dev_set_bilateral_persistent(int on);
 
 /* C[b][m][n] = act(sum_k A[b][m][k]*W[b][n][k] + bias[n] + pos[m][n]) + residual[b][m % res_rows][n]
  * A [M,K] f16 (lda), W [N,K] f16 (ldw) — torch Linear layout; C f32 or f16 (out_f16); bias/residual f32 or NULL.

@@ -167,42 +167,6 @@ def test_solver_batched_equals_per_image_bitwise(dev):
     assert vs[3] > 2 * max(vs[:3])
 
 
-def test_persistent_pcg_equals_per_phase_launches(dev):
-    """All PCG iterations of a batch in ONE launch (cg_persistent_kernel: image-local barriers between the three phases) against
-    the round-2 form (three launches per iteration): bitwise the same soft output and iteration counts, batch 1 and batch 4,
-    several solves in flight on different streams included (every block must stay resident: one block per CU per batch)."""
-    from zutis_amd import ops, detgen, _lib
-    L = _lib.load(raw=True)
-    h, w = 200, 280
-    rgbs = np.stack([detgen.selfmask_like_rgb(h, w, seed=s) for s in (3, 5, 9, 11)])
-    yy, xx = np.mgrid[:h, :w]
-    tg = np.stack([(((yy - 100 - 5 * i) ** 2 + (xx - 140) ** 2) < (50 + 4 * i) ** 2).astype(np.uint8) for i in range(4)])
-    R, T = torch.from_numpy(rgbs).to(dev), torch.from_numpy(tg).to(dev)
-    try:
-        L.zh_dev_set_bilateral_persistent(0)
-        ref_b, st_b = ops.bilateral_solve(R, T)
-        ref_1, st_1 = ops.bilateral_solve(R[2].contiguous(), T[2].contiguous())
-        torch.cuda.synchronize()
-        L.zh_dev_set_bilateral_persistent(1)
-        got_b, gst_b = ops.bilateral_solve(R, T)
-        got_1, gst_1 = ops.bilateral_solve(R[2].contiguous(), T[2].contiguous())
-        assert torch.equal(got_b, ref_b) and torch.equal(gst_b, st_b)
-        assert torch.equal(got_1, ref_1) and torch.equal(gst_1, st_1)
-        assert int(gst_b[:, 1].min()) > 3                      # real iterations happened (and none reported -1)
-        streams = [torch.cuda.Stream() for _ in range(6)]
-        outs = []
-        torch.cuda.synchronize()
-        for rep in range(3):
-            for st in streams:
-                with torch.cuda.stream(st):
-                    outs.append(ops.bilateral_solve(R, T)[0])
-        torch.cuda.synchronize()
-        ops.solver_check()
-        assert all(torch.equal(o, ref_b) for o in outs)
-    finally:
-        L.zh_dev_set_bilateral_persistent(1)
-
-
 def test_solver_nonbinary_and_float_targets_ordered_splat(dev):
     """Targets that are not {0,1}: the splat S.(t*w) is summed per vertex in ascending pixel order (SciPy's CSR row order),
     for uint8 0..255 and for float64 targets, against the NumPy/SciPy oracle."""

@@ -18,7 +18,6 @@ for B in (1, 2, 4, 8, 16, 32):
         ops.bilateral_solve(rgb, tg)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    ops.solver_check()
     V = stats[:, 0].float().mean().item()
     byts = H * W * (3 + 1 + 8 + 16) + V * 250 * 36
     print(f"B={B:2d}: {dt*1e3:7.3f} ms per call, {dt/B*1e3:6.3f} ms per image, V~{V:.0f}, iters {stats[:,1].tolist()[:4]}, "

@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c0, BgBatch bt) {  
   const double bb = sum_partials(c.part_pq, cg_active_blocks(c), red);
   if (threadIdx.x == 0) { c.sc[2] = c.rtol * sqrt(bb); c.sc[3] = 0.0; c.sc[4] = 0.0; }
 }
-// The three phases of one PCG iteration as device functions: the per-phase kernels below and the persistent kernel run the SAME
-// code in the same order, so both paths give bitwise the same iterates.
+// The three phases of one PCG iteration as device functions, parametrised by (g, G) = this block's index among the G blocks of its
+// image (the per-phase kernels below call them; so did the persistent single-launch experiments of round 3, see further down).
 // phase 1: convergence test at the top of iteration `it` (every block re-derives it from the same partials: deterministic, no flag
 // race), then p = z + beta p.  Returns false when converged (||r|| < atol).
 __device__ __forceinline__ bool cg_phase_p(const CgPtrs& c, int it, int nb, double rho_prev, double& rho, double* red, int g, int G) {
@@ -487,114 +487,21 @@ __global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBat
   cg_phase_x(c, nb, c.sc[it & 1], red, blockIdx.x, gridDim.x);
 }
 
-// ---- persistent PCG: ALL iterations of a batch in ONE launch (the per-phase form is 3 launches per iteration = 75 per solve at
-// the dispatch floor of 5-8 us each: 57 % of a batched solve, profiles/r02_bilateral_b8_kernel_stats.csv).
-//
-// One image per XCD.  A 512x683 image has ~20 k vertices: its PCG vectors (~2 MB) live in ONE XCD's 4 MiB L2, and the L2 is the
-// coherence point of that XCD's 32 CUs.  Workgroups are dealt to the XCDs round-robin (linear id % 8), so the launch is 1-D and
-// block b works on image (b % 8) + 8 * ((b / 8) / G) as block (b / 8) % G of G: every block of an image lands on the same XCD, up
-// to one block per CU.  Between the three phases of an iteration the image's blocks meet at an XCD-LOCAL barrier:
-//     every wave:  s_waitcnt vmcnt(0)            its stores (write-through L1) have reached the L2
-//     thread 0:    global_atomic_add (sc0)        executed AT the L2; polled with add 0 until all G blocks arrived
-//                  buffer_inv sc0                 drop this CU's L1 lines: the loads that follow come from the L2
-// — no agent-scope release / acquire, i.e. no L2 write-back + invalidate.  (A first version used the portable agent-scope
-// fences, as cooperative-groups grid sync does: 26 us per barrier on this 8-XCD part, 2.15 ms per solve against 0.49 ms for the
-// 75 separate launches — measured, tools/bilateral_bench.py, round 3.)
-// The placement is VERIFIED, not assumed: every block publishes its HW_REG_XCC_ID before the first barrier, which is a portable
-// agent-scope one; only if all blocks of the image report the same XCD do they switch to the XCD-local barrier — otherwise the
-// image keeps the portable barrier (slow, still correct).  Every poll is bounded: on expiry the block raises `*err` and leaves
-// (cg_finish_kernel then reports iterations = -1 and the Python side raises).  At most one block per CU in total, so all blocks
-// are resident even with several solves in flight on other streams.
-#define CG_SPIN_LIMIT (1 << 21)      // polls (each an L2 or memory round trip): seconds, far beyond any legitimate wait
-__device__ __forceinline__ unsigned l2_atomic_add(unsigned* p, unsigned v) {   // executes at the XCD's L2, returns the old value
-  unsigned old;
-  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
-  return old;
-}
-struct ImgBarrier { unsigned* cnt; unsigned epoch; unsigned G; int* err; bool local; };
-__device__ __forceinline__ bool img_barrier(ImgBarrier& bar) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  __shared__ int ok;
-  if (threadIdx.x == 0) {
-    bar.epoch += 1;
-    const unsigned target = bar.epoch * bar.G;
-    int good = 1;
-    if (bar.local) {
-      l2_atomic_add(bar.cnt, 1u);
-      for (int spins = 0; l2_atomic_add(bar.cnt, 0u) < target; ++spins)
-        if (spins > CG_SPIN_LIMIT) { good = 0; break; }
-      asm volatile("buffer_inv sc0" ::: "memory");
-    } else {
-      __threadfence();
-      __hip_atomic_fetch_add(bar.cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      for (int spins = 0; __hip_atomic_load(bar.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
-        if (spins > CG_SPIN_LIMIT || __hip_atomic_load(bar.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { good = 0; break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      __threadfence();
-    }
-    if (!good) __hip_atomic_store(bar.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok = good;
-  }
-  __syncthreads();
-  return ok != 0;
-}
-__global__ __launch_bounds__(256) void cg_persistent_kernel(CgPtrs c0, int maxiter, int B, int G, int* err, BgBatch bt) {
-  __shared__ double red[4];
-  __shared__ int s_local;
-  const int b = blockIdx.x, slot = b >> 3, img = (b & 7) + 8 * (slot / G), g = slot % G;
-  if (img >= B) return;
-  CgPtrs c = c0;
-  {   // per-image pointers (cg_img uses blockIdx.y: this grid is 1-D)
-    const size_t off = (size_t)img * bt.ws;
-    auto at = [&](auto* p) { return (decltype(p))((char*)p + off); };
-    c.n = at(c.n); c.m = at(c.m); c.wsplat = at(c.wsplat); c.b = at(c.b); c.nbr = at(c.nbr); c.nv = at(c.nv); c.minv = at(c.minv);
-    c.x = at(c.x); c.r = at(c.r); c.z = at(c.z); c.p = at(c.p); c.q = at(c.q); c.part_rz = at(c.part_rz); c.part_rr = at(c.part_rr);
-    c.part_pq = at(c.part_pq); c.sc = at(c.sc);
-  }
-  // the image's scalar block (zeroed per call), bytes: [128] portable barrier counter, [132] max (XCC id + 1), [136] max (16 - XCC id),
-  // [144] XCD-local barrier counter (its own word: only ever touched by L2-executed atomics)
-  unsigned* line = (unsigned*)((char*)c.sc + 128);
-  ImgBarrier bar{line, 0u, (unsigned)G, err, false};
-  if (threadIdx.x == 0) {
-    unsigned id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-    id &= 15u;
-    __hip_atomic_fetch_max(line + 1, id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // max of (id + 1)
-    __hip_atomic_fetch_max(line + 2, 16u - id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // max of (16 - id) = 16 - min id
-  }
-  if (!img_barrier(bar)) return;                                           // portable barrier: everybody's id is published
-  if (threadIdx.x == 0) {
-    const unsigned mx = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned mn = __hip_atomic_load(line + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_local = (mx - 1u) == (16u - mn);                                     // max id == min id: the whole image sits on one XCD
-  }
-  __syncthreads();
-  bar.local = s_local != 0;
-  if (bar.local) { bar.cnt = line + 4; bar.epoch = 0; }
-  const int nb = cg_active_blocks(c);
-  double rho_prev = 1.0;
-  for (int it = 0; it < maxiter; ++it) {
-    double rho;
-    if (!cg_phase_p(c, it, nb, rho_prev, rho, red, g, G)) break;           // every block of the image takes the same decision
-    if (!img_barrier(bar)) return;                                         // p complete before any neighbour gathers it
-    cg_phase_q(c, red, g, G);
-    if (!img_barrier(bar)) return;                                         // all p.q partials written
-    cg_phase_x(c, nb, rho, red, g, G);
-    if (!img_barrier(bar)) return;                                         // all r.z / r.r partials written
-    rho_prev = rho;
-  }
-  if (g == 0 && threadIdx.x == 0) c.sc[5] = bar.local ? 1.0 : 2.0;         // which barrier ran (tests / tools read it through stats)
-}
+// (Round 3 measured two persistent single-launch forms of this loop — all iterations in one kernel with image-local barriers
+// between the phases — and kept neither; both are in the git history.  With portable agent-scope release / acquire fences, as
+// cooperative-groups grid sync does, a barrier costs ~26 us on this 8-XCD part (L2 write-back + invalidate): 2.15 ms per
+// 512x683 solve against 0.49 ms for the 75 separate launches.  With one image per XCD (blocks b, b+8, ... share an XCD; placement
+// verified through HW_REG_XCC_ID) and barriers that stay inside that XCD's L2 (s_waitcnt vmcnt(0) + an L2-executed atomic + poll +
+// buffer_inv sc0) a barrier still costs ~5 us with 32 blocks polling one line — the price of a launch: 0.538 vs 0.477 ms at batch 1,
+// 0.711 vs 0.740 ms at batch 8.  A phase is ~1 us of work on 20 k vertices; the solve is bound by the synchronisation latency
+// itself, whichever mechanism provides it.  DESIGN.md section 3, "Bilateral solver".)
 
 __global__ void cg_finish_kernel(CgPtrs c0, int maxiter, int* stats, const double* n_src, const double* m_src, double* n_out, double* m_out,
-                                 const int* err, BgBatch bt) {
+                                 BgBatch bt) {
   const CgPtrs c = cg_img(c0, bt);
   if (threadIdx.x == 0) {
     if (c.sc[3] == 0.0) c.sc[4] = (double)maxiter;
-    // err != 0: a barrier of the persistent PCG kernel timed out — the iterates are unfinished: iterations = -1 (callers raise)
-    if (stats) { stats[2 * blockIdx.y] = *c.nv; stats[2 * blockIdx.y + 1] = (err && *err) ? -1 : (int)c.sc[4]; }
+    if (stats) { stats[2 * blockIdx.y] = *c.nv; stats[2 * blockIdx.y + 1] = (int)c.sc[4]; }
   }
   if (n_out || m_out) {                                                       // debug copies of the bistochastisation vectors
     n_src = ws_img(n_src, bt); m_src = ws_img(m_src, bt);
@@ -671,26 +578,6 @@ extern "C" int zh_bgrid_coords(const unsigned char* rgb, int H, int W, double si
 // [B,H,W] (target_f64), exactly one non-NULL; out_soft f64 [B,H,W].  stats (device, may be NULL): int32 [B,2] = {nvertices,
 // cg iterations}.  Optional debug outputs (device, may be NULL): n_out / m_out f64 [B, H*W] (first nvertices entries of
 // each row).  workspace: B * zh_bilateral_workspace_size(H, W, ...) bytes.
-// Blocks per image of the persistent PCG kernel: the whole batch gets at most ONE block per CU (so that, with up to 8 solves in
-// flight on other streams, every block is still resident and the image barriers cannot starve); 0 = use the per-phase launches.
-// ZH_BILATERAL_PERSISTENT=0 (read once) or zh_dev_set_bilateral_persistent(0) forces the per-phase form (A/B, tests).
-static int& bg_persistent_mode() {
-  static int mode = [] { const char* e = getenv("ZH_BILATERAL_PERSISTENT"); return e ? atoi(e) : 1; }();
-  return mode;
-}
-extern "C" int zh_dev_set_bilateral_persistent(int on) { bg_persistent_mode() = on ? 1 : 0; return ZH_OK; }
-static int bg_persistent_blocks(int B, int nblocks) {
-  const int mode = bg_persistent_mode();
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    return n;
-  }();
-  const int groups = (B + 7) / 8;                      // images per XCD; the grid is 8 * G * groups blocks <= one per CU
-  if (!mode || cus < 8 || groups * 8 > cus) return 0;
-  const int g = cus / (8 * groups);
-  return g < nblocks ? g : nblocks;
-}
 __global__ __launch_bounds__(256) void bg_zero_kernel(u64* a, long na, u64* b, long nb, u64* c, long nc, BgBatch bt) {
   a = ws_img(a, bt); b = ws_img(b, bt); c = ws_img(c, bt);
   const long stride = (long)gridDim.x * 256, i0 = (long)blockIdx.x * 256 + threadIdx.x;
@@ -736,7 +623,7 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
   int* nv = (int*)(ws + L.nv);
 
   const dim3 blk(256), gN(zh_cdiv(N, 256), B), gV(L.nblocks < VGRID ? L.nblocks : VGRID, B), g1(1, B);
-  // bitmaps, integer splats, scalars (+ the barrier counter / error flag of the persistent PCG): ONE launch for the whole batch
+  // bitmaps, integer splats, scalars: ONE launch for the whole batch
   // (it was three hipMemsetAsync per image: 120 fill kernels per 5 batched calls, 7.5 % of the GPU time in the round-2 profile)
   hipLaunchKernelGGL(bg_zero_kernel, dim3(64, B), blk, 0, stream, (u64*)(ws + L.bitmap), L.nwords, (u64*)(ws + L.ints), (long)((2 * istride + 256) / 8),
                      (u64*)(ws + L.sc), 32L, bt);
@@ -766,21 +653,13 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
   hipLaunchKernelGGL(cg_y0_kernel, gV, blk, 0, stream, c, bt);
   hipLaunchKernelGGL(cg_init_kernel, gV, blk, 0, stream, c, bt);
   hipLaunchKernelGGL(cg_atol_kernel, g1, blk, 0, stream, c, bt);
-  // all iterations in ONE launch when the batch fits one block per CU in total (see cg_persistent_kernel); else 3 launches per iteration
-  int* err = (int*)(ws + L.sc + 192);                                            // image 0's scalar line: one flag for the batch
-  const int per_image = bg_persistent_blocks(B, L.nblocks);
-  if (per_image > 0 && cg_maxiter > 0) {
-    const int groups = (B + 7) / 8;                                              // images per XCD
-    hipLaunchKernelGGL(cg_persistent_kernel, dim3(8 * per_image * groups), blk, 0, stream, c, cg_maxiter, B, per_image, err, bt);
-  } else {
-    for (int it = 0; it < cg_maxiter; ++it) {
-      hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it, bt);
-      hipLaunchKernelGGL(cg_matvec_kernel, gV, blk, 0, stream, c, bt);
-      hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it, bt);
-    }
+  for (int it = 0; it < cg_maxiter; ++it) {
+    hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it, bt);
+    hipLaunchKernelGGL(cg_matvec_kernel, gV, blk, 0, stream, c, bt);
+    hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it, bt);
   }
   hipLaunchKernelGGL(bg_slice_kernel, gN, blk, 0, stream, c.x, pix2v, N, out_soft, bt);
-  hipLaunchKernelGGL(cg_finish_kernel, g1, blk, 0, stream, c, cg_maxiter, stats, ncur, m, n_out, m_out, err, bt);
+  hipLaunchKernelGGL(cg_finish_kernel, g1, blk, 0, stream, c, cg_maxiter, stats, ncur, m, n_out, m_out, bt);
   ZH_CHECK_LAUNCH("zh_bilateral_solve");
   return ZH_OK;
 }

@@ -130,5 +130,4 @@ class SelfMask(nn.Module):
             rgb = torch.stack([_ops.denormalize_u8(xf[b].contiguous()) for b in range(x.shape[0])])   # utils/utils.py:261-273
             soft, _ = _ops.bilateral_solve(rgb, dts_dev.contiguous())
             dict_outputs["dts_bi"] = [d for d in _ops.threshold_f64_u8(soft, 0.5).cpu()]
-            _ops.solver_check()
         return dict_outputs

@@ -28,9 +28,7 @@ def _postprocess(output_solver: np.ndarray) -> np.ndarray:
 def _solve(rgb_dev: torch.Tensor, target_dev: torch.Tensor, sigma_spatial, sigma_luma, sigma_chroma) -> np.ndarray:
     soft, _ = _ops.bilateral_solve(rgb_dev, target_dev, sigma_spatial, sigma_luma, sigma_chroma,
                                    confidence=0.999, lam=256.0, a_diag_min=1e-5, cg_tol=1e-5, cg_maxiter=25)   # :162-175
-    out = soft.cpu().numpy()
-    _ops.solver_check()
-    return out
+    return soft.cpu().numpy()
 
 
 def bilateral_solver_output(img, target: np.ndarray, sigma_spatial=16, sigma_luma=16, sigma_chroma=8,

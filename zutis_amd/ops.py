@@ -445,38 +445,10 @@ def bilateral_solve(rgb_u8, target, sigma_spatial=16, sigma_luma=16, sigma_chrom
     _lib.check(L.zh_bilateral_solve_batch(_p(r4), _p(t8), _p(t64), B, H, W, float(sigma_spatial), float(sigma_luma), float(sigma_chroma),
                                           float(confidence), float(lam), float(a_diag_min), float(cg_tol), int(cg_maxiter), _p(out),
                                           _p(stats), _p(n), _p(m), _p(ws), need, _stream()), "zh_bilateral_solve_batch")
-    # a barrier timeout of the persistent PCG kernel is reported as iterations = -1: copy the stats to pinned host memory behind the
-    # solve (async, same stream) and look at FINISHED earlier solves now — no host / stream synchronisation on the hot path
-    host = torch.empty((B, 2), dtype=torch.int32).pin_memory()
-    host.copy_(stats, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    _SOLVER_PENDING.append((ev, host))
-    solver_check(wait=False)
     if not batched:
         out, stats = out[0], stats[0]
         n, m = (n[0], m[0]) if debug else (None, None)
     return (out, stats, n, m) if debug else (out, stats)
-
-
-_SOLVER_PENDING = []
-
-
-def solver_check(wait: bool = True):
-    """Raise if a bilateral solve reported a barrier timeout (stats iterations == -1: its iterates are unfinished).  wait=False
-    inspects only the solves that have already completed; callers that hand results to the host call it with wait=True."""
-    keep = []
-    for ev, host in _SOLVER_PENDING:
-        if wait:
-            ev.synchronize()
-        elif not ev.query():
-            keep.append((ev, host))
-            continue
-        if bool((host[:, 1] < 0).any()):
-            _SOLVER_PENDING.clear()
-            raise _lib.ZutisHipError("zh_bilateral_solve_batch: an image barrier of the persistent PCG kernel timed out (blocks not "
-                                     "co-resident?); set ZH_BILATERAL_PERSISTENT=0 to use the per-phase launches")
-    _SOLVER_PENDING[:] = keep
 
 
 def threshold_f64_u8(x, threshold=0.5):

@@ -37,9 +37,7 @@ def _device_mask(engine: SelfMaskEngine, image: torch.Tensor, original_size: Opt
 def pseudo_mask(engine: SelfMaskEngine, image: torch.Tensor, original_size: Optional[Tuple[int, int]] = None,
                 bilateral_solver: bool = True) -> np.ndarray:
     """image f32 [3,H,W] (normalised, on the GPU) -> uint8 {0,1} mask [H0,W0] (original_size or H,W) on the host."""
-    m = _device_mask(engine, image, original_size, bilateral_solver).cpu().numpy()
-    ops.solver_check()
-    return m
+    return _device_mask(engine, image, original_size, bilateral_solver).cpu().numpy()
 
 
 @torch.no_grad()
@@ -89,7 +87,6 @@ def generate_pseudo_masks_batched(engine: SelfMaskEngine, images: Sequence[torch
         masks = pseudo_masks_batch(engine, torch.stack(list(images[i:j])), original_sizes[i:j], bilateral_solver)
         for m, path in zip(masks, out_paths[i:j]):
             save_rle_json(m.cpu().numpy(), path)
-        ops.solver_check()
         i = j
     return list(out_paths)
 
@@ -134,5 +131,4 @@ def generate_pseudo_masks(engine: SelfMaskEngine, images: Sequence[torch.Tensor]
         pending.append((ev, pinned[k], tuple(dt.shape), path))
     while pending:
         finish(pending.popleft())
-    ops.solver_check()
     return list(out_paths)
