@@ -82,6 +82,10 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // 192 x 256 (waves of 96 x 64, 56 KiB) — a third fewer staged bytes per MFMA than 256 x 128, which is what bounds the 3-slot
   // loop (tools/gemm_x3_probe.sh).  256 x 256 serves the wide GEMMs (QKV, c_fc, the K / V projections); 192 x 256 turns the
   // N = 768 ones (out_proj, c_proj) into ONE round of 222 tiles where 192 x 128 needs two rounds of 444.
+  // (Measured and not kept, round 3: a 128 x 128 two-slot tile at TWO blocks per CU, so that one block's epilogue overlaps the
+  //  other's K loop — K / V 514 us against 454 for 256 x 256: the extra staged bytes per MFMA cost more than the overlap gives;
+  //  and starting the first wave of tiles out of phase — no change: the K = 256 projections write their 1.04 GB at the rate a
+  //  pure store kernel reaches for any store shape, 5.4 - 5.8 TB/s (tools/micro/store_pattern.hip), only not while MFMAs run.)
   const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
   const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
   const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
