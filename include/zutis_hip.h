@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 211 /* 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 212 /* 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -87,6 +87,15 @@ int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void
  * probabilities are split in registers, O += Vh.Ph + Vl.Ph + Vh.Pl (fp32-class).  planeO != 0: O is written as a split pair.
  * Replaces nn.MultiheadAttention core at clip_arch.py:314-316, transformer.py:272-286,
  * selfmask/vision_transformer.py:110-133 (which materialises [B,heads,T,T]). */
+/* The same attention with the KEYS split over `ksplit` (2..16) workgroups per (image, head, 128-query block) and one merge launch:
+ * for few queries against many keys (the decoder's cross-attention, transformer.py:281-286: 100 queries x 1764 keys).  Partials
+ * (unnormalised fp32 O, running max, row sum) go through `workspace` (zh_attention_splitk_workspace_size bytes, 16-byte aligned). */
+size_t zh_attention_splitk_workspace_size(int batch, int heads, int Tq, int head_dim, int ksplit);
+int zh_attention_f16_splitk(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                            const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
+                            int batch, int heads, int Tq, int Tk, int head_dim, float scale,
+                            long planeQ, long planeK, long planeV, long planeO, int ksplit, void* workspace, size_t workspace_bytes,
+                            zh_stream_t stream);
 int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                      const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                      int batch, int heads, int Tq, int Tk, int head_dim, float scale,

@@ -320,6 +320,36 @@ def test_attention_x3_scores(dev, dh, heads, Tq, Tk, causal):
     assert e3 < 2e-5 and e3 * 100 < e1, (e3, e1)
 
 
+@pytest.mark.parametrize("x3", [True, False])
+@pytest.mark.parametrize("dh,heads,Tq,Tk,S", [(96, 8, 100, 1764, 2), (96, 2, 100, 1764, 3), (64, 3, 130, 1000, 4), (96, 1, 20, 5504, 16)])
+def test_attention_key_split_matches_unsplit(dev, dh, heads, Tq, Tk, S, x3):
+    """zh_attention_f16_splitk (keys split over S workgroups + merge launch) against the single-pass kernel and float64: the
+    merge is the online-softmax rescale, so the result differs from the unsplit one only by fp32 reassociation."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    B, D = 3, heads * dh
+    q, k, v = _randn((B * Tq, D), 1, 1.5), _randn((B * Tk, D), 2, 1.5), _randn((B * Tk, D), 3)
+    qd, kd = q.view(B, Tq, heads, dh).transpose(1, 2).double(), k.view(B, Tk, heads, dh).transpose(1, 2).double()
+    vd = v.view(B, Tk, heads, dh).transpose(1, 2).double()
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) / math.sqrt(dh), -1) @ vd).transpose(1, 2).reshape(B * Tq, D)
+    mk = (lambda t: _split_act(t, dev)) if x3 else (lambda t: Act(t.to(f16)[None].contiguous().to(dev)))
+    Q, K, V = mk(q), mk(k), mk(v)
+    kw = dict(batch=B, heads=heads, Tq=Tq, Tk=Tk, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=Tq * D, strideK=Tk * D,
+              strideV=Tk * D, strideO=Tq * D, x3=x3)
+    O1, O2 = Act.empty((B * Tq, D), x3, dev), Act.empty((B * Tq, D), x3, dev)
+    ops.attention(Q, K, V, O1, **kw)
+    ws = torch.empty(ops.attention_splitk_workspace_size(B, heads, Tq, dh, S), dtype=torch.uint8, device=dev)
+    ops.attention(Q, K, V, O2, ksplit=S, workspace=ws, **kw)
+    val = (lambda o: (o.t[0].float() + o.t[1].float()) if x3 else o.hi.float())
+    e1 = float((val(O1).cpu().double() - ref).abs().max())
+    e2 = float((val(O2).cpu().double() - ref).abs().max())
+    if x3:
+        assert e2 < 2e-5, (e1, e2)
+    else:      # same operand rounding as the single pass: within the same error of float64
+        assert e2 < 2 * e1 + 1e-3, (e1, e2)
+    assert float((val(O1) - val(O2)).abs().max()) < (1e-5 if x3 else 2e-3)
+
+
 # ------------------------------------------------------------------------------------------- whole-model stress test
 def _stress_case(dev, B, S, sharp=3.0):
     from zutis_amd import detgen

@@ -34,6 +34,8 @@ _SIGS = {
     "zh_gemm_f16x3": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _f, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i,
                            _vp]),
     "zh_attention_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _l, _l, _l, _l, _vp]),
+    "zh_attention_splitk_workspace_size": (_sz, [_i, _i, _i, _i, _i]),
+    "zh_attention_f16_splitk": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _l, _l, _l, _l, _i, _vp, _sz, _vp]),
     "zh_attention_causal_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _f, _l, _l, _l, _l, _vp]),
     "zh_embed_tokens_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "zh_eot_rows_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),

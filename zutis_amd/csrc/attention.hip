@@ -26,6 +26,10 @@ struct AttnArgs {
   float scale_log2;
   int causal;       // keys > query masked (CLIP text tower, clip_arch.py:525-531)
   long planeQ, planeK, planeV, planeO;   // X3 kernels: lo planes of the split-pair Q / K / V inputs; planeO != 0: O is written as a split pair
+  // key split (zh_attention_f16_splitk): workgroup (group, qb, ks) covers keys [ks * kchunk, (ks + 1) * kchunk) and leaves its
+  // UNNORMALISED fp32 accumulators + running max (log2 units) + row sum in the workspace; attn_combine_kernel merges them
+  int ksplit, kchunk;
+  float* part_o; float* part_m; float* part_l;   // [ksplit][B*Tq][H*dh], [ksplit][B*H][Tq] x 2
 };
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -75,12 +79,13 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   const int id = blockIdx.y * gridDim.x + blockIdx.x;
 #ifdef ZH_ATTN_PLAIN_ORDER                               // developer A/B build: query blocks of a group on consecutive ids
   const int rr = id;
-  const int qb = rr % p.nqb;
+  const int qb = rr % p.nqb, ks = 0;
   const int group = rr / p.nqb;
 #else
   const int rr = id >> 3;
-  const int qb = rr % p.nqb;
-  const int group = (rr / p.nqb) * 8 + (id & 7);
+  const int qbs = rr % (p.nqb * p.ksplit);
+  const int qb = qbs / p.ksplit, ks = qbs - qb * p.ksplit;
+  const int group = (rr / (p.nqb * p.ksplit)) * 8 + (id & 7);
 #endif
   if (group >= p.groups) return;                        // padding blocks (whole workgroup, before any barrier)
   const int head = group % p.H, img = group / p.H;
@@ -88,6 +93,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   const int ql = lane & 31, hh = lane >> 5;
   const long hoff = (long)head * DH;
 
+  // this workgroup's keys: all of them, or chunk ks of the key split (kchunk is a multiple of the tile height)
+  const int key0 = ks * p.kchunk;
+  const int key_end = p.ksplit > 1 ? min(p.Tk, key0 + p.kchunk) : p.Tk;
   const half_t* Q = p.Q + (long)img * p.sQ + hoff;
   const half_t* K = p.K + (long)img * p.sK + hoff;
   const half_t* V = p.V + (long)img * p.sV + hoff;
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
       const int c = tid + i * NT;
       const int row = c / CPR, cc = c - row * CPR;
       const int key = kbase + row;
-      if (key < p.Tk && (LDFULL || c < KTT * CPR)) {
+      if (key < key_end && (LDFULL || c < KTT * CPR)) {
         r.k[i] = *(const half8_t*)(K + (long)key * p.ldk + cc * 8);
         r.v[i] = *(const half8_t*)(V + (long)key * p.ldv + cc * 8);
         if (X3) {
@@ -168,18 +176,18 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   const int tr_row = 8 * hh + ((lane & 15) >> 2);
   const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
-  int ntiles = (p.Tk + KTT - 1) / KTT;
+  int ntiles = (max(key_end - key0, 0) + KTT - 1) / KTT;
   if (p.causal) {                                           // key tiles entirely above this block's last query are skipped
     const int qlast = min(p.Tq, (qb + 1) * (32 * NWAVE)) - 1;
     ntiles = min(ntiles, qlast / KTT + 1);
   }
   const int qidx = q0 + ql;
-  load_tile(0, ra);
+  load_tile(key0, ra);
   store_tile(0, ra);
   __syncthreads();
 
   auto compute = [&](int t) {
-    const int kbase = t * KTT;
+    const int kbase = key0 + t * KTT;
     const half_t* sK = sKb[t & 1];
     const half_t* sV = sVb[t & 1];
     // a wave whose 32 queries all lie beyond Tq (T = 442: two of the last block's four) only helps with the tile loads
@@ -208,13 +216,13 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     }
     // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
     float mx = -INFINITY;
-    if (kbase + KTT > p.Tk || (p.causal && kbase + KTT - 1 > q0)) {   // ragged last tile / tiles crossing the diagonal
+    if (kbase + KTT > key_end || (p.causal && kbase + KTT - 1 > q0)) {   // ragged last tile / tiles crossing the diagonal
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kbase + 32 * u + 16 * (r >> 3) + 8 * hh + (r & 7);
-          if (key >= p.Tk || (p.causal && key > qidx)) s[u][r] = -INFINITY;
+          if (key >= key_end || (p.causal && key > qidx)) s[u][r] = -INFINITY;
         }
     }
     {   // 32 scores per lane: four independent v_max3 chains instead of one 32-deep dependent chain
@@ -340,12 +348,12 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   }
 #else
   for (int t = 0; t < ntiles; t += 2) {           // two tiles per trip: the LDS buffer index is a compile-time constant
-    if (t + 1 < ntiles) load_tile((t + 1) * KTT, ra);
+    if (t + 1 < ntiles) load_tile(key0 + (t + 1) * KTT, ra);
     compute(t);
     if (t + 1 < ntiles) store_tile(1, ra);
     __syncthreads();
     if (t + 1 >= ntiles) break;
-    if (t + 2 < ntiles) load_tile((t + 2) * KTT, ra);
+    if (t + 2 < ntiles) load_tile(key0 + (t + 2) * KTT, ra);
     compute(t + 1);
     if (t + 2 < ntiles) store_tile(0, ra);
     __syncthreads();
@@ -353,8 +361,24 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
 #endif
 
   // every row of lacc holds the full row sum of this lane's query (the MFMA already summed both key halves)
-  const float inv = 1.0f / lacc[0];
   const int qr = q0 + ql;
+  if (p.ksplit > 1) {                                   // partial result of this key chunk: unnormalised O, running max, row sum
+    if (qr < p.Tq) {
+      float* po = p.part_o + (((long)ks * (p.groups / p.H) + img) * p.Tq + qr) * ((long)p.H * DH) + hoff + 4 * hh;
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)(po + 32 * d + 8 * g) = (f32x4){oacc[d][4 * g], oacc[d][4 * g + 1], oacc[d][4 * g + 2], oacc[d][4 * g + 3]};
+      if (hh == 0) {
+        const long mi = ((long)ks * p.groups + group) * p.Tq + qr;
+        p.part_m[mi] = m_run;
+        p.part_l[mi] = lacc[0];
+      }
+    }
+    return;
+  }
+  const float inv = 1.0f / lacc[0];
   if (qr < p.Tq) {
     half_t* op = p.O + (long)img * p.sO + (long)qr * p.ldo + hoff + 4 * hh;
 #pragma unroll
@@ -367,10 +391,35 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   }
 }
 
+// Merge of the key-split partials: per (row = image * Tq + query, head), m = max_s m_s, w_s = 2^(m_s - m),
+// O = sum_s w_s O_s / sum_s w_s l_s — the same arithmetic a single workgroup does when it meets a new running max.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* part_o, const float* part_m, const float* part_l, half_t* O, long ldo, long sO,
+                                                           long planeO, int S, int B, int H, int Tq, int DH) {
+  const int D = H * DH, c4 = D / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * Tq * c4) return;
+  const int col = (int)(i % c4) * 4;
+  const long row = i / c4;
+  const int img = (int)(row / Tq), q = (int)(row - (long)img * Tq), head = col / DH;
+  float m = -INFINITY;
+  for (int s = 0; s < S; ++s) m = fmaxf(m, part_m[(((long)s * B + img) * H + head) * Tq + q]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const long mi = (((long)s * B + img) * H + head) * Tq + q;
+    const float w = __builtin_amdgcn_exp2f(part_m[mi] - m);
+    l += w * part_l[mi];
+    acc += *(const f32x4*)(part_o + (((long)s * B + img) * Tq + q) * D + col) * w;
+  }
+  const float inv = 1.0f / l;
+  zh_store_h4(O + (long)img * sO + (long)q * ldo + col, planeO, acc * inv);
+}
+
 static int attention_launch(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                             const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
                             int batch, int heads, int Tq, int Tk, int head_dim, float scale, int causal,
-                            long planeQ, long planeK, long planeV, long planeO, hipStream_t stream) {
+                            long planeQ, long planeK, long planeV, long planeO, hipStream_t stream, int ksplit = 1, void* workspace = nullptr,
+                            size_t workspace_bytes = 0) {
   ZH_CHECK_ARG(Q && K && V && O, "zh_attention_f16: null operand");
   ZH_CHECK_ARG(batch > 0 && heads > 0 && Tq > 0 && Tk > 0, "zh_attention_f16: bad shape");
   ZH_CHECK_ARG(head_dim == 64 || head_dim == 96, "zh_attention_f16: head_dim %d not in {64, 96}", head_dim);
@@ -395,10 +444,22 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   // every shape of the model (encoder 301 vs 423 TF, cross-attention 230 vs 397 TF) and was dropped.
   p.nqb = zh_cdiv(Tq, 128);
   p.groups = heads * batch;
-  const long nblk = (long)zh_cdiv(p.groups, 8) * 8 * p.nqb;  // decoded XCD-aware in the kernel
+  const bool x3 = planeQ != 0;
+  p.ksplit = 1; p.kchunk = 0; p.part_o = p.part_m = p.part_l = nullptr;
+  if (ksplit > 1) {
+    ZH_CHECK_ARG(!causal && ksplit <= 16, "zh_attention_f16_splitk: ksplit %d not in 1..16 (and not for the causal form)", ksplit);
+    const int ktt = x3 ? 32 : 64;
+    p.ksplit = ksplit;
+    p.kchunk = zh_cdiv(zh_cdiv(Tk, ktt), ksplit) * ktt;
+    ZH_CHECK_ARG((long)(ksplit - 1) * p.kchunk < Tk, "zh_attention_f16_splitk: ksplit %d leaves an empty key chunk for Tk = %d", ksplit, Tk);
+    const size_t no = (size_t)ksplit * batch * Tq * heads * head_dim, nm = (size_t)ksplit * batch * heads * Tq;
+    ZH_CHECK_ARG(workspace && workspace_bytes >= (no + 2 * nm) * 4 && ((uintptr_t)workspace & 15) == 0,
+                 "zh_attention_f16_splitk: workspace too small or misaligned (%zu < %zu)", workspace_bytes, (no + 2 * nm) * 4);
+    p.part_o = (float*)workspace; p.part_m = p.part_o + no; p.part_l = p.part_m + nm;
+  }
+  const long nblk = (long)zh_cdiv(p.groups, 8) * 8 * p.nqb * p.ksplit;  // decoded XCD-aware in the kernel
   ZH_CHECK_ARG(nblk < (1L << 31), "zh_attention_f16: grid too large");
   dim3 grid((unsigned)nblk);
-  const bool x3 = planeQ != 0;
   if (head_dim == 64) {
     if (x3) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_f16_kernel<64, 4, 0>), grid, dim3(256), 0, stream, p);
@@ -407,7 +468,28 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
     else hipLaunchKernelGGL((attn_f16_kernel<96, 4, 0>), grid, dim3(256), 0, stream, p);
   }
   ZH_CHECK_LAUNCH("zh_attention_f16");
+  if (p.ksplit > 1) {
+    const long n4 = (long)batch * Tq * heads * head_dim / 4;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)zh_cdiv(n4, 256)), dim3(256), 0, stream, p.part_o, p.part_m, p.part_l, p.O, ldo, strideO,
+                       planeO, p.ksplit, batch, heads, Tq, head_dim);
+    ZH_CHECK_LAUNCH("zh_attention_f16_splitk (combine)");
+  }
   return ZH_OK;
+}
+
+// Keys split over `ksplit` workgroups per (image, head, query block) + one merge launch: for few queries against many keys (the
+// decoder's cross-attention: 100 queries, 1764 keys -> 256 workgroups, ONE per CU, each streaming 1.35 MB of K / V with a single
+// tile of prefetch: bytes in flight bound the kernel at half the HBM rate).  Two workgroups per CU double the bytes in flight.
+extern "C" size_t zh_attention_splitk_workspace_size(int batch, int heads, int Tq, int head_dim, int ksplit) {
+  return ((size_t)ksplit * batch * Tq * heads * head_dim + 2 * (size_t)ksplit * batch * heads * Tq) * 4;
+}
+extern "C" int zh_attention_f16_splitk(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                                       const void* V, long ldv, long strideV, void* O, long ldo, long strideO,
+                                       int batch, int heads, int Tq, int Tk, int head_dim, float scale,
+                                       long planeQ, long planeK, long planeV, long planeO, int ksplit, void* workspace, size_t workspace_bytes,
+                                       hipStream_t stream) {
+  return attention_launch(Q, ldq, strideQ, K, ldk, strideK, V, ldv, strideV, O, ldo, strideO, batch, heads, Tq, Tk, head_dim,
+                          scale, 0, planeQ, planeK, planeV, planeO, stream, ksplit, workspace, workspace_bytes);
 }
 
 extern "C" int zh_attention_f16(const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,

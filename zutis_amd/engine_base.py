@@ -296,6 +296,14 @@ class _EngineBase:
         ff16 = self._abuf("ff16", (R, Ff), xd)
         inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
         out32 = self._buf("dec_out32", (R, D), f32)
+        # cross-attention: Q <= 128 queries against M keys is ONE workgroup per (image, head) — at batch 32 one per CU, each
+        # streaming its K / V with a single tile of prefetch (bytes in flight bound it at half the HBM rate).  The keys are split
+        # over CROSS_KSPLIT workgroups + a merge launch.  A function of (Q, M) only, never of the batch: image i's result must
+        # be bitwise the same alone and inside a batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
+        ksplit = self.CROSS_KSPLIT if (Q <= 128 and M >= 1024) else 1
+        attn_ws = None
+        if ksplit > 1:
+            attn_ws = self._buf("attn_ws", (ops.attention_splitk_workspace_size(B, heads, Q, dh, ksplit),), torch.uint8)
         # `tgt + query_pos` never exists: the row tables of _pack_decoder enter the GEMMs as a row-periodic residual (row m gets
         # table[m % Q], added in fp32 to the finished accumulator, before the one rounding to fp16 / a split pair).  NOT as an
         # accumulator start value (the `pos` form): with large query embeddings the table dwarfs the products and every MFMA
@@ -330,7 +338,7 @@ class _EngineBase:
             self._gemm("dec", tgt_in16, W_[pp + "ca_q_w"], qc16, residual=W_[pp + "ca_q_tab"], res_rows=Q)   # :281-282 query projection
             ops.attention(qc16, KALL.view(KALL.hi[:, l * D:]), VALL.view(VALL.hi[:, l * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=M,
                           head_dim=dh, ldq=D, ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D,
-                          strideO=Q * D, x3=xk)
+                          strideO=Q * D, x3=xk, ksplit=ksplit, workspace=attn_ws)
             self._gemm("dec", o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt_in)
             ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
             self._gemm("dec", tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
@@ -342,5 +350,8 @@ class _EngineBase:
             elif l == L - 1:
                 ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16, out_f32=out32)
         return inter16
+
+    import os as _os
+    CROSS_KSPLIT = int(_os.environ.get("ZH_CROSS_KSPLIT", "2"))     # developer override, read once at import
 
     _dec_out_sites = ("ffn2",)   # sites consuming the decoder's normed outputs (ZUTIS: ffn2; SelfMask: mask einsum + objectness MLP)

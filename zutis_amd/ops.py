@@ -184,9 +184,15 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, bias=None, residua
     return out_ret
 
 
+def attention_splitk_workspace_size(batch, heads, Tq, head_dim, ksplit) -> int:
+    return int(_lib.load(raw=True).zh_attention_splitk_workspace_size(batch, heads, Tq, head_dim, ksplit))
+
+
 def attention(Q, K, V, O, *, batch, heads, Tq, Tk, head_dim, ldq, ldk, ldv, ldo, strideQ, strideK, strideV, strideO,
-              scale=None, causal=False, x3=False):
-    """x3: Q, K and V are split-pair Acts; scores and P.V get the three-product fp32-class form; a split O is filled as a pair."""
+              scale=None, causal=False, x3=False, ksplit: int = 1, workspace=None):
+    """x3: Q, K and V are split-pair Acts; scores and P.V get the three-product fp32-class form; a split O is filled as a pair.
+    ksplit > 1: the keys are split over ksplit workgroups per (image, head, query block) and merged by a second launch; workspace =
+    a uint8 CUDA tensor of attention_splitk_workspace_size() bytes."""
     L = _lib.load()
     scale = 1.0 / math.sqrt(head_dim) if scale is None else scale
     (Q, pq), (K, pk), (V, pv), (O, po) = _hp(Q), _hp(K), _hp(V), _hp(O)
@@ -202,6 +208,16 @@ def attention(Q, K, V, O, *, batch, heads, Tq, Tk, head_dim, ldq, ldk, ldv, ldo,
                 batch, heads, Tq, head_dim, float(scale), pq, pk, pv, po, _stream())
         _lib.check(_launch(name, 2.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_causal_f16(*args)),
                    "zh_attention_causal_f16")
+        return O
+    if ksplit > 1:
+        need = attention_splitk_workspace_size(batch, heads, Tq, head_dim, ksplit)
+        if workspace is None or workspace.numel() * workspace.element_size() < need:
+            raise _lib.ZutisHipError(f"attention(ksplit={ksplit}): workspace of {need} bytes required")
+        args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
+                batch, heads, Tq, Tk, head_dim, float(scale), pq, pk, pv, po, ksplit, _p(workspace),
+                workspace.numel() * workspace.element_size(), _stream())
+        _lib.check(_launch(name, 4.0 * batch * heads * Tq * Tk * head_dim, lambda: L.zh_attention_f16_splitk(*args)),
+                   "zh_attention_f16_splitk")
         return O
     args = (_p(Q), ldq, strideQ, _p(K), ldk, strideK, _p(V), ldv, strideV, _p(O), ldo, strideO,
             batch, heads, Tq, Tk, head_dim, float(scale), pq, pk, pv, po, _stream())
