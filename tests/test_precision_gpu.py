@@ -321,7 +321,7 @@ def test_attention_x3_scores(dev, dh, heads, Tq, Tk, causal):
 
 
 @pytest.mark.parametrize("x3", [True, False])
-@pytest.mark.parametrize("dh,heads,Tq,Tk,S", [(96, 8, 100, 1764, 2), (96, 2, 100, 1764, 3), (64, 3, 130, 1000, 4), (96, 1, 20, 5504, 16)])
+@pytest.mark.parametrize("dh,heads,Tq,Tk,S", [(96, 8, 100, 1764, 2), (96, 2, 100, 1764, 3), (64, 3, 130, 1000, 4), (96, 1, 20, 5504, 8)])
 def test_attention_key_split_matches_unsplit(dev, dh, heads, Tq, Tk, S, x3):
     """zh_attention_f16_splitk (keys split over S workgroups + merge launch) against the single-pass kernel and float64: the
     merge is the online-softmax rescale, so the result differs from the unsplit one only by fp32 reassociation."""

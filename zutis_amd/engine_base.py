@@ -297,9 +297,12 @@ class _EngineBase:
         inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
         out32 = self._buf("dec_out32", (R, D), f32)
         # cross-attention: Q <= 128 queries against M keys is ONE workgroup per (image, head) — at batch 32 one per CU, each
-        # streaming its K / V with a single tile of prefetch (bytes in flight bound it at half the HBM rate).  The keys are split
-        # over CROSS_KSPLIT workgroups + a merge launch.  A function of (Q, M) only, never of the batch: image i's result must
-        # be bitwise the same alone and inside a batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
+        # streaming its K / V with a single tile of prefetch (bytes in flight bound it at half the HBM rate).  The keys CAN be split
+        # over CROSS_KSPLIT workgroups + a merge launch (zh_attention_f16_splitk): measured in round 3, the attention kernels of an
+        # instrumented one-stream step run 172 -> 187 TFLOP/s with a split of 2, but the step with three batches in flight does not
+        # move (2854 / 2848 / 2844 / 2839 images/s for splits 1 / 2 / 3 / 4: the other lanes' GEMMs already fill the memory stalls),
+        # so the default is 1.  When used it must stay a function of (Q, M) only, never of the batch: image i's result has to be
+        # bitwise the same alone and inside a batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
         ksplit = self.CROSS_KSPLIT if (Q <= 128 and M >= 1024) else 1
         attn_ws = None
         if ksplit > 1:
@@ -352,6 +355,6 @@ class _EngineBase:
         return inter16
 
     import os as _os
-    CROSS_KSPLIT = int(_os.environ.get("ZH_CROSS_KSPLIT", "2"))     # developer override, read once at import
+    CROSS_KSPLIT = int(_os.environ.get("ZH_CROSS_KSPLIT", "1"))     # developer override, read once at import
 
     _dec_out_sites = ("ffn2",)   # sites consuming the decoder's normed outputs (ZUTIS: ffn2; SelfMask: mask einsum + objectness MLP)
