@@ -7,7 +7,7 @@ from zutis_amd import ops
 from zutis_amd.ops import Act
 dev = torch.device("cuda:0")
 shapes = [(14144, 2304, 768, "qkv", "split"), (14144, 768, 768, "out", "f32"), (14144, 3072, 768, "fc", "split"), (14144, 768, 3072, "proj", "f32"),
-          (56448, 4608, 256, "kv-all", "split"), (3200, 768, 768, "dec768", "split"), (3200, 2048, 768, "dec l1", "split"), (8192, 8192, 8192, "8k", "f32")]
+          (56448, 4608, 256, "kv-all", "split"), (3200, 768, 768, "dec768", "split"), (3200, 2048, 768, "dec l1", "split"), (3200, 768, 768, "dec768f", "f32"), (3200, 768, 2048, "dec l2", "f32"), (8192, 8192, 8192, "8k", "f32")]
 def t(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()

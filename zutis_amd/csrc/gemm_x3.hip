@@ -97,8 +97,15 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
     if (cbig < cur && cbig <= c448) pick = 512;
     else if (c448 < cur) pick = 448;
   }
+  // few-row GEMMs whose 128 x 64 tiling is a bit more than one tile per CU (the decoder's 3200 x 768: 300 tiles — the CUs with two
+  // tiles stream 1.2 MB of operands at the ~61 GB/s a CU's LDS-DMA sustains = 19 us, and that is the kernel): 128 x 96 tiles
+  // (4 waves of 64 x 48, 3-slot ring, one block per CU) make it 200 tiles of 0.69 MB, ONE per CU
+  if (pick == 64 && M <= 4096 && N % 96 == 0) {
+    const long t64 = (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch, t96 = (long)zh_cdiv(M, 128) * (N / 96) * batch;
+    if (t64 > 256 && t96 <= 256) pick = 96;
+  }
   const int forced = gemm_dev_overrides().tile;
-  if (forced == 64 || forced == 192 || forced == 256 || forced == 512 || forced == 448) pick = forced;
+  if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448) pick = forced;
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
   if ((pick == 512 || pick == 448) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
   bool ok;
@@ -108,6 +115,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   else if (pick == 448) ok = launch_x3<2, 4, 6, 4, 2, 2>(p, batch, out_kind, stream);
   else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
+  else if (pick == 96) ok = launch_x3<2, 2, 4, 3, 3, 2>(p, batch, out_kind, stream);
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16x3");
