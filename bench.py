@@ -240,6 +240,7 @@ def bench_c5(args):
         parity = {"embedding_max_abs_err": float((got - ref).abs().max()), "tolerance": 1e-3,
                   "against": "fp32 oracle on the same %d images (unit-norm embeddings)" % ns}
     if world > 1:
+        dist.barrier()                    # rank 0 measured the roofline after the timed region: leave together
         dist.destroy_process_group()
     if rank == 0:
         total = world * B * args.steps
@@ -554,6 +555,7 @@ def main():
             if other is not None:
                 line["second_precision"]["vs_torch_gpu_fp32_eager"] = round(other["value"] / torch_gpu["value"], 2)
     if dist_on:
+        dist.barrier()                    # rank 0 measured the roofline / baselines after the timed region: leave together
         dist.destroy_process_group()      # first: RCCL prints its version banner on stdout when the communicator goes away
     if rank == 0:
         import ctypes
