@@ -24,6 +24,7 @@ Reference call sites are cited per step (paths relative to the reference root).
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -354,7 +355,6 @@ class _EngineBase:
                 ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16, out_f32=out32)
         return inter16
 
-    import os as _os
-    CROSS_KSPLIT = int(_os.environ.get("ZH_CROSS_KSPLIT", "1"))     # developer override, read once at import
+    CROSS_KSPLIT = int(os.environ.get("ZH_CROSS_KSPLIT", "1"))      # developer override, read once at import
 
     _dec_out_sites = ("ffn2",)   # sites consuming the decoder's normed outputs (ZUTIS: ffn2; SelfMask: mask einsum + objectness MLP)
