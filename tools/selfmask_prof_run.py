@@ -6,9 +6,10 @@ import torch
 from zutis_amd import detgen, pseudo_masks
 from zutis_amd.engine import SelfMaskEngine
 dev = torch.device("cuda:0")
-eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()})
 H, W = 512, 683
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+PREC = sys.argv[2] if len(sys.argv) > 2 else "exact"
+eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()}, precision=PREC)
 x = torch.from_numpy(detgen.images(B, H, W, seed=7)).to(dev)
 for _ in range(2):
     pseudo_masks.pseudo_masks_batch(eng, x, [(480, 640)] * B, True)
@@ -18,4 +19,4 @@ for _ in range(5):
     pseudo_masks.pseudo_masks_batch(eng, x, [(480, 640)] * B, True)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 5
-print(f"SelfMask + solver + resize, batch {B} @ {H}x{W}: {dt*1e3:.2f} ms per batch, {B/dt:.1f} images/s (device side)")
+print(f"[{PREC}] SelfMask + solver + resize, batch {B} @ {H}x{W}: {dt*1e3:.2f} ms per batch, {B/dt:.1f} images/s (device side)")
