@@ -159,10 +159,12 @@ def test_gemm_x3_batched_activation_operands(dev):
 def test_gemm_x3_race_screen_bitwise_repeatable(dev):
     """The x3 K loop is a 3-slot LDS-DMA ring with counted vmcnt waits: a mis-counted wait shows up as rare wrong tiles."""
     from zutis_amd import ops
-    for (M, N, K) in [(3000, 2304, 768), (1500, 768, 3072), (700, 640, 192), (300, 200, 64), (5000, 512, 128)]:
+    # M >= 4096 reaches the two-slot 256x256 / 192x256 tiles (barrier + LDS-DMA into the slot just read: lgkmcnt(0) before it)
+    for (M, N, K) in [(3000, 2304, 768), (1500, 768, 3072), (700, 640, 192), (300, 200, 64), (5000, 512, 128), (4500, 2304, 768),
+                      (4200, 768, 3072), (4100, 4608, 256), (3200, 768, 768)]:
         A, W = _split_act(_randn((M, K), 100 + M), dev), ops.split_weight(_randn((N, K), 200 + N, 0.05).to(dev))
         outs = []
-        for _ in range(6):
+        for _ in range(12):
             o = torch.empty((M, N), dtype=f32, device=dev)
             ops.gemm_x3(A, W, o)
             outs.append(o)
