@@ -122,9 +122,14 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   float m_run = -INFINITY;
   // Row sums of P ride the MFMA pipe: one extra "d tile" whose V^T operand is all ones accumulates sum_k P[k][q] in every row
   // of lacc (32 v_add_f32 per key tile leave the VALU, which is the bound; the sum is of the SAME rounded P the numerator uses).
+  // Split-pair kernels (X3) keep the row sum on the VALU instead: they are MFMA-bound (three products per score and per P.V
+  // element), the ones-operand tile is 4 of their 28 MFMAs per key tile, and P = hi + lo carries 22 bits, so the fp32 sum of the
+  // un-rounded exponentials is the same number to 2^-22 — l_run accumulates this lane's 16 keys per tile (v_pk_add_f32), the
+  // two key halves (lanes l, l ^ 32) meet once at the end.
   f32x16 lacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  float l_run = 0.f;
   half8_t ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (half_t)1.0f;
@@ -246,6 +251,8 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     // P as packed fp16 pairs: register (r >> 1) & 3 of fragment r >> 3 holds scores r, r + 1 — the MFMA B operand as is
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 pfu[NU][2], plu[X3 ? NU : 1][2];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 lsum2 = {0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
         const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], p.scale_log2, -m_new));
         const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r + 1], p.scale_log2, -m_new));
 #endif
+        if (X3) { lsum2[0] += e0; lsum2[1] += e1; }
         const half2_t eh2 = {(half_t)e0, (half_t)e1};      // one v_cvt_pk_f16_f32
         unsigned eh = __builtin_bit_cast(unsigned, eh2);
         if (X3) {
@@ -283,21 +291,23 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
       for (int d = 0; d < NDT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      if (!X3) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+        for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+      }
     }
+    if (X3) l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
 
     // ---- O^T += V^T P^T
 #if ZH_ATTN_ABL & 2
     oacc[0][0] += (float)pf[0][0][0] + (float)pf[NU - 1][1][7] + (float)pf[0][1][3] + (float)pf[NU - 1][0][5];
-    lacc[0] += 1.0f;
+    lacc[0] += 1.0f; l_run += 1.0f;
 #else
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[u][ks], lacc, 0, 0, 0);
-        if (X3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pl[u][ks], lacc, 0, 0, 0);
+        if (!X3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[u][ks], lacc, 0, 0, 0);
         const half_t* vp = sV + (32 * u + 16 * ks + tr_row) * VS + tr_col;
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
@@ -360,7 +370,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   }
 #endif
 
-  // every row of lacc holds the full row sum of this lane's query (the MFMA already summed both key halves)
+  // f16: every row of lacc holds the full row sum of this lane's query (the MFMA already summed both key halves);
+  // split pairs: this lane's half of the keys + the other half's (lane ^ 32)
+  const float l_row = X3 ? l_run + __shfl_xor(l_run, 32, 64) : lacc[0];
   const int qr = q0 + ql;
   if (p.ksplit > 1) {                                   // partial result of this key chunk: unnormalised O, running max, row sum
     if (qr < p.Tq) {
@@ -373,12 +385,12 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
       if (hh == 0) {
         const long mi = ((long)ks * p.groups + group) * p.Tq + qr;
         p.part_m[mi] = m_run;
-        p.part_l[mi] = lacc[0];
+        p.part_l[mi] = l_row;
       }
     }
     return;
   }
-  const float inv = 1.0f / lacc[0];
+  const float inv = 1.0f / l_row;
   if (qr < p.Tq) {
     half_t* op = p.O + (long)img * p.sO + (long)qr * p.ldo + hoff + 4 * hh;
 #pragma unroll
