@@ -199,6 +199,16 @@ def test_selfmask_engine_vs_reference_golden(dev, golden_dir, precision, t_obj, 
         got = inf["dts"].cpu().numpy().astype(bool)
         assert got.shape == (b, H, W)
         assert (got != ref).mean() <= t_dts, (got != ref).mean()
+        # and every differing pixel is explained: the oracle's own upsampled probability of the selected query lies within the
+        # measured mask error of the 0.5 threshold there (x4 bilinear is a convex combination of mask_pred values)
+        from oracle import selfmask_ref as S, zutis_ref as O
+        with torch.no_grad():
+            dts_o, idx_o, up_o = S.selfmask_inference(O.to_torch_params(detgen.selfmask_state_dict()), x.cpu())
+        assert np.array_equal(np.stack(dts_o).astype(bool), ref)            # the oracle reproduces the reference's masks exactly
+        if np.array_equal(inf["index"].cpu().numpy(), idx_o):
+            sel = np.stack([up_o[i, idx_o[i]] for i in range(b)])
+            unexplained = int(((got != ref) & (np.abs(sel - 0.5) > e_mask + 2e-6)).sum())
+            assert unexplained == 0, (tag, precision, unexplained, int((got != ref).sum()))
 
 
 @pytest.mark.parametrize("precision,t_obj,t_mask", [("exact", 2e-5, 4e-4), ("fast", 2e-3, 2e-2)])
