@@ -342,6 +342,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 #pragma unroll
       for (int t = 0; t < TN; ++t) fw[TN + t] = *(const half8_t*)(rdW + so + (BN + t * 16) * BK);
     };
+    // (Measured and not kept, round 3: the two waves of a SIMD taking their DMA issues at different points of the slice — waves
+    //  4 .. 7 after the hi * hi sweep — so that one feeds the MFMA pipe while the other sits in its ~1000 cycles of issue stalls:
+    //  QKV 147 -> 153 us, c_fc 189 -> 195, K / V 479 -> 488.  The later issue costs the landing time it was meant to hide.)
     auto body = [&](int slot, bool prefetch) {
       const int so = slot * STAGE_HALVES;
 #ifndef ZH_X3_NOBAR
