@@ -85,7 +85,10 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // (Measured and not kept, round 3: a 128 x 128 two-slot tile at TWO blocks per CU, so that one block's epilogue overlaps the
   //  other's K loop — K / V 514 us against 454 for 256 x 256: the extra staged bytes per MFMA cost more than the overlap gives;
   //  and starting the first wave of tiles out of phase — no change: the K = 256 projections write their 1.04 GB at the rate a
-  //  pure store kernel reaches for any store shape, 5.4 - 5.8 TB/s (tools/micro/store_pattern.hip), only not while MFMAs run.)
+  //  pure store kernel reaches for any store shape, 5.4 - 5.8 TB/s (tools/micro/store_pattern.hip), only not while MFMAs run.
+  //  Also timed and not kept: weights read as if packed slice-major [K/32][N][32] (every W piece one contiguous KiB instead of 16
+  //  half lines: c_proj 175 -> 168 us, QKV / c_fc / K / V within the noise), `s_setprio` around the MFMA sweeps (-20 %) and a
+  //  static priority difference between the two waves of a SIMD (no change).)
   const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
   const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
   const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
