@@ -41,7 +41,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PRECISION_DTYPE = {"fast": "f16", "exact": "f16x3", "f16": "f16"}
+# arithmetic type of the contractions: "f16x3" = fp16 split pairs (hi + lo, 22 significand bits), three MFMA products per fp32
+# accumulator — the reference's fp32 arithmetic class; "f16" = fp16 MFMA operands (narrower than the reference)
+PRECISION_DTYPE = {"fast": "f16", "exact": "f16x3 (fp32-class)", "f16": "f16"}
 PRECISION_TEXT = {
     "fast": "fp16 MFMA operands / fp32 accumulate in the transformer bodies, fp32 residual stream + LayerNorm + softmax; the "
             "output-facing contractions (ffn1, ffn2, mask einsum, text-space projection, class logits) in the f16x3 mode",
