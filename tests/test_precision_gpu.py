@@ -118,7 +118,7 @@ def test_gemm_x3_pos_tables(dev, N):
     assert float((both.cpu().double() - ref).abs().max()) < tol
 
 
-@pytest.mark.parametrize("tile", [64, 96, 192, 256, 448, 512])
+@pytest.mark.parametrize("tile", [64, 96, 192, 256, 448, 512, 3064])
 @pytest.mark.parametrize("hh,ww", [(12, 20), (52, 80)])
 def test_gemm_x3_pos_tables_every_tile(dev, tile, hh, ww):
     """The pos tables under every x3 tile, on both table paths: the slice staged through the free ring slot (small images)
@@ -204,7 +204,7 @@ def test_gemm_x3_row_periodic_table_before_rounding(dev, kind):
     assert float((got - ref).abs().max()) < tol, float((got - ref).abs().max())
 
 
-@pytest.mark.parametrize("tile", [64, 96, 192, 256, 512, 448])
+@pytest.mark.parametrize("tile", [64, 96, 192, 256, 512, 448, 3064])
 def test_gemm_x3_every_tile_variant(dev, tile):
     """Every x3 tile (128x64, 192x128, 256x128 on the 3-slot ring; 256x256 on the two-slot ring with the SGPR-base LDS-DMA and
     the in-place A lo fragments), forced through zh_dev_set_gemm_overrides, over K = 64 .. 1024 (every prologue / steady / tail

@@ -107,8 +107,12 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
     const long t64 = (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch, t96 = (long)zh_cdiv(M, 128) * (N / 96) * batch;
     if (t64 > 256 && t96 <= 256) pick = 96;
   }
+  // few-tile GEMMs (batch-1 inference, the COCO-20K evaluation's regime: M = 442 tokens -> 48 .. 192 tiles of 128 x 64 on 256 CUs):
+  // they are bound by the load latency of a 3-slot ring, not by arithmetic — 64 x 64 tiles on a 6-deep ring put more CUs to
+  // work and keep five slices in flight (the fp16 kernel's `3064` tile, for the split-pair operands)
+  if (pick == 64 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch <= 200) pick = 3064;
   const int forced = gemm_dev_overrides().tile;
-  if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448) pick = forced;
+  if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448 || forced == 3064) pick = forced;
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
   if ((pick == 512 || pick == 448) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
   bool ok;
@@ -119,6 +123,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 96) ok = launch_x3<2, 2, 4, 3, 3, 2>(p, batch, out_kind, stream);
+  else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, 6, 2>(p, batch, out_kind, stream);   // 64 x 64, 6-deep ring
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16x3");

@@ -297,13 +297,13 @@ class _EngineBase:
         ff16 = self._abuf("ff16", (R, Ff), xd)
         inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
         out32 = self._buf("dec_out32", (R, D), f32)
-        # cross-attention: Q <= 128 queries against M keys is ONE workgroup per (image, head) — at batch 32 one per CU, each
-        # streaming its K / V with a single tile of prefetch (bytes in flight bound it at half the HBM rate).  The keys CAN be split
-        # over CROSS_KSPLIT workgroups + a merge launch (zh_attention_f16_splitk): measured in round 3, the attention kernels of an
-        # instrumented one-stream step run 172 -> 187 TFLOP/s with a split of 2, but the step with three batches in flight does not
-        # move (2854 / 2848 / 2844 / 2839 images/s for splits 1 / 2 / 3 / 4: the other lanes' GEMMs already fill the memory stalls),
-        # so the default is 1.  When used it must stay a function of (Q, M) only, never of the batch: image i's result has to be
-        # bitwise the same alone and inside a batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
+        # cross-attention: Q <= 128 queries against M keys is ONE workgroup per (image, head): 8 workgroups at batch 1 (the COCO-20K
+        # evaluation's regime), 256 at batch 32 (one per CU, each streaming its K / V with a single tile of prefetch).  The keys are
+        # split over CROSS_KSPLIT workgroups + a merge launch (zh_attention_f16_splitk).  Measured (round 3): batch-1 forward +
+        # predict 2.99 / 2.73 / 2.60 / 2.54 ms for splits 1 / 2 / 4 / 8; the batch-32 step with three batches in flight 2854 / 2848 /
+        # 2844 / 2839 images/s for 1 / 2 / 3 / 4 (the partials' round trip costs what the extra occupancy gives there).  The split
+        # must be a function of (Q, M) only, never of the batch — image i's result has to be bitwise the same alone and inside a
+        # batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size) — so ONE value serves both regimes: 2.
         ksplit = self.CROSS_KSPLIT if (Q <= 128 and M >= 1024) else 1
         attn_ws = None
         if ksplit > 1:
@@ -355,6 +355,6 @@ class _EngineBase:
                 ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16, out_f32=out32)
         return inter16
 
-    CROSS_KSPLIT = int(os.environ.get("ZH_CROSS_KSPLIT", "1"))      # developer override, read once at import
+    CROSS_KSPLIT = int(os.environ.get("ZH_CROSS_KSPLIT", "2"))      # developer override, read once at import
 
     _dec_out_sites = ("ffn2",)   # sites consuming the decoder's normed outputs (ZUTIS: ffn2; SelfMask: mask einsum + objectness MLP)
