@@ -538,7 +538,7 @@ def main():
                                    f"predict(semantic,size=({S},{S}))", "global_batch": world * B, "image_size": S,
                        "n_classes": n, "parallelism": f"dp{world}", "accumulate": "f32", "residual_stream": "f32",
                        "collective": "all_gather(low-res logits) per step, overlapped" if dist_on else "none",
-                       "steps_in_flight": n_lanes, **({"input": "pinned host batch copied in every step (--h2d)"} if args.h2d else {}),
+                       "steps_in_flight": n_lanes, "cross_attention_key_split": ZutisEngine.cross_ksplit, **({"input": "pinned host batch copied in every step (--h2d)"} if args.h2d else {}),
                        "launch": ("native launch plans, interleaved on %d HIP streams" % n_lanes) if n_lanes > 1 else "eager, 1 stream",
                        "flops_per_image": FLOPS_PER_IMAGE_C2 if (S, n) == (336, 81) else None},
             "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1) if (S, n) == (336, 81) else None,

@@ -22,6 +22,7 @@ def timeit(fn):
 
 
 eng = ZutisEngine(sd, cfg.patch, cfg.dec_heads)
+eng.cross_ksplit = int(os.environ.get("ZH_CROSS_KSPLIT", "2"))     # the drop-in modules' setting (they serve batch-1 loops)
 def eager():
     o = eng.forward(x); return eng.predict_semantic(o["patch_tokens"], text, (336, 336))
 ms = timeit(eager); print(f"B={B} eager        {ms:.3f} ms  {B / ms * 1e3:.0f} img/s")

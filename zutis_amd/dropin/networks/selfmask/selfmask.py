@@ -96,6 +96,7 @@ class SelfMask(nn.Module):
         self.scale_factor = scale_factor
         self._engine = None
         self.precision: str = "exact"             # "fast" | "exact" | "f16" (zutis_amd.engine)
+        self.cross_attention_key_split: int = 2      # engine_base._decoder: this module serves batch-1 evaluation loops
 
     def _get_engine(self) -> SelfMaskEngine:
         if self._engine is not None and self._engine.precision != self.precision:
@@ -103,6 +104,7 @@ class SelfMask(nn.Module):
         if self._engine is None:
             self._engine = SelfMaskEngine(dict(self.named_parameters()), self.encoder.patch_size, self.encoder.n_heads,
                                           precision=self.precision)
+            self._engine.cross_ksplit = self.cross_attention_key_split      # batch-1 evaluation loops: see engine_base._decoder
         return self._engine
 
     def _apply(self, fn, *args, **kwargs):

@@ -204,6 +204,7 @@ class ZUTIS(nn.Module):
         self._engine: Optional[ZutisEngine] = None
         # "fast" | "exact" | "f16" (zutis_amd.engine): exact = every contraction in the reference-equivalent f16x3 mode
         self.precision: str = "exact"
+        self.cross_attention_key_split: int = 2      # engine_base._decoder: this module serves batch-1 evaluation loops
         self.use_hip_graph: bool = False       # opt-in: forward() of batches <= 4 replays a hipGraph captured per input shape
 
     # ------------------------------------------------------------------ plumbing
@@ -213,6 +214,7 @@ class ZUTIS(nn.Module):
         if self._engine is None:
             self._engine = ZutisEngine(dict(self.named_parameters()), self.encoder.patch_size, self.n_heads,
                                        precision=self.precision)
+            self._engine.cross_ksplit = self.cross_attention_key_split      # batch-1 evaluation loops: see engine_base._decoder
         return self._engine
 
     def _apply(self, fn, *args, **kwargs):

@@ -298,13 +298,14 @@ class _EngineBase:
         inter16 = self._abuf("inter16", (B * (L if stack_all else 1) * Q, D), self._x3(*self._dec_out_sites))
         out32 = self._buf("dec_out32", (R, D), f32)
         # cross-attention: Q <= 128 queries against M keys is ONE workgroup per (image, head): 8 workgroups at batch 1 (the COCO-20K
-        # evaluation's regime), 256 at batch 32 (one per CU, each streaming its K / V with a single tile of prefetch).  The keys are
-        # split over CROSS_KSPLIT workgroups + a merge launch (zh_attention_f16_splitk).  Measured (round 3): batch-1 forward +
-        # predict 2.99 / 2.73 / 2.60 / 2.54 ms for splits 1 / 2 / 4 / 8; the batch-32 step with three batches in flight 2854 / 2848 /
-        # 2844 / 2839 images/s for 1 / 2 / 3 / 4 (the partials' round trip costs what the extra occupancy gives there).  The split
-        # must be a function of (Q, M) only, never of the batch — image i's result has to be bitwise the same alone and inside a
-        # batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size) — so ONE value serves both regimes: 2.
-        ksplit = self.CROSS_KSPLIT if (Q <= 128 and M >= 1024) else 1
+        # evaluation's regime), 256 at batch 32 (one per CU, each streaming its K / V with a single tile of prefetch).  The keys can be
+        # split over `self.cross_ksplit` workgroups + a merge launch (zh_attention_f16_splitk).  Measured (round 3): batch-1 forward
+        # + predict 2.99 / 2.73 / 2.60 / 2.54 ms for splits 1 / 2 / 4 / 8; the batch-32 step with three batches in flight loses
+        # 0.3 - 1 % with a split of 2 (2825 / 2842 against 2852 / 2851 images/s, same box: the partials' round trip costs more than
+        # the extra occupancy gives there).  The split is a property of the ENGINE INSTANCE (throughput: 1, the engine's default
+        # and what bench.py runs; the drop-in modules set 2, they serve batch-1 evaluation loops) and never of the batch — image
+        # i's result is bitwise the same alone and inside a batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
+        ksplit = self.cross_ksplit if (Q <= 128 and M >= 1024) else 1
         attn_ws = None
         if ksplit > 1:
             attn_ws = self._buf("attn_ws", (ops.attention_splitk_workspace_size(B, heads, Q, dh, ksplit),), torch.uint8)
@@ -355,6 +356,6 @@ class _EngineBase:
                 ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16, out_f32=out32)
         return inter16
 
-    CROSS_KSPLIT = int(os.environ.get("ZH_CROSS_KSPLIT", "2"))      # developer override, read once at import
+    cross_ksplit = int(os.environ.get("ZH_CROSS_KSPLIT", "1"))      # class default (env = developer override); instances may set it
 
     _dec_out_sites = ("ffn2",)   # sites consuming the decoder's normed outputs (ZUTIS: ffn2; SelfMask: mask einsum + objectness MLP)
