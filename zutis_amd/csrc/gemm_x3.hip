@@ -110,7 +110,9 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // few-tile GEMMs (batch-1 inference, the COCO-20K evaluation's regime: M = 442 tokens -> 48 .. 192 tiles of 128 x 64 on 256 CUs):
   // they are bound by the load latency of a 3-slot ring, not by arithmetic — 64 x 64 tiles on a 6-deep ring put more CUs to
   // work and keep five slices in flight (the fp16 kernel's `3064` tile, for the split-pair operands)
-  if (pick == 64 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch <= 200) pick = 3064;
+  // (only while the 64 x 64 tiles still fit ONE round of the chip, one block per CU: c_fc at M = 442 is 336 such tiles and ran
+  //  18.3 -> 23.6 us with them)
+  if (pick == 64 && (long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch <= 256) pick = 3064;
   const int forced = gemm_dev_overrides().tile;
   if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448 || forced == 3064) pick = forced;
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
