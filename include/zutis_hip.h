@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 212 /* 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 213 /* 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -205,9 +205,11 @@ int zh_confusion_hist(const long long* label_true, const long long* label_pred, 
 int zh_instance_mask_stats(const float* mask_proposals, long stride_image, float threshold, int B, int Q, int M,
                            float* sizes, float* confidence, unsigned char* binary, zh_stream_t stream);
 /* avg[b,q,:] = sum_m binary[b,q,m]*tokens[b,m,:] / (size+1e-7)  (zutis.py:404-406; the reference materialises
- * B x Q x hw x E). */
+ * B x Q x hw x E).  Pixels are processed in chunks of 128 by separate workgroups; per-chunk partial sums go through `workspace`
+ * (zh_masked_mean_workspace_size bytes) and are added in chunk order. */
+size_t zh_masked_mean_workspace_size(int B, int Q, int M, int E);
 int zh_masked_mean_tokens(const float* tokens, const unsigned char* binary, const float* sizes, float* avg,
-                          int B, int Q, int M, int E, zh_stream_t stream);
+                          int B, int Q, int M, int E, void* workspace, size_t workspace_bytes, zh_stream_t stream);
 /* category = argmax_n sigmoid(T * text_n . avg/(||avg||+1e-7)); score = confidence * max  (zutis.py:409-420). */
 int zh_instance_classify(const float* avg, const float* text, const float* confidence, float temperature,
                          int rows, int n_classes, int E, long long* category, float* score, zh_stream_t stream);

@@ -62,7 +62,8 @@ _SIGS = {
     "zh_rle_encode_host": (C.c_long, [_vp, _i, _i, _vp, C.c_long]),
     "zh_resize_nearest_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "zh_instance_mask_stats": (_i, [_vp, _l, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "zh_masked_mean_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "zh_masked_mean_workspace_size": (_sz, [_i, _i, _i, _i]),
+    "zh_masked_mean_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "zh_instance_classify": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "zh_denormalize_u8": (_i, [_vp, _vp, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "zh_bgrid_coords": (_i, [_vp, _i, _i, _d, _d, _d, _vp, _vp]),

@@ -36,62 +36,80 @@ extern "C" int zh_instance_mask_stats(const float* mask_proposals, long stride_i
 }
 
 // ---- avg[b,q,:] = sum_m binary[b,q,m] * tokens[b,m,:] / (size[b,q] + 1e-7)   (zutis.py:404-406)
-// block = (image, tile of QT queries); thread owns CPT channels; masks of the tile are staged in LDS by chunks.
+// block = (tile of QT queries, image, chunk of MCH pixels); thread owns CPT channels; the tile's mask bytes of the chunk are
+// staged in LDS.  Per-chunk partial sums go to the workspace [chunks][B*Q][E] and masked_mean_reduce_kernel adds them in chunk
+// order (deterministic, independent of the batch) and divides.  (Round 3: the first version walked ALL pixels in one block per
+// (query tile, image) — 10 blocks at batch 1, the COCO-20K evaluation's regime, 4800 dependent iterations: 1.8 ms of the
+// 3.5 ms instance predict.)
 #define QT 10
-#define MCH 512
+#define MCH 128
 template <int CPT>
-__global__ __launch_bounds__(256) void masked_mean_kernel(const float* tokens, const unsigned char* binary, const float* sizes,
-                                                          float* avg, int Q, int M, int E) {
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float* tokens, const unsigned char* binary, float* partial, int Q, int M, int E,
+                                                          long rows) {
   __shared__ unsigned char sm[QT][MCH];
-  const int b = blockIdx.y, q0 = blockIdx.x * QT;
-  const int nq = min(QT, Q - q0);
+  const int b = blockIdx.y, q0 = blockIdx.x * QT, m0 = blockIdx.z * MCH;
+  const int nq = min(QT, Q - q0), mc = min(MCH, M - m0);
   const float* tk = tokens + (long)b * M * E;
   float acc[QT][CPT];
 #pragma unroll
   for (int q = 0; q < QT; ++q)
 #pragma unroll
     for (int c = 0; c < CPT; ++c) acc[q][c] = 0.f;
-  for (int m0 = 0; m0 < M; m0 += MCH) {
-    const int mc = min(MCH, M - m0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < QT * MCH; i += 256) {
-      const int q = i / MCH, m = i - q * MCH;
-      sm[q][m] = (q < nq && m < mc) ? binary[((long)b * Q + q0 + q) * M + m0 + m] : 0;
-    }
-    __syncthreads();
-    for (int m = 0; m < mc; ++m) {
-      float v[CPT];
-#pragma unroll
-      for (int c = 0; c < CPT; ++c) {
-        const int ch = threadIdx.x + 256 * c;
-        v[c] = ch < E ? tk[(long)(m0 + m) * E + ch] : 0.f;
-      }
-#pragma unroll
-      for (int q = 0; q < QT; ++q) {
-        const float f = sm[q][m] ? 1.f : 0.f;
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) acc[q][c] += f * v[c];
-      }
-    }
+  for (int i = threadIdx.x; i < QT * MCH; i += 256) {
+    const int q = i / MCH, m = i - q * MCH;
+    sm[q][m] = (q < nq && m < mc) ? binary[((long)b * Q + q0 + q) * M + m0 + m] : 0;
   }
-  for (int q = 0; q < nq; ++q) {
-    const float inv = 1.0f / (sizes[(long)b * Q + q0 + q] + 1e-7f);
+  __syncthreads();
+  for (int m = 0; m < mc; ++m) {
+    float v[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int ch = threadIdx.x + 256 * c;
-      if (ch < E) avg[((long)b * Q + q0 + q) * E + ch] = acc[q][c] * inv;
+      v[c] = ch < E ? tk[(long)(m0 + m) * E + ch] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const float f = sm[q][m] ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) acc[q][c] += f * v[c];
     }
   }
+  float* po = partial + ((long)blockIdx.z * rows + (long)b * Q + q0) * E;
+  for (int q = 0; q < nq; ++q)
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int ch = threadIdx.x + 256 * c;
+      if (ch < E) po[(long)q * E + ch] = acc[q][c];
+    }
+}
+__global__ __launch_bounds__(256) void masked_mean_reduce_kernel(const float* partial, const float* sizes, float* avg, long rows, int E, int chunks) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * E) return;
+  float s = 0.f;
+  for (int z = 0; z < chunks; ++z) s += partial[(long)z * rows * E + i];
+  avg[i] = s * (1.0f / (sizes[i / E] + 1e-7f));
 }
 
+extern "C" size_t zh_masked_mean_workspace_size(int B, int Q, int M, int E) {
+  return (size_t)zh_cdiv(M, MCH) * B * Q * E * sizeof(float);
+}
 extern "C" int zh_masked_mean_tokens(const float* tokens, const unsigned char* binary, const float* sizes, float* avg,
-                                     int B, int Q, int M, int E, hipStream_t stream) {
+                                     int B, int Q, int M, int E, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   ZH_CHECK_ARG(tokens && binary && sizes && avg && B > 0 && Q > 0 && M > 0 && E > 0, "zh_masked_mean_tokens: bad arguments");
   ZH_CHECK_ARG(E <= 1024 && B < 65536, "zh_masked_mean_tokens: E=%d > 1024 unsupported", E);
-  dim3 grid(zh_cdiv(Q, QT), B);
-  if (E <= 256) hipLaunchKernelGGL(masked_mean_kernel<1>, grid, dim3(256), 0, stream, tokens, binary, sizes, avg, Q, M, E);
-  else if (E <= 512) hipLaunchKernelGGL(masked_mean_kernel<2>, grid, dim3(256), 0, stream, tokens, binary, sizes, avg, Q, M, E);
-  else hipLaunchKernelGGL(masked_mean_kernel<4>, grid, dim3(256), 0, stream, tokens, binary, sizes, avg, Q, M, E);
+  const int chunks = zh_cdiv(M, MCH);
+  ZH_CHECK_ARG(chunks < 65536, "zh_masked_mean_tokens: M=%d too large", M);
+  if (!workspace || workspace_bytes < zh_masked_mean_workspace_size(B, Q, M, E)) {
+    zh_set_error("zh_masked_mean_tokens: workspace too small (%zu < %zu)", workspace_bytes, zh_masked_mean_workspace_size(B, Q, M, E));
+    return ZH_ERR_WORKSPACE;
+  }
+  float* partial = (float*)workspace;
+  const long rows = (long)B * Q;
+  dim3 grid(zh_cdiv(Q, QT), B, chunks);
+  if (E <= 256) hipLaunchKernelGGL(masked_mean_kernel<1>, grid, dim3(256), 0, stream, tokens, binary, partial, Q, M, E, rows);
+  else if (E <= 512) hipLaunchKernelGGL(masked_mean_kernel<2>, grid, dim3(256), 0, stream, tokens, binary, partial, Q, M, E, rows);
+  else hipLaunchKernelGGL(masked_mean_kernel<4>, grid, dim3(256), 0, stream, tokens, binary, partial, Q, M, E, rows);
+  hipLaunchKernelGGL(masked_mean_reduce_kernel, dim3(zh_cdiv(rows * E, 256)), dim3(256), 0, stream, partial, sizes, avg, rows, E, chunks);
   ZH_CHECK_LAUNCH("zh_masked_mean_tokens");
   return ZH_OK;
 }
@@ -203,32 +221,49 @@ extern "C" int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels
 //      a block owns one mask, walks it in 64-column panels staged through LDS (coalesced row reads), counts the value
 //      changes per column, prefix-sums them, and writes the column-major pixel positions where the value changes.
 //      counts = diff([0, positions..., H*W]) with a leading 0-run inserted when pixel 0 is set (host, tiny).
-#define RUNS_PANEL 64
+// PANEL = columns per pass: 256 (every thread owns a column; the panel [H][256] must fit the LDS: H <= ~620) or 64 (taller masks).
+// Round 3: the 64-column form kept 64 of 256 threads busy and staged the panel with byte loads — 0.75 ms for 17 masks of
+// 480 x 640 at batch 1 (a fifth of the instance predict).
+template <int PANEL>
 __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* masks, const int* sel, int H, int W, int max_runs,
                                                         int* positions, int* nruns, int* box_area) {
-  extern __shared__ unsigned char sm[];                    // [H][RUNS_PANEL] panel, then int colcnt[RUNS_PANEL + 1]
+  extern __shared__ unsigned char sm[];                    // [H][PANEL] panel, then int colcnt[PANEL + 1]
   __shared__ int s_base, s_first, s_minx, s_maxx, s_miny, s_maxy, s_area;
   const unsigned char* m = masks + (long)sel[blockIdx.x] * H * W;
   int* pos = positions + (long)blockIdx.x * max_runs;
-  int* colcnt = (int*)(sm + (((long)H * RUNS_PANEL + 15) & ~15L));
+  int* colcnt = (int*)(sm + (((long)H * PANEL + 15) & ~15L));
   if (threadIdx.x == 0) { s_base = 0; s_first = m[0] != 0; s_minx = W; s_maxx = -1; s_miny = H; s_maxy = -1; s_area = 0; }
   __syncthreads();
-  for (int x0 = 0; x0 < W; x0 += RUNS_PANEL) {
-    const int pw = min(RUNS_PANEL, W - x0);
-    for (int i = threadIdx.x; i < H * RUNS_PANEL; i += 256) {
-      const int y = i / RUNS_PANEL, c = i - y * RUNS_PANEL;
-      sm[i] = c < pw ? (m[(long)y * W + x0 + c] != 0) : 0;
+  const bool vec = (W % 16 == 0) && (((uintptr_t)m & 15) == 0);
+  for (int x0 = 0; x0 < W; x0 += PANEL) {
+    const int pw = min(PANEL, W - x0);
+    if (vec && pw % 16 == 0) {                             // 16 columns per load: rows are 16-byte aligned
+      const int cpr = PANEL / 16;
+      for (int i = threadIdx.x; i < H * cpr; i += 256) {
+        const int y = i / cpr, c16 = i - y * cpr;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (c16 * 16 < pw) v = *(const uint4*)(m + (long)y * W + x0 + c16 * 16);
+        // != 0 per byte: a byte is nonzero iff (b | (b + 0x7f)) has its top bit set (for b in 0..255 taken bytewise without carries)
+        auto nz = [](unsigned w) { const unsigned t = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w; return (t >> 7) & 0x01010101u; };
+        uint4 o = {nz(v.x), nz(v.y), nz(v.z), nz(v.w)};
+        *(uint4*)(sm + (long)y * PANEL + c16 * 16) = o;
+      }
+    } else {
+      for (int i = threadIdx.x; i < H * PANEL; i += 256) {
+        const int y = i / PANEL, c = i - y * PANEL;
+        sm[i] = c < pw ? (m[(long)y * W + x0 + c] != 0) : 0;
+      }
     }
     __syncthreads();
     // pass 1: transitions per column (a column's first pixel is compared with the previous column's last pixel)
-    if (threadIdx.x < RUNS_PANEL) {
+    if (threadIdx.x < PANEL) {
       const int c = threadIdx.x;
       int cnt = 0;
       if (c < pw) {
-        unsigned char prev = c > 0 ? sm[(H - 1) * RUNS_PANEL + c - 1] : (x0 > 0 ? (m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0]);
+        unsigned char prev = c > 0 ? sm[(H - 1) * PANEL + c - 1] : (x0 > 0 ? (m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0]);
         int area = 0, ymin = H, ymax = -1;
         for (int y = 0; y < H; ++y) {
-          const unsigned char v = sm[y * RUNS_PANEL + c];
+          const unsigned char v = sm[y * PANEL + c];
           cnt += v != prev;
           prev = v;
           if (v) { ++area; ymin = min(ymin, y); ymax = y; }
@@ -241,19 +276,19 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
       colcnt[c] = cnt;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {                               // exclusive scan of <= 64 counts
+    if (threadIdx.x == 0) {                               // exclusive scan of <= PANEL counts
       int acc = s_base;
-      for (int c = 0; c < RUNS_PANEL; ++c) { const int t = colcnt[c]; colcnt[c] = acc; acc += t; }
+      for (int c = 0; c < PANEL; ++c) { const int t = colcnt[c]; colcnt[c] = acc; acc += t; }
       s_base = acc;
     }
     __syncthreads();
     // pass 2: write positions
     if (threadIdx.x < pw) {
       const int c = threadIdx.x;
-      unsigned char prev = c > 0 ? sm[(H - 1) * RUNS_PANEL + c - 1] : (x0 > 0 ? (m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0]);
+      unsigned char prev = c > 0 ? sm[(H - 1) * PANEL + c - 1] : (x0 > 0 ? (m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0]);
       int o = colcnt[c];
       for (int y = 0; y < H; ++y) {
-        const unsigned char v = sm[y * RUNS_PANEL + c];
+        const unsigned char v = sm[y * PANEL + c];
         if (v != prev) { if (o < max_runs) pos[o] = (x0 + c) * H + y; ++o; }
         prev = v;
       }
@@ -271,12 +306,19 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
 extern "C" int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, int W, int max_runs,
                             int* positions, int* nruns, int* box_area, hipStream_t stream) {
   ZH_CHECK_ARG(masks && sel && positions && nruns && box_area && n_sel > 0 && H > 0 && W > 0 && max_runs > 0, "zh_mask_runs: bad arguments");
-  const size_t lds = (((size_t)H * RUNS_PANEL + 15) & ~(size_t)15) + (RUNS_PANEL + 1) * sizeof(int);
-  ZH_CHECK_ARG(lds <= 160 * 1024 - 64, "zh_mask_runs: H=%d too tall for the LDS panel", H);
   ZH_CHECK_ARG((long)H * W < (1L << 31), "zh_mask_runs: mask too large");
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)mask_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(mask_runs_kernel, dim3(n_sel), dim3(256), lds, stream, masks, sel, H, W, max_runs, positions, nruns, box_area);
+  auto lds_of = [&](int panel) { return (((size_t)H * panel + 15) & ~(size_t)15) + (panel + 1) * sizeof(int); };
+  const size_t cap = 160 * 1024 - 64;
+  if (lds_of(256) <= cap) {
+    const size_t lds = lds_of(256);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mask_runs_kernel<256>, dim3(n_sel), dim3(256), lds, stream, masks, sel, H, W, max_runs, positions, nruns, box_area);
+  } else {
+    const size_t lds = lds_of(64);
+    ZH_CHECK_ARG(lds <= cap, "zh_mask_runs: H=%d too tall for the LDS panel", H);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mask_runs_kernel<64>, dim3(n_sel), dim3(256), lds, stream, masks, sel, H, W, max_runs, positions, nruns, box_area);
+  }
   ZH_CHECK_LAUNCH("zh_mask_runs");
   return ZH_OK;
 }

@@ -375,7 +375,9 @@ def instance_mask_stats(mask_proposals_last, stride_image, threshold, B, Q, M, s
 
 def masked_mean_tokens(tokens, binary, sizes, avg, B, Q, M, E):
     L = _lib.load()
-    _lib.check(L.zh_masked_mean_tokens(_p(tokens), _p(binary), _p(sizes), _p(avg), B, Q, M, E, _stream()), "zh_masked_mean_tokens")
+    need = int(_lib.load(raw=True).zh_masked_mean_workspace_size(B, Q, M, E))
+    ws = torch.empty(need, dtype=torch.uint8, device=tokens.device)
+    _lib.check(L.zh_masked_mean_tokens(_p(tokens), _p(binary), _p(sizes), _p(avg), B, Q, M, E, _p(ws), need, _stream()), "zh_masked_mean_tokens")
 
 
 def instance_classify(avg, text, conf, temperature, rows, n, E, category, score):
