@@ -96,7 +96,7 @@ class SelfMask(nn.Module):
         self.scale_factor = scale_factor
         self._engine = None
         self.precision: str = "exact"             # "fast" | "exact" | "f16" (zutis_amd.engine)
-        self.cross_attention_key_split: int = 2      # engine_base._decoder: this module serves batch-1 evaluation loops
+        self.cross_attention_key_split: int = 8      # engine_base._decoder / engine_selfmask: 20 queries x ~5500 keys at batch 1 - 8
 
     def _get_engine(self) -> SelfMaskEngine:
         if self._engine is not None and self._engine.precision != self.precision:

@@ -306,6 +306,9 @@ class _EngineBase:
         # and what bench.py runs; the drop-in modules set 2, they serve batch-1 evaluation loops) and never of the batch — image
         # i's result is bitwise the same alone and inside a batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
         ksplit = self.cross_ksplit if (Q <= 128 and M >= 1024) else 1
+        ktiles = -(-M // (32 if xk else 64))               # key tiles of the kernel (32 keys for split pairs, 64 for fp16)
+        while ksplit > 1 and (ksplit - 1) * -(-ktiles // ksplit) >= ktiles:
+            ksplit -= 1                                    # the largest split that leaves no workgroup without keys (a function of M only)
         attn_ws = None
         if ksplit > 1:
             attn_ws = self._buf("attn_ws", (ops.attention_splitk_workspace_size(B, heads, Q, dh, ksplit),), torch.uint8)

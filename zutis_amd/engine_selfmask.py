@@ -19,6 +19,9 @@ class SelfMaskEngine(_EngineBase):
     objectness MLP; inference picks the argmax-objectness query, x4 bilinear, crop, > 0.5."""
 
     _dec_out_sites = ("mask", "ffn2")
+    # 20 queries against ~5500 memory tokens, 6 heads, batches of 1 - 8: the cross-attention is 6 .. 48 workgroups of 172 key tiles
+    # each; its keys are split 8 ways (engine_base._decoder: a property of the engine, never of the batch)
+    cross_ksplit = 8
 
     def __init__(self, params: Dict[str, torch.Tensor], patch: int = 8, heads: int = 6, precision="exact"):
         self.params = params
