@@ -9,8 +9,8 @@ MASKS = [0, 1, 2, 4, 8, 16, 32, 64]
 # --ab: whole-kernel variants timed ABBA in one process and compared with the first one: name -> (flags, source or None = product)
 VARIANTS = {"product": ([], None), "variant": ([], os.path.join(HERE, "_abl", "attn_variant.hip"))}   # drop a modified attention.hip there
 for a in sys.argv[1:]:
-    if a.startswith("-D"):
-        VARIANTS[a[2:].lower()] = ([a], None)
+    if a.startswith("-D") or a.startswith("-f"):           # one variant per argument; "-DX=1,-fno-slp-vectorize" = several flags in one variant
+        VARIANTS[a.lstrip("-").lower().replace("=", "").replace(",", "_")] = (a.split(","), None)
 VARIANTS = {k: v for k, v in VARIANTS.items() if v[1] is None or os.path.exists(v[1])}
 if "--build" in sys.argv and "--ab" in sys.argv:
     for name, (flags, src) in VARIANTS.items():

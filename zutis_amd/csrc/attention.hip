@@ -30,13 +30,62 @@ struct AttnArgs {
   // UNNORMALISED fp32 accumulators + running max (log2 units) + row sum in the workspace; attn_combine_kernel merges them
   int ksplit, kchunk;
   float* part_o; float* part_m; float* part_l;   // [ksplit][B*Tq][H*dh], [ksplit][B*H][Tq] x 2
+#ifdef ZH_ATTN_STAMP
+  long long* stamp;   // developer build (tools/attn_stamp.py): [workgroup][wave][12] cycle sums per loop segment + clocks
+#endif
 };
+#ifdef ZH_ATTN_STAMP
+static long long* g_attn_stamp = nullptr;
+extern "C" void zh_attn_set_stamp(long long* p) { g_attn_stamp = p; }
+#define ZH_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_prev; st_prev = n_; \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ZH_STAMP(i)
+#endif
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 
 #define KT 64
 #define VS 96
+
+// VALU diet of the key-tile loop (round 3; every vector instruction costs the SIMD's issue port 4 cycles, v_exp_f32 8, an MFMA 8 of
+// its 32 — MI355X_MICROARCH.md "vector-instruction ISSUE cost" — and the softmax of a split-pair tile was ~145 of them beside 24
+// MFMAs: issue-bound, not MFMA-bound).  Developer A/B mask (tools/attn_ablate.py --ab -DZH_ATTN_V=n): 1 = the two key halves of a
+// query meet through v_permlane32_swap instead of ds_bpermute (+ 6 address instructions + an LDS round trip per tile),
+// 2 = tile loads as SGPR base + 32-bit lane offset with the row clamped to the last key (no zero fill, no 64-bit address
+// arithmetic per tile), 4 = the running max only moves when it grows by more than 2^8 (the accumulator rescale — 32 multiplies
+// per lane — then runs on the first tile and almost never again; P <= 256 stays far inside fp16 / the split pair).
+// Measured (same box, us; split-pair / fp16 kernels): encoder 79.1 -> 73.3 / 41.8 -> 37.4, cross-attention 123.0 -> 118.0 / 43.7 ->
+// 38.2, 518-px encoder 111.8 -> 101.6 / 56.9 -> 50.6, ViT-L/14 1335 -> 1246 / 681 -> 625, SelfMask T = 5505 251 -> 231 / 128 -> 113;
+// each piece alone 1 - 3 %.  Not kept: s_setprio 1 around the K.Q^T MFMAs, the P.V MFMAs or the softmax (all within noise),
+// -fno-slp-vectorize (the packed multiplies left are the now rare rescale).
+#ifndef ZH_ATTN_V
+#define ZH_ATTN_V 7
+#endif
+#define ZH_ATTN_LAZY_LOG2 8.0f
+
+// max over the two lanes l, l ^ 32 (both get it)
+__device__ __forceinline__ float zh_xor32_max(float x) {
+#if ZH_ATTN_V & 1
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: lanes 32.. <- x[0..31]; b: lanes 0..31 <- x[32..]
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return fmaxf(x, __shfl_xor(x, 32, 64));
+#endif
+}
+__device__ __forceinline__ float zh_xor32_sum(float x) {
+#if ZH_ATTN_V & 1
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+#else
+  return x + __shfl_xor(x, 32, 64);
+#endif
+}
 
 // X3 = 1 (the reference-equivalent mode): Q, K and V arrive as split pairs (hi = f16(x), lo = f16(x - hi)):
 // S = Kh.Qh + Kl.Qh + Kh.Ql in fp32 — the softmax exponent sees fp32-class scores, which is where fp16 operand rounding is
@@ -139,6 +188,30 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   // gain — the kernel is VALU-bound — and its 16 registers are what keeps dh = 64 at three waves per SIMD).
   struct TileRegs { half8_t k[NLD], v[NLD], kl[X3 ? NLD : 1], vl[X3 ? NLD : 1]; };
   TileRegs ra;
+#if ZH_ATTN_V & 2
+  // per-lane byte offsets of this thread's chunk(s) inside a tile; a tile's rows are clamped to the last key of the chunk (a
+  // duplicate of a real row: its scores are masked to -inf below, its V rows meet P = 0) — host check: Tk * ld * 2 < 2^32
+  const unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
+  const char* const Kl = (const char*)(K + p.planeK);
+  const char* const Vl = (const char*)(V + p.planeV);
+  auto load_tile = [&](int kbase, TileRegs& r) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * NT;
+      const int row = c / CPR, cc = c - row * CPR;
+      if (LDFULL || c < KTT * CPR) {
+        const unsigned key = (unsigned)min(kbase + row, key_end - 1);
+        const unsigned ok = key * ldk2 + (unsigned)cc * 16u, ov = key * ldv2 + (unsigned)cc * 16u;
+        r.k[i] = *(const half8_t*)((const char*)K + ok);
+        r.v[i] = *(const half8_t*)((const char*)V + ov);
+        if (X3) {
+          r.kl[i] = *(const half8_t*)(Kl + ok);
+          r.vl[i] = *(const half8_t*)(Vl + ov);
+        }
+      }
+    }
+  };
+#else
   auto load_tile = [&](int kbase, TileRegs& r) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -159,6 +232,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
       }
     }
   };
+#endif
   auto store_tile = [&](int buf, const TileRegs& r) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -187,6 +261,11 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     ntiles = min(ntiles, qlast / KTT + 1);
   }
   const int qidx = q0 + ql;
+#ifdef ZH_ATTN_STAMP
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  long long st_prev = st_t0;
+#endif
   load_tile(key0, ra);
   store_tile(0, ra);
   __syncthreads();
@@ -219,6 +298,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
         }
       }
     }
+    ZH_STAMP(1);
     // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
     float mx = -INFINITY;
     if (kbase + KTT > key_end || (p.causal && kbase + KTT - 1 > q0)) {   // ragged last tile / tiles crossing the diagonal
@@ -243,16 +323,24 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
         }
       mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = zh_xor32_max(mx);
+    ZH_STAMP(2);
     // running max kept in log2 units (scale_log2 > 0 commutes with max): p = 2^(s*c - m) is ONE fma + v_exp_f32
+#if ZH_ATTN_V & 4
+    // lazy: the reference point only moves when the tile's max exceeds it by more than 2^8 (any fixed reference gives the same
+    // softmax; both key halves of a query see the same mx and m_run, so they decide alike)
+    const float m_cand = mx * p.scale_log2;
+    const float m_new = m_cand > m_run + ZH_ATTN_LAZY_LOG2 ? m_cand : m_run;
+#else
     const float m_new = fmaxf(m_run, mx * p.scale_log2);
+#endif
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     // P as packed fp16 pairs: register (r >> 1) & 3 of fragment r >> 3 holds scores r, r + 1 — the MFMA B operand as is
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 pfu[NU][2], plu[X3 ? NU : 1][2];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 lsum2 = {0.f, 0.f};
+    float lsum2[2] = {0.f, 0.f};                             // scalar adds: packed fp32 VALU is an anti-lever beside MFMAs (v_pk_add_f32 ~ +13 issue cycles)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -297,6 +385,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
       }
     }
     if (X3) l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
+    ZH_STAMP(3);
 
     // ---- O^T += V^T P^T
 #if ZH_ATTN_ABL & 2
@@ -330,6 +419,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
         }
       }
 #endif
+    ZH_STAMP(4);
     }
 
   };
@@ -359,20 +449,34 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
 #else
   for (int t = 0; t < ntiles; t += 2) {           // two tiles per trip: the LDS buffer index is a compile-time constant
     if (t + 1 < ntiles) load_tile(key0 + (t + 1) * KTT, ra);
+    ZH_STAMP(0);
     compute(t);
     if (t + 1 < ntiles) store_tile(1, ra);
+    ZH_STAMP(5);
     __syncthreads();
+    ZH_STAMP(6);
     if (t + 1 >= ntiles) break;
     if (t + 2 < ntiles) load_tile(key0 + (t + 2) * KTT, ra);
+    ZH_STAMP(0);
     compute(t + 1);
     if (t + 2 < ntiles) store_tile(0, ra);
+    ZH_STAMP(5);
     __syncthreads();
+    ZH_STAMP(6);
+  }
+#endif
+#ifdef ZH_ATTN_STAMP
+  if (p.stamp && lane == 0) {
+    long long* sp = p.stamp + ((long)id * NWAVE + wave) * 12;
+    const long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 8; ++i) sp[i] = st_acc[i];
+    sp[8] = st_t1 - st_t0; sp[9] = st_r1 - st_r0; sp[10] = ntiles; sp[11] = q0 < p.Tq;
   }
 #endif
 
   // f16: every row of lacc holds the full row sum of this lane's query (the MFMA already summed both key halves);
   // split pairs: this lane's half of the keys + the other half's (lane ^ 32)
-  const float l_row = X3 ? l_run + __shfl_xor(l_run, 32, 64) : lacc[0];
+  const float l_row = X3 ? zh_xor32_sum(l_run) : lacc[0];
   const int qr = q0 + ql;
   if (p.ksplit > 1) {                                   // partial result of this key chunk: unnormalised O, running max, row sum
     if (qr < p.Tq) {
@@ -441,6 +545,8 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   ZH_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 && ((uintptr_t)O & 7) == 0,
                "zh_attention_f16: misaligned pointer");
   ZH_CHECK_ARG(heads < 65536 && batch < 65536, "zh_attention_f16: heads/batch exceed grid limits");
+  // K / V rows are addressed as (per-image, per-head base) + 32-bit byte offset
+  ZH_CHECK_ARG((long)Tk * ldk * 2 < (1L << 32) && (long)Tk * ldv * 2 < (1L << 32), "zh_attention_f16: Tk * ldk (ldv) exceeds 2^31 elements");
   ZH_CHECK_ARG((planeQ != 0) == (planeK != 0) && (planeQ != 0) == (planeV != 0),
                "zh_attention_f16: the split-pair mode needs the lo planes of Q, K and V (all three or none)");
   AttnArgs p;
@@ -458,6 +564,9 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   p.groups = heads * batch;
   const bool x3 = planeQ != 0;
   p.ksplit = 1; p.kchunk = 0; p.part_o = p.part_m = p.part_l = nullptr;
+#ifdef ZH_ATTN_STAMP
+  p.stamp = g_attn_stamp;
+#endif
   if (ksplit > 1) {
     ZH_CHECK_ARG(!causal && ksplit <= 16, "zh_attention_f16_splitk: ksplit %d not in 1..16 (and not for the causal form)", ksplit);
     const int ktt = x3 ? 32 : 64;
