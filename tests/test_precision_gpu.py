@@ -352,6 +352,30 @@ def test_attention_key_split_matches_unsplit(dev, dh, heads, Tq, Tk, S, x3):
     assert float((val(O1) - val(O2)).abs().max()) < (1e-5 if x3 else 2e-3)
 
 
+@pytest.mark.parametrize("T", [442, 449, 64])
+def test_attention_x3_pipelined_loop_is_bitwise_the_plain_loop(dev, T):
+    """The split-pair dh = 64 kernel runs its software-pipelined loop on small grids and the plain loop on large ones (the
+    launcher's rule in attention.hip): image 0 alone (48 workgroups at T = 442: pipelined) and as the first of 40 images (1920
+    workgroups: plain) must agree bit for bit — the two loops issue the same arithmetic, only in a different order in time — and
+    both must match float64.  T = 449 = 14 tiles + 1 key (a ragged peeled tile), T = 64 = two full tiles (nothing ragged)."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    dh, heads, B = 64, 12, 40
+    D = heads * dh
+    q, k, v = _randn((B * T, D), 11, 1.5), _randn((B * T, D), 12, 1.5), _randn((B * T, D), 13)
+    Q, K, V = _split_act(q, dev), _split_act(k, dev), _split_act(v, dev)
+    kw = dict(heads=heads, Tq=T, Tk=T, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=T * D, strideK=T * D, strideV=T * D, strideO=T * D, x3=True)
+    O_all, O_one = Act.empty((B * T, D), True, dev), Act.empty((B * T, D), True, dev)
+    O_one.t.zero_()
+    ops.attention(Q, K, V, O_all, batch=B, **kw)
+    ops.attention(Q, K, V, O_one, batch=1, **kw)
+    assert torch.equal(O_all.t[:, :T], O_one.t[:, :T])
+    qd, kd, vd = (t[:T].view(T, heads, dh).transpose(0, 1).double() for t in (q, k, v))
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) / math.sqrt(dh), -1) @ vd).transpose(0, 1).reshape(T, D)
+    got = (O_one.t[0, :T].float() + O_one.t[1, :T].float()).cpu().double()
+    assert float((got - ref).abs().max()) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------- whole-model stress test
 def _stress_case(dev, B, S, sharp=3.0):
     from zutis_amd import detgen

@@ -35,7 +35,7 @@ for name in names:
     pq, pk, po = (B * Tq * D, B * Tk * D, B * Tq * D) if X3 else (0, 0, 0)
     nqb = (Tq + 127) // 128
     nwg = ((B * H + 7) // 8) * 8 * nqb
-    stamp = torch.zeros(nwg * 4 * 12, dtype=torch.int64, device=dev)
+    stamp = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     run = lambda: L.zh_attention_f16(q.data_ptr(), D, Tq * D, k.data_ptr(), D, Tk * D, v.data_ptr(), D, Tk * D, o.data_ptr(), D, Tq * D,
                                      B, H, Tq, Tk, dh, dh ** -0.5, pq, pk, pk, po, s)
@@ -57,7 +57,7 @@ for name in names:
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    st = stamp.cpu().numpy().reshape(nwg, 4, 12).astype(np.float64)
+    st = stamp.cpu().numpy().reshape(nwg, 4, 16).astype(np.float64)
     act = st[:, :, 11] > 0                             # waves with queries
     used = st[:, :, 10] > 0
     a = st[act & used]
@@ -68,6 +68,13 @@ for name in names:
           f"{a[:, 8].mean():.0f} cycles for {tiles:.1f} tiles = {a[:, 8].mean() / tiles:.0f} per tile; {int(act.sum())} active waves of {int(used.sum())}")
     for nm, c in zip(SEG, per):
         print(f"    {nm:22s} {c:7.0f} cycles / tile  ({100 * c / per.sum():4.1f} %)")
+    u = st[used]
+    t0 = u[:, 12].min()
+    start, loop_end, end = (u[:, 12] - t0) / 100.0, (u[:, 13] - t0) / 100.0, (u[:, 14] - t0) / 100.0          # us since the first wave's entry
+    print(f"    prologue {u[:, 7].mean():.0f} cycles; timeline (us since the first entry): last entry {start.max():.1f}, entries after 5 us: "
+          f"{(start > 5).mean() * 100:.0f} %, median loop end {np.median(loop_end):.1f}, last loop end {loop_end.max():.1f}, last store done {end.max():.1f}")
+    hs, _ = np.histogram(start, bins=10, range=(0, end.max())); he, _ = np.histogram(end, bins=10, range=(0, end.max()))
+    print(f"    entries per tenth of the span {hs.tolist()}  exits {he.tolist()}")
     idle = st[used & ~act]
     if len(idle):
         print(f"    (query-less waves: lifetime {idle[:, 8].mean():.0f} cycles)")

@@ -16,6 +16,7 @@
 // LDS strides: K rows dh+8 halves (conflict-free ds_read_b128), V rows 96 halves (4 consecutive rows cover
 // disjoint 16-dword bank ranges for the transposed read).
 #include "common.h"
+#include <type_traits>
 
 struct AttnArgs {
   const half_t* Q; long ldq, sQ;
@@ -31,7 +32,7 @@ struct AttnArgs {
   int ksplit, kchunk;
   float* part_o; float* part_m; float* part_l;   // [ksplit][B*Tq][H*dh], [ksplit][B*H][Tq] x 2
 #ifdef ZH_ATTN_STAMP
-  long long* stamp;   // developer build (tools/attn_stamp.py): [workgroup][wave][12] cycle sums per loop segment + clocks
+  long long* stamp;   // developer build (tools/attn_stamp.py): [workgroup][wave][16] cycle sums per loop segment + clocks
 #endif
 };
 #ifdef ZH_ATTN_STAMP
@@ -51,40 +52,33 @@ typedef __attribute__((address_space(3))) fp16x4* lds_fp16x4_ptr;
 
 // VALU diet of the key-tile loop (round 3; every vector instruction costs the SIMD's issue port 4 cycles, v_exp_f32 8, an MFMA 8 of
 // its 32 — MI355X_MICROARCH.md "vector-instruction ISSUE cost" — and the softmax of a split-pair tile was ~145 of them beside 24
-// MFMAs: issue-bound, not MFMA-bound).  Developer A/B mask (tools/attn_ablate.py --ab -DZH_ATTN_V=n): 1 = the two key halves of a
-// query meet through v_permlane32_swap instead of ds_bpermute (+ 6 address instructions + an LDS round trip per tile),
-// 2 = tile loads as SGPR base + 32-bit lane offset with the row clamped to the last key (no zero fill, no 64-bit address
-// arithmetic per tile), 4 = the running max only moves when it grows by more than 2^8 (the accumulator rescale — 32 multiplies
-// per lane — then runs on the first tile and almost never again; P <= 256 stays far inside fp16 / the split pair).
+// MFMAs: issue-bound, not MFMA-bound).  Three pieces: the two key halves of a query meet through v_permlane32_swap instead of
+// ds_bpermute (+ 6 address instructions + an LDS round trip per tile); tile loads are SGPR base + 32-bit lane offset with the
+// row clamped to the last key (no zero fill, no 64-bit address arithmetic per tile); the running max only moves when it grows
+// by more than 2^8 (the accumulator rescale — 32 multiplies per lane — then runs on the first tile and almost never again;
+// P <= 256 stays far inside fp16 / the split pair).
 // Measured (same box, us; split-pair / fp16 kernels): encoder 79.1 -> 73.3 / 41.8 -> 37.4, cross-attention 123.0 -> 118.0 / 43.7 ->
 // 38.2, 518-px encoder 111.8 -> 101.6 / 56.9 -> 50.6, ViT-L/14 1335 -> 1246 / 681 -> 625, SelfMask T = 5505 251 -> 231 / 128 -> 113;
 // each piece alone 1 - 3 %.  Not kept: s_setprio 1 around the K.Q^T MFMAs, the P.V MFMAs or the softmax (all within noise),
 // -fno-slp-vectorize (the packed multiplies left are the now rare rescale).
-#ifndef ZH_ATTN_V
-#define ZH_ATTN_V 7
+// ZH_ATTN_PIPE (developer A/B): -1 = the launcher's rule, 0 / 1 = the split-pair kernels never / always run the pipelined loop
+#ifndef ZH_ATTN_PIPE
+#define ZH_ATTN_PIPE -1
 #endif
 #define ZH_ATTN_LAZY_LOG2 8.0f
 
 // max over the two lanes l, l ^ 32 (both get it)
 __device__ __forceinline__ float zh_xor32_max(float x) {
-#if ZH_ATTN_V & 1
   float a = x, b = x;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: lanes 32.. <- x[0..31]; b: lanes 0..31 <- x[32..]
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
-#else
-  return fmaxf(x, __shfl_xor(x, 32, 64));
-#endif
 }
 __device__ __forceinline__ float zh_xor32_sum(float x) {
-#if ZH_ATTN_V & 1
   float a = x, b = x;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
   return a + b;
-#else
-  return x + __shfl_xor(x, 32, 64);
-#endif
 }
 
 // X3 = 1 (the reference-equivalent mode): Q, K and V arrive as split pairs (hi = f16(x), lo = f16(x - hi)):
@@ -98,8 +92,9 @@ __device__ __forceinline__ float zh_xor32_sum(float x) {
 #ifndef ZH_ATTN_ABL
 #define ZH_ATTN_ABL 0      // developer ablations (tools/attn_ablate.py): 1 no exp, 2 no P.V, 4 no K.Q^T, 8 no tile traffic and no
 #endif                     // barriers, 16 no barriers, 32 barriers only, 64 no LDS stores.  0 in the product build.
-template <int DH, int NWAVE, int X3>
+template <int DH, int NWAVE, int X3, int PIPE>
 __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_f16_kernel(AttnArgs p) {
+  static_assert(!PIPE || X3, "the pipelined loop exists for the split-pair kernels");
   constexpr int NT = 64 * NWAVE;
   constexpr int KS = DH + 8;          // K row stride (halves)
   constexpr int NKS = DH / 16;        // k-steps of QK^T
@@ -122,6 +117,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   __shared__ __attribute__((aligned(16))) half_t sVl[X3 ? 2 : 1][X3 ? KTT * VS : 8];   // lo plane of V (X3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef ZH_ATTN_STAMP
+  const long long st_e0 = __builtin_amdgcn_s_memtime(), st_re0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2, so the query
   // blocks of one (image, head) — which all stream the same K / V — get ids that are congruent mod 8 and meet in one L2:
   // id = ((group / 8) * nqb + qb) * 8 + group % 8, group = img * heads + head.  The grid is padded to a multiple of 8 groups.
@@ -188,63 +186,55 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   // gain — the kernel is VALU-bound — and its 16 registers are what keeps dh = 64 at three waves per SIMD).
   struct TileRegs { half8_t k[NLD], v[NLD], kl[X3 ? NLD : 1], vl[X3 ? NLD : 1]; };
   TileRegs ra;
-#if ZH_ATTN_V & 2
-  // per-lane byte offsets of this thread's chunk(s) inside a tile; a tile's rows are clamped to the last key of the chunk (a
-  // duplicate of a real row: its scores are masked to -inf below, its V rows meet P = 0) — host check: Tk * ld * 2 < 2^32
+  // per-lane byte offsets of this thread's chunk(s) inside a tile: SGPR base + 32-bit offset; a tile's rows are clamped to the last
+  // key of the chunk (a duplicate of a real row: its scores are masked to -inf below, its V rows meet P = 0) — host check:
+  // Tk * ld * 2 < 2^32.  K and V are fetched separately: the pipelined loop keeps K one tile ahead of V.
   const unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
   const char* const Kl = (const char*)(K + p.planeK);
   const char* const Vl = (const char*)(V + p.planeV);
-  auto load_tile = [&](int kbase, TileRegs& r) {
+  auto load_k = [&](int kbase, TileRegs& r) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
       const int row = c / CPR, cc = c - row * CPR;
       if (LDFULL || c < KTT * CPR) {
-        const unsigned key = (unsigned)min(kbase + row, key_end - 1);
-        const unsigned ok = key * ldk2 + (unsigned)cc * 16u, ov = key * ldv2 + (unsigned)cc * 16u;
+        const unsigned ok = (unsigned)min(kbase + row, key_end - 1) * ldk2 + (unsigned)cc * 16u;
         r.k[i] = *(const half8_t*)((const char*)K + ok);
-        r.v[i] = *(const half8_t*)((const char*)V + ov);
-        if (X3) {
-          r.kl[i] = *(const half8_t*)(Kl + ok);
-          r.vl[i] = *(const half8_t*)(Vl + ov);
-        }
+        if (X3) r.kl[i] = *(const half8_t*)(Kl + ok);
       }
     }
   };
-#else
-  auto load_tile = [&](int kbase, TileRegs& r) {
+  auto load_v = [&](int kbase, TileRegs& r) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
       const int row = c / CPR, cc = c - row * CPR;
-      const int key = kbase + row;
-      if (key < key_end && (LDFULL || c < KTT * CPR)) {
-        r.k[i] = *(const half8_t*)(K + (long)key * p.ldk + cc * 8);
-        r.v[i] = *(const half8_t*)(V + (long)key * p.ldv + cc * 8);
-        if (X3) {
-          r.kl[i] = *(const half8_t*)(K + p.planeK + (long)key * p.ldk + cc * 8);
-          r.vl[i] = *(const half8_t*)(V + p.planeV + (long)key * p.ldv + cc * 8);
-        }
-      } else {
-        r.k[i] = (half8_t)(half_t)0;
-        r.v[i] = (half8_t)(half_t)0;
-        if (X3) { r.kl[i] = (half8_t)(half_t)0; r.vl[i] = (half8_t)(half_t)0; }
+      if (LDFULL || c < KTT * CPR) {
+        const unsigned ov = (unsigned)min(kbase + row, key_end - 1) * ldv2 + (unsigned)cc * 16u;
+        r.v[i] = *(const half8_t*)((const char*)V + ov);
+        if (X3) r.vl[i] = *(const half8_t*)(Vl + ov);
       }
     }
   };
-#endif
-  auto store_tile = [&](int buf, const TileRegs& r) {
+  auto store_k = [&](int buf, const TileRegs& r) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
       const int row = c / CPR, cc = c - row * CPR;
       if (LDFULL || c < KTT * CPR) {
         *(half8_t*)(sKb[buf] + row * KS + cc * 8) = r.k[i];
+        if (X3) *(half8_t*)(sKl[buf] + row * KS + cc * 8) = r.kl[i];
+      }
+    }
+  };
+  auto store_v = [&](int buf, const TileRegs& r) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * NT;
+      const int row = c / CPR, cc = c - row * CPR;
+      if (LDFULL || c < KTT * CPR) {
         *(half8_t*)(sVb[buf] + row * VS + cc * 8) = r.v[i];
-        if (X3) {
-          *(half8_t*)(sKl[buf] + row * KS + cc * 8) = r.kl[i];
-          *(half8_t*)(sVl[buf] + row * VS + cc * 8) = r.vl[i];
-        }
+        if (X3) *(half8_t*)(sVl[buf] + row * VS + cc * 8) = r.vl[i];
       }
     }
   };
@@ -261,23 +251,17 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     ntiles = min(ntiles, qlast / KTT + 1);
   }
   const int qidx = q0 + ql;
+  // a wave whose 32 queries all lie beyond Tq (T = 442: two of the last block's four) only helps with the tile loads
+  const bool active = q0 < p.Tq;
 #ifdef ZH_ATTN_STAMP
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
   long long st_prev = st_t0;
 #endif
-  load_tile(key0, ra);
-  store_tile(0, ra);
-  __syncthreads();
 
-  auto compute = [&](int t) {
-    const int kbase = key0 + t * KTT;
+  // ---- S^T(t) = K(t) Q^T from K buffer t & 1 (NU 32-key slot tiles)
+  auto qk = [&](int t, f32x16 (&s)[NU]) {
     const half_t* sK = sKb[t & 1];
-    const half_t* sV = sVb[t & 1];
-    // a wave whose 32 queries all lie beyond Tq (T = 442: two of the last block's four) only helps with the tile loads
-    if (q0 < p.Tq) {
-    // ---- S^T = K Q^T  (two 32-key slot tiles)
-    f32x16 s[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -298,10 +282,19 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
         }
       }
     }
-    ZH_STAMP(1);
+  };
+  // P as packed fp16 pairs: register (r >> 1) & 3 of fragment r >> 3 holds scores r, r + 1 — the MFMA B operand as is
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  struct PFrag { u32x4 hi[NU][2], lo[X3 ? NU : 1][2]; };
+  // ---- online softmax of tile t: scores -> P (fp16, or a split pair), accumulators rescaled when the reference point moves
+  // (MASKED = false: the caller knows the tile is full and the attention not causal — no branch splits the block, so the
+  //  pipelined loop's K.Q^T MFMAs of the next tile can be scheduled in among these instructions)
+  auto softmax = [&](int t, f32x16 (&s)[NU], PFrag& P, auto masked) {
+    constexpr bool MASKED = decltype(masked)::value;
+    const int kbase = key0 + t * KTT;
     // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
     float mx = -INFINITY;
-    if (kbase + KTT > key_end || (p.causal && kbase + KTT - 1 > q0)) {   // ragged last tile / tiles crossing the diagonal
+    if (MASKED && (kbase + KTT > key_end || (p.causal && kbase + KTT - 1 > q0))) {   // ragged last tile / tiles crossing the diagonal
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -325,21 +318,13 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     }
     mx = zh_xor32_max(mx);
     ZH_STAMP(2);
-    // running max kept in log2 units (scale_log2 > 0 commutes with max): p = 2^(s*c - m) is ONE fma + v_exp_f32
-#if ZH_ATTN_V & 4
-    // lazy: the reference point only moves when the tile's max exceeds it by more than 2^8 (any fixed reference gives the same
+    // running max kept in log2 units (scale_log2 > 0 commutes with max): p = 2^(s*c - m) is ONE fma + v_exp_f32.
+    // Lazy: the reference point only moves when the tile's max exceeds it by more than 2^8 (any fixed reference gives the same
     // softmax; both key halves of a query see the same mx and m_run, so they decide alike)
     const float m_cand = mx * p.scale_log2;
     const float m_new = m_cand > m_run + ZH_ATTN_LAZY_LOG2 ? m_cand : m_run;
-#else
-    const float m_new = fmaxf(m_run, mx * p.scale_log2);
-#endif
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    // P as packed fp16 pairs: register (r >> 1) & 3 of fragment r >> 3 holds scores r, r + 1 — the MFMA B operand as is
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 pfu[NU][2], plu[X3 ? NU : 1][2];
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     float lsum2[2] = {0.f, 0.f};                             // scalar adds: packed fp32 VALU is an anti-lever beside MFMAs (v_pk_add_f32 ~ +13 issue cycles)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
@@ -362,17 +347,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
           asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
               "v_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
               : "=&v"(el) : "v"(eh), "v"(e0), "v"(e1));
-          plu[u][r >> 3][(r >> 1) & 3] = el;
+          P.lo[u][r >> 3][(r >> 1) & 3] = el;
         }
-        pfu[u][r >> 3][(r >> 1) & 3] = eh;
-      }
-    half8_t pf[NU][2], pl[X3 ? NU : 1][2];
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        pf[u][k] = __builtin_bit_cast(half8_t, pfu[u][k]);
-        if (X3) pl[u][k] = __builtin_bit_cast(half8_t, plu[u][k]);
+        P.hi[u][r >> 3][(r >> 1) & 3] = eh;
       }
     if (__any(alpha != 1.0f)) {
 #pragma unroll
@@ -386,17 +363,20 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     }
     if (X3) l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
     ZH_STAMP(3);
-
-    // ---- O^T += V^T P^T
+  };
+  // ---- O^T += V(t)^T P^T from V buffer t & 1
+  auto pv = [&](int t, const PFrag& P) {
+    const half_t* sV = sVb[t & 1];
 #if ZH_ATTN_ABL & 2
-    oacc[0][0] += (float)pf[0][0][0] + (float)pf[NU - 1][1][7] + (float)pf[0][1][3] + (float)pf[NU - 1][0][5];
+    oacc[0][0] += (float)__builtin_bit_cast(half8_t, P.hi[0][0])[0] + (float)__builtin_bit_cast(half8_t, P.hi[NU - 1][1])[7];
     lacc[0] += 1.0f; l_run += 1.0f;
 #else
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        if (!X3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[u][ks], lacc, 0, 0, 0);
+        const half8_t pf = __builtin_bit_cast(half8_t, P.hi[u][ks]);
+        if (!X3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
         const half_t* vp = sV + (32 * u + 16 * ks + tr_row) * VS + tr_col;
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
@@ -405,7 +385,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
           half8_t vf;
           __builtin_memcpy(&vf, &lo, 8);
           __builtin_memcpy(((char*)&vf) + 8, &hi, 8);
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][ks], oacc[d], 0, 0, 0);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
           if (X3) {
             const half_t* vq = sVl[t & 1] + (32 * u + 16 * ks + tr_row) * VS + tr_col;
             fp16x4 llo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(vq + 32 * d));
@@ -413,15 +393,80 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
             half8_t vl;
             __builtin_memcpy(&vl, &llo, 8);
             __builtin_memcpy(((char*)&vl) + 8, &lhi, 8);
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[u][ks], oacc[d], 0, 0, 0);
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl[u][ks], oacc[d], 0, 0, 0);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf, oacc[d], 0, 0, 0);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, __builtin_bit_cast(half8_t, P.lo[u][ks]), oacc[d], 0, 0, 0);
           }
         }
       }
 #endif
     ZH_STAMP(4);
-    }
+  };
 
+#if !ZH_ATTN_ABL
+  if (PIPE && !p.causal) {
+    // ---- software-pipelined loop (split-pair kernels): K runs ONE TILE AHEAD of V, and a wave issues the 12 K.Q^T MFMAs of tile
+    // t+1 — which depend on nothing the softmax of tile t touches — in among that softmax's ~95 vector instructions, which
+    // then issue in the shadow of the MFMAs instead of next to an idle matrix pipe (in-kernel stamps, tools/attn_stamp.py: with
+    // three uncoordinated waves per SIMD the pipe was 62 % busy inside the loop; a wave spent 19 % of a tile in exp / split /
+    // pack with no MFMA of its own in flight).  Step t: global loads of K(t+2), V(t+1) -> [S(t+1) || softmax(t)] -> P(t).V(t) ->
+    // stores -> barrier.  K(t+2) overwrites the buffer of K(t), last read in step t-1; V(t+1) that of V(t-1), last read in step
+    // t-1.  Steps are branch-free inside (full tiles, not causal); the last tile — the only one that can be ragged — is peeled.
+    load_k(key0, ra);
+    load_v(key0, ra);
+    store_k(0, ra);
+    store_v(0, ra);
+    if (ntiles > 1) { load_k(key0 + KTT, ra); store_k(1, ra); }
+    __syncthreads();
+    f32x16 sA[NU], sB[NU];
+    PFrag P;
+    if (active) qk(0, sA);
+    __syncthreads();                               // step 0 stores K(2) over K(0): every wave's reads of K(0) come first
+    // one step: tile t has a successor; par = t & 1 as a compile-time constant
+    auto step = [&](int t, auto par, f32x16 (&cur)[NU], f32x16 (&nxt)[NU]) {
+      constexpr int PAR = decltype(par)::value;
+      if (t + 2 < ntiles) load_k(key0 + (t + 2) * KTT, ra);
+      load_v(key0 + (t + 1) * KTT, ra);
+      ZH_STAMP(0);
+      if (active) {
+        qk(PAR ^ 1, nxt);
+        softmax(t, cur, P, std::false_type{});
+        pv(PAR, P);
+      }
+      if (t + 2 < ntiles) store_k(PAR, ra);
+      store_v(PAR ^ 1, ra);
+      ZH_STAMP(5);
+      __syncthreads();
+      ZH_STAMP(6);
+    };
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {              // two tiles per trip: buffer indices and the S register sets are compile-time
+      step(t, std::integral_constant<int, 0>{}, sA, sB);
+      step(t + 1, std::integral_constant<int, 1>{}, sB, sA);
+    }
+    if (t + 1 < ntiles) {                         // two tiles left
+      step(t, std::integral_constant<int, 0>{}, sA, sB);
+      if (active) { softmax(t + 1, sB, P, std::true_type{}); pv(1, P); }
+    } else if (active) {                          // one tile left
+      softmax(t, sA, P, std::true_type{});
+      pv(0, P);
+    }
+  } else
+#endif
+  {
+  auto load_tile = [&](int kbase, TileRegs& r) { load_k(kbase, r); load_v(kbase, r); };
+  auto store_tile = [&](int buf, const TileRegs& r) { store_k(buf, r); store_v(buf, r); };
+  load_tile(key0, ra);
+  store_tile(0, ra);
+  __syncthreads();
+  auto compute = [&](int t) {
+    if (active) {
+      f32x16 s[NU];
+      PFrag P;
+      qk(t, s);
+      ZH_STAMP(1);
+      softmax(t, s, P, std::true_type{});
+      pv(t, P);
+    }
   };
 
   // buffer (t+1)&1 was last read in iteration t-1 and every wave passed the barrier that ended it => free to overwrite
@@ -465,12 +510,15 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     ZH_STAMP(6);
   }
 #endif
+  }
 #ifdef ZH_ATTN_STAMP
   if (p.stamp && lane == 0) {
-    long long* sp = p.stamp + ((long)id * NWAVE + wave) * 12;
+    long long* sp = p.stamp + ((long)id * NWAVE + wave) * 16;
     const long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < 8; ++i) sp[i] = st_acc[i];
+    for (int i = 0; i < 7; ++i) sp[i] = st_acc[i];
+    sp[7] = st_t0 - st_e0;                               // prologue: block decode, Q fragments, first tile
     sp[8] = st_t1 - st_t0; sp[9] = st_r1 - st_r0; sp[10] = ntiles; sp[11] = q0 < p.Tq;
+    sp[12] = st_re0; sp[13] = st_r1;                     // absolute 100-MHz times: kernel entry, end of the tile loop
   }
 #endif
 
@@ -505,6 +553,12 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
         zh_store_h4(op + 32 * d + 8 * g, p.planeO, o);
       }
   }
+#ifdef ZH_ATTN_STAMP
+  if (p.stamp && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p.stamp[((long)id * NWAVE + wave) * 16 + 14] = __builtin_amdgcn_s_memrealtime();   // output stores done
+  }
+#endif
 }
 
 // Merge of the key-split partials: per (row = image * Tq + query, head), m = max_s m_s, w_s = 2^(m_s - m),
@@ -581,12 +635,21 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   const long nblk = (long)zh_cdiv(p.groups, 8) * 8 * p.nqb * p.ksplit;  // decoded XCD-aware in the kernel
   ZH_CHECK_ARG(nblk < (1L << 31), "zh_attention_f16: grid too large");
   dim3 grid((unsigned)nblk);
+  // Split-pair kernels: the software-pipelined loop (K.Q^T of tile t+1 issued in among the softmax of tile t; bit-identical
+  // results) needs 193 registers at dh = 64, two waves per SIMD instead of three.  Same box, us, plain -> pipelined: decoder
+  // cross-attention (dh = 96, two waves either way) 120.4 -> 103.7; SelfMask T = 5505 (264 workgroups) 240.1 -> 223.2; 518-px
+  // encoder (864) 102.3 -> 98.7; 336-px encoder (1536) 76.5 -> 77.4; ViT-L/14 (20480) 1249 -> 1306.  So dh = 96 always takes it,
+  // dh = 64 when the grid needs no more rounds of the chip at two workgroups per CU than at three.
+  bool pipe = x3 && (head_dim == 96 || zh_cdiv(nblk, 512L) <= zh_cdiv(nblk, 768L));
+  if (ZH_ATTN_PIPE >= 0) pipe = x3 && ZH_ATTN_PIPE;
   if (head_dim == 64) {
-    if (x3) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((attn_f16_kernel<64, 4, 0>), grid, dim3(256), 0, stream, p);
+    if (x3 && pipe) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1, 1>), grid, dim3(256), 0, stream, p);
+    else if (x3) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1, 0>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_f16_kernel<64, 4, 0, 0>), grid, dim3(256), 0, stream, p);
   } else {
-    if (x3) hipLaunchKernelGGL((attn_f16_kernel<96, 4, 1>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((attn_f16_kernel<96, 4, 0>), grid, dim3(256), 0, stream, p);
+    if (x3 && pipe) hipLaunchKernelGGL((attn_f16_kernel<96, 4, 1, 1>), grid, dim3(256), 0, stream, p);
+    else if (x3) hipLaunchKernelGGL((attn_f16_kernel<96, 4, 1, 0>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_f16_kernel<96, 4, 0, 0>), grid, dim3(256), 0, stream, p);
   }
   ZH_CHECK_LAUNCH("zh_attention_f16");
   if (p.ksplit > 1) {
