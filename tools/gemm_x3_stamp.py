@@ -1,0 +1,44 @@
+"""Developer: per-block phase timestamps of the f16x3 GEMM's two-slot tiles (a variant library built with -DZH_GEMM_PROBE:
+   bash tools/build_variant_lib.sh tools/_abl/libzutis_probe.so -DZH_GEMM_PROBE gemm_x3.hip).  Phases: entry -> first slice issued
+(+ pos tables) -> K loop done -> output stores drained; 100-MHz wall clock and shader cycles.
+   gpurun -- env ZUTIS_HIP_LIB=$PWD/tools/_abl/libzutis_probe.so python tools/gemm_x3_stamp.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C, numpy as np, torch
+from zutis_amd import ops, _lib
+from zutis_amd.ops import Act
+dev = torch.device("cuda:0")
+raw = _lib.load(raw=True)
+raw.zh_gemm_x3_set_probe.argtypes = [C.c_void_p]
+shapes = [(56448, 4608, 256, "kv-all", "split"), (14144, 2304, 768, "qkv", "split"), (14144, 3072, 768, "fc", "split"), (14144, 768, 768, "out", "f32"),
+          (14144, 768, 3072, "proj", "f32")]
+for M, N, K, name, kind in shapes:
+    A32 = torch.randn(M, K, device=dev); W32 = torch.randn(N, K, device=dev) * 0.03
+    A = Act.empty((M, K), True, dev); ops.cast_f16(A32, A, M, K)
+    W = ops.split_weight(W32)
+    out = torch.empty(M, N, device=dev) if kind == "f32" else Act.empty((M, N), True, dev)
+    res = out if kind == "f32" else None
+    probe = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+    run = lambda: ops.gemm_x3(A, W, out, residual=res)
+    raw.zh_gemm_x3_set_probe(None)
+    for _ in range(10): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    raw.zh_gemm_x3_set_probe(probe.data_ptr())
+    run(); torch.cuda.synchronize()
+    raw.zh_gemm_x3_set_probe(None)
+    r = probe.cpu().numpy().reshape(-1, 8)
+    r = r[r[:, 0] > 0]
+    t = r[:, :4].astype(np.float64) / 100.0
+    t -= t[:, 0].min()
+    clk = ((r[:, 6] - r[:, 5]) / np.maximum(r[:, 2] - r[:, 1], 1)).mean() * 0.1
+    pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+    print(f"{name:7s} {M}x{N}x{K} {kind}: {us:.1f} us; {len(r)} blocks, span {t[:, 3].max():.1f} us, clock in the K loop {clk:.2f} GHz")
+    first = t[:, 0] < 2.0
+    for lab, sel in (("first-round blocks", first), ("later blocks", ~first)):
+        if sel.sum():
+            print(f"    {lab:18s} n={int(sel.sum()):5d}  prologue {pro[sel].mean():6.2f}  K loop {loop[sel].mean():6.2f} (min {loop[sel].min():.2f}, max {loop[sel].max():.2f})  "
+                  f"epilogue {epi[sel].mean():6.2f} (max {epi[sel].max():.2f})  block {(t[sel, 3] - t[sel, 0]).mean():6.2f} us")

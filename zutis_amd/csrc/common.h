@@ -56,15 +56,36 @@ __device__ __forceinline__ float wave_max(float v) {
 // the value subtracted below) and on gfx950 the two instructions do not agree on every input (seen on exact rounding ties,
 // ~2^-13 of all values): hi + lo was then off by one fp16 ulp.  The barrier makes `h` opaque, so lo is computed from the very
 // bits that are stored.
+// The lo halves come from v_fma_mix{lo,hi}_f16 — ONE instruction per value: it reads hi as fp16 out of the packed pair, forms
+// y - hi in fp32 (exact: the difference has at most 13 significant bits) and rounds to fp16, i.e. the same number as
+// (half)(y - (float)hi) for 3 instructions (v_cvt_f32_f16, v_sub_f32, half a v_cvt_pk_f16_f32).
+__device__ __forceinline__ unsigned zh_lo_pair(unsigned hpair, float y0, float y1) {
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l) : "v"(hpair), "v"(y0), "v"(y1));
+  return l;
+}
 __device__ __forceinline__ void zh_store_h4(half_t* p, long lo_plane, f32x4 y) {
-  half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+  typedef unsigned zh_u32x2 __attribute__((ext_vector_type(2)));
+  const half2_t h01 = {(half_t)y[0], (half_t)y[1]}, h23 = {(half_t)y[2], (half_t)y[3]};
+  zh_u32x2 h = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
   asm volatile("" : "+v"(h));
-  *(half4_t*)p = h;
+  *(zh_u32x2*)p = h;
   if (lo_plane) {
-    const half4_t l = {(half_t)(y[0] - (float)h[0]), (half_t)(y[1] - (float)h[1]), (half_t)(y[2] - (float)h[2]),
-                       (half_t)(y[3] - (float)h[3])};
-    *(half4_t*)(p + lo_plane) = l;
+    const zh_u32x2 l = {zh_lo_pair(h[0], y[0], y[1]), zh_lo_pair(h[1], y[2], y[3])};
+    *(zh_u32x2*)(p + lo_plane) = l;
   }
+}
+// 8 consecutive values as a split pair: two 16-byte stores (hi plane, lo plane)
+__device__ __forceinline__ void zh_store_h8(half_t* p, long lo_plane, f32x4 a, f32x4 b) {
+  typedef unsigned zh_u32x4 __attribute__((ext_vector_type(4)));
+  const half2_t h0 = {(half_t)a[0], (half_t)a[1]}, h1 = {(half_t)a[2], (half_t)a[3]}, h2 = {(half_t)b[0], (half_t)b[1]}, h3 = {(half_t)b[2], (half_t)b[3]};
+  zh_u32x4 h = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+  asm volatile("" : "+v"(h));
+  *(zh_u32x4*)p = h;
+  const zh_u32x4 l = {zh_lo_pair(h[0], a[0], a[1]), zh_lo_pair(h[1], a[2], a[3]), zh_lo_pair(h[2], b[0], b[1]), zh_lo_pair(h[3], b[2], b[3])};
+  *(zh_u32x4*)(p + lo_plane) = l;
 }
 __device__ __forceinline__ void zh_store_h1(half_t* p, long lo_plane, float y) {
   half_t h = (half_t)y;

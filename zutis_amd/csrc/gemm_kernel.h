@@ -313,7 +313,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     unsigned goffb[NP], ldsb[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      sbase[i] = gbase[i];
+      // wave-uniform by construction; readfirstlane makes it so for the compiler too (the "s" constraint below was handed a
+      // VGPR pair — an assembler error — in the -DZH_GEMM_PROBE build, where its uniformity analysis gave up)
+      const uintptr_t gb = (uintptr_t)gbase[i];
+      sbase[i] = (const half_t*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(gb >> 32)) << 32) |
+                                 (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gb));
       goffb[i] = goff[i] * 2u;                                   // host check: operands below 2^31 elements for this tile
       ldsb[i] = (unsigned)(uintptr_t)smem + (unsigned)lds_piece[i] * 2u;
     }
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     pos_before_prologue();
     issue2(0);
     pos_after_prologue();
+    ZH_PROBE(1);
     // Registers: 128 accumulators + A hi (32) + W hi (16) + W lo (16); a fourth fragment set does not fit (the build fails on
     // scratch).  The A lo fragments therefore REPLACE the A hi ones: the second sweep walks the A fragments in order and, as
     // soon as fragment mt has fed its TN MFMAs, its lo plane is read into the same registers — TM - 1 groups of MFMAs ahead
@@ -600,6 +605,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
           }
         }
       }
+      if constexpr (OUT == 2) {
+        // split pair: a lane takes 8 consecutive columns — one 16-byte store per plane instead of two 8-byte ones (the epilogue
+        // of a 256 x 256 tile was 7.9 us of a 29.6-us K = 256 block, store-issue bound: tools/gemm_x3_stamp.py)
+        constexpr int UPR = CPRW / 2, NIT2 = PR * UPR / 64;
+        static_assert(CPRW % 2 == 0 && (PR * UPR) % 64 == 0, "split-pair epilogue: 8-column units must tile the pass");
+#pragma clang loop unroll(full)
+        for (int it = 0; it < NIT2; ++it) {
+          const int c = it * 64 + lane;
+          const int row = c / UPR, un = c - row * UPR;
+          const int m = m0 + wr * TM * 16 + pass * PR + row;
+          const int n = n0 + wc * TN * 16 + un * 8;
+          f32x4 d0 = *(const f32x4*)(slab + row * RS + un * 32), d1 = *(const f32x4*)(slab + row * RS + un * 32 + 16);
+          if (m < p.M && n < p.N) {                       // N % 8 == 0 (host: wide_ok)
+            if (R) {
+              const float* rp = R + (long)(m % p.res_rows) * p.ldr + n;
+              d0 += *(const f32x4*)rp; d1 += *(const f32x4*)(rp + 4);
+            }
+            zh_store_h8((half_t*)p.C + cb + (long)m * p.ldc + n, p.planeC, d0, d1);
+          }
+        }
+      } else
 #pragma clang loop unroll(full)
       for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;

@@ -6,6 +6,9 @@
 // Weights are packed as W * 2^s (s chosen per matrix so that lo stays a normal fp16 number); `out_scale` = 2^-s is applied
 // to the accumulator before the bias.  Kernel: gemm_kernel.h with SPLIT = 1.
 #include "gemm_kernel.h"
+#ifdef ZH_GEMM_PROBE
+extern "C" void zh_gemm_x3_set_probe(long long* p) { g_probe = p; }   // developer build (tools/gemm_x3_stamp.py)
+#endif
 
 template <int WM, int WN, int TM, int TN, int STAGES, int VEC>
 static bool launch_x3(const GemmArgs& p, int batch, int out_kind, hipStream_t stream) {
