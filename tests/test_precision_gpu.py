@@ -376,6 +376,38 @@ def test_attention_x3_pipelined_loop_is_bitwise_the_plain_loop(dev, T):
     assert float((got - ref).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("x3", [True, False])
+@pytest.mark.parametrize("per_tile", [3.0, 7.9, 8.1, 20.0])
+def test_attention_lazy_running_max_on_rising_scores(dev, x3, per_tile):
+    """The flash kernels move their softmax reference point only when a tile's maximum exceeds it by more than 2^8
+    (attention.hip: lazy running max).  Keys whose scores RISE by `per_tile` log2 units from one key tile to the next keep the
+    reference stale for as long as the rule allows (3.0: two tiles in three; 7.9: every other tile, probabilities up to 2^7.9;
+    8.1 / 20: every tile) — the result must stay the float64 softmax to the precision of the mode."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    dh, heads, B, T = 64, 2, 2, 448
+    D = heads * dh
+    kt = 32 if x3 else 64
+    g = torch.Generator().manual_seed(5)
+    u = torch.nn.functional.normalize(torch.randn(heads, dh, generator=g), dim=-1)              # one direction per head
+    ramp = (torch.arange(T) // kt).float() * per_tile * math.log(2.0) * math.sqrt(dh)           # score offset of key j (natural log units)
+    q = (0.3 * torch.randn(B, T, heads, dh, generator=g) + u).reshape(B * T, D)
+    k = (0.3 * torch.randn(B, T, heads, dh, generator=g) + ramp.view(1, T, 1, 1) * u / (1.0 + 0.0)).reshape(B * T, D)
+    v = torch.randn(B * T, D, generator=g)
+    if not x3:                                                                                  # the fp16 kernel sees fp16 operands
+        q, k, v = q.half().float(), k.half().float(), v.half().float()
+    qd, kd, vd = (t.view(B, T, heads, dh).transpose(1, 2).double() for t in (q, k, v))
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) / math.sqrt(dh), -1) @ vd).transpose(1, 2).reshape(B * T, D)
+    mk = (lambda t: _split_act(t, dev)) if x3 else (lambda t: Act(t.to(f16)[None].contiguous().to(dev)))
+    O = Act.empty((B * T, D), x3, dev)
+    ops.attention(mk(q), mk(k), mk(v), O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D,
+                  strideQ=T * D, strideK=T * D, strideV=T * D, strideO=T * D, x3=x3)
+    got = ((O.t[0].float() + O.t[1].float()) if x3 else O.hi.float()).cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err < (3e-5 if x3 else 3e-3), err
+
+
 # ------------------------------------------------------------------------------------------- whole-model stress test
 def _stress_case(dev, B, S, sharp=3.0):
     from zutis_amd import detgen
