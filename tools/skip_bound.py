@@ -16,15 +16,23 @@ text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
 x = torch.randn((B, 3, S, S), generator=torch.Generator().manual_seed(1000)).to(dev)
 real_gemm, real_attn = engine_base._EngineBase._gemm, ops.attention
 skip = set()
+real_ln = ops.layernorm
+sites = set()
 def gemm(self, site, *a, **k):
+    sites.add(site)
     if site == "dec_kv" and "kv" in skip: return None
+    if ("site:" + site) in skip: return None
     return real_gemm(self, site, *a, **k)
 def attention(q, k_, v, o, **kw):
     if "ca" in skip and kw.get("Tk", 0) >= 1024 and kw.get("heads") == 8: return None
+    if "enc_attn" in skip and kw.get("heads") == 12: return None
     return real_attn(q, k_, v, o, **kw)
+def layernorm(*a, **k):
+    if "ln" in skip: return None
+    return real_ln(*a, **k)
 engine_base._EngineBase._gemm = gemm
 ops.attention = attention
-engine_base.ops.attention = attention
+ops.layernorm = layernorm
 eng = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision="exact")
 engs = [eng, eng.fork(), eng.fork()]
 for e in engs: e.forward(x)
@@ -54,5 +62,9 @@ print(f"full step, three in flight: {base:.3f} ms ({B / base * 1e3:.0f} images/s
 for what, name in ((("kv",), "without the two K / V projection GEMMs"), (("ca",), "without the six cross-attention launches"), (("kv", "ca"), "without both")):
     t = measure(what)
     print(f"{name:45s}: {t:.3f} ms  (-{base - t:.3f} ms, {100 * (base - t) / base:.1f} %)")
+if "--all" in sys.argv:            # attribution of the in-flight step to kernel families (each left out alone)
+    for what in [("ln",), ("enc_attn",)] + [("site:" + st,) for st in sorted(sites)]:
+        t = measure(what)
+        print(f"without {what[0]:42s}: {t:.3f} ms  (-{base - t:.3f} ms, {100 * (base - t) / base:.1f} %)")
 t = measure(())
 print(f"full step again: {t:.3f} ms")
