@@ -189,6 +189,10 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   // per-lane byte offsets of this thread's chunk(s) inside a tile: SGPR base + 32-bit offset; a tile's rows are clamped to the last
   // key of the chunk (a duplicate of a real row: its scores are masked to -inf below, its V rows meet P = 0) — host check:
   // Tk * ld * 2 < 2^32.  K and V are fetched separately: the pipelined loop keeps K one tile ahead of V.
+  // (Measured and not kept: a steady-state form with NO vector instruction per tile — constant per-lane offsets, the tile base
+  //  advanced in SGPRs — on the theory that the 750-cycle tile-load segment of the stamps was the address instructions queueing
+  //  for the vector issue port: encoder 79.8 vs 79.7 us, ViT-L/14 1331 vs 1300, fp16 kernels the same.  The segment is the
+  //  loads' own issue into the CU's shared memory pipeline.)
   const unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
   const char* const Kl = (const char*)(K + p.planeK);
   const char* const Vl = (const char*)(V + p.planeV);
