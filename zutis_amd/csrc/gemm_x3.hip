@@ -93,7 +93,9 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   //  half lines: c_proj 175 -> 168 us, QKV / c_fc / K / V within the noise), `s_setprio` around the MFMA sweeps (-20 %) and a
   //  static priority difference between the two waves of a SIMD (no change).  A 224 x 256 tile for c_fc — 768 tiles = three FULL
   //  rounds of the chip instead of 2.6 rounds of 256 x 256: 184.3 against 183 - 190 us, no change (and hipcc spills 4 registers
-  //  at TM = 7): under the power limit a round that leaves CUs idle lets the others clock higher.)
+  //  at TM = 7): under the power limit a round that leaves CUs idle lets the others clock higher.  Touching the tile's residual
+  //  lines eight slices before the end of the K loop, so that the fp32-residual epilogue finds them in the L2: out_proj 58.1 ->
+  //  63 - 65 us, c_proj 175 -> 179 — the loads stall the slice that retires them and the residual was cache-resident anyway.)
   const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
   const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
   const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
