@@ -194,7 +194,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   //  for the vector issue port: encoder 79.8 vs 79.7 us, ViT-L/14 1331 vs 1300, fp16 kernels the same.  The segment is the
   //  loads' own issue into the CU's shared memory pipeline.  Nor did 8-wave workgroups help — 256 queries sharing every tile, one
   //  workgroup per CU with the pipelined loop, a third of the tile bytes per wave: encoder 85.2 vs 75.7 us, ViT-L/14 1438 vs 1255,
-  //  518 px 99.1 vs 98.4, only SelfMask's T = 5505 gained (208 vs 219.5).)
+  //  518 px 99.1 vs 98.4, only SelfMask's T = 5505 gained (208 vs 219.5).  Dealing the partly filled last query block of every
+  //  group after all the full ones (longest first): encoder 77.8 -> 75.7, 518 px 97.3 -> 94.9, but ViT-L/14 1248 -> 1325 (its
+  //  light blocks then re-read K / V long after the group's other blocks left the L2).)
   const unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
   const char* const Kl = (const char*)(K + p.planeK);
   const char* const Vl = (const char*)(V + p.planeV);
