@@ -376,6 +376,27 @@ def test_attention_x3_pipelined_loop_is_bitwise_the_plain_loop(dev, T):
     assert float((got - ref).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("dh,heads,B,Tq,Tk", [(96, 8, 4, 100, 1764), (64, 12, 1, 449, 449), (64, 6, 1, 2200, 2200), (96, 8, 2, 100, 70)])
+def test_attention_x3_pipelined_loop_race_screen(dev, dh, heads, B, Tq, Tk):
+    """The pipelined split-pair loop overlaps LDS tile stores of K(t+2) / V(t+1) with reads of K(t+1) / V(t) behind ONE barrier per
+    tile (+ one after the first K.Q^T): 40 repeats of the same launch on grids that take that loop must return the same bits
+    (a missing barrier showed up as run-to-run differences on the first implementation)."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    D = heads * dh
+    Q, K, V = (_split_act(_randn((B * T, D), 21 + i, 1.2), dev) for i, T in enumerate((Tq, Tk, Tk)))
+    kw = dict(batch=B, heads=heads, Tq=Tq, Tk=Tk, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=Tq * D, strideK=Tk * D,
+              strideV=Tk * D, strideO=Tq * D, x3=True)
+    O0 = Act.empty((B * Tq, D), True, dev)
+    ops.attention(Q, K, V, O0, **kw)
+    ref = O0.t.clone()
+    O = Act.empty((B * Tq, D), True, dev)
+    for _ in range(40):
+        O.t.fill_(7.0)
+        ops.attention(Q, K, V, O, **kw)
+        assert torch.equal(O.t, ref)
+
+
 @pytest.mark.parametrize("x3", [True, False])
 @pytest.mark.parametrize("per_tile", [3.0, 7.9, 8.1, 20.0])
 def test_attention_lazy_running_max_on_rising_scores(dev, x3, per_tile):
