@@ -110,6 +110,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // few-row GEMMs whose 128 x 64 tiling is a bit more than one tile per CU (the decoder's 3200 x 768: 300 tiles — the CUs with two
   // tiles stream 1.2 MB of operands at the ~61 GB/s a CU's LDS-DMA sustains = 19 us, and that is the kernel): 128 x 96 tiles
   // (4 waves of 64 x 48, 3-slot ring, one block per CU) make it 200 tiles of 0.69 MB, ONE per CU
+  // (a 4- or 5-slot ring for this tile — three or four slices in flight instead of two: 19.8 / 19.8 / 20.5 us, no change)
   if (pick == 64 && M <= 4096 && N % 96 == 0) {
     const long t64 = (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch, t96 = (long)zh_cdiv(M, 128) * (N / 96) * batch;
     if (t64 > 256 && t96 <= 256) pick = 96;
