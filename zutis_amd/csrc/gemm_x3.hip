@@ -109,7 +109,8 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   }
   // few-row GEMMs whose 128 x 64 tiling is a bit more than one tile per CU (the decoder's 3200 x 768: 300 tiles — the CUs with two
   // tiles stream 1.2 MB of operands at the ~61 GB/s a CU's LDS-DMA sustains = 19 us, and that is the kernel): 128 x 96 tiles
-  // (4 waves of 64 x 48, 3-slot ring, one block per CU) make it 200 tiles of 0.69 MB, ONE per CU
+  // (3-slot ring, one block per CU) make it 200 tiles of 0.69 MB, ONE per CU.  Eight waves of 32 x 48 (two per SIMD) rather than
+  // four of 64 x 48: the fp32-residual epilogue has twice the waves to hide its loads behind (24.5 -> 21.8 us; split out 20.2 both)
   // (a 4- or 5-slot ring for this tile — three or four slices in flight instead of two: 19.8 / 19.8 / 20.5 us, no change)
   if (pick == 64 && M <= 4096 && N % 96 == 0) {
     const long t64 = (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch, t96 = (long)zh_cdiv(M, 128) * (N / 96) * batch;
@@ -132,7 +133,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   else if (pick == 448) ok = launch_x3<2, 4, 6, 4, 2, 2>(p, batch, out_kind, stream);
   else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
-  else if (pick == 96) ok = launch_x3<2, 2, 4, 3, 3, 2>(p, batch, out_kind, stream);
+  else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2>(p, batch, out_kind, stream);   // 8 waves of 32 x 48
   else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, 6, 2>(p, batch, out_kind, stream);   // 64 x 64, 6-deep ring
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
