@@ -30,6 +30,7 @@
 #pragma once
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define BK 32
 #define GROUP_M 4
@@ -567,6 +568,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const long cb = (long)batch * p.sC;
   const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
   const float osc = SPLIT ? p.out_scale : 1.0f;
+  const bool res_nowrap = p.res_rows >= p.M;               // the residual has its own row for every output row: no modulo
   if (VEC == 2) {
     // LDS-staged epilogue: the direct form stores 32-byte runs (4 lanes x 8 B) into 16 different 128-B lines per
     // instruction and measured 2.4 TB/s, fully exposed (34 % of a K=768 tile).  Here each wave transposes its tile through
@@ -610,6 +612,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         // of a 256 x 256 tile was 7.9 us of a 29.6-us K = 256 block, store-issue bound: tools/gemm_x3_stamp.py)
         constexpr int UPR = CPRW / 2, NIT2 = PR * UPR / 64;
         static_assert(CPRW % 2 == 0 && (PR * UPR) % 64 == 0, "split-pair epilogue: 8-column units must tile the pass");
+        // the residual (row-periodic table) of the whole pass is requested FIRST, branch-free (clamped addresses), so its loads
+        // are in flight together — see the fp32 form below
+        f32x4 rv0[NIT2], rv1[NIT2];
+        if (R) {
+#pragma clang loop unroll(full)
+          for (int it = 0; it < NIT2; ++it) {
+            const int c = it * 64 + lane;
+            const int row = c / UPR, un = c - row * UPR;
+            const int m = min(m0 + wr * TM * 16 + pass * PR + row, p.M - 1);
+            int n = n0 + wc * TN * 16 + un * 8;
+            n = n < p.N ? n : 0;
+            const float* rp = R + (long)(res_nowrap ? m : m % p.res_rows) * p.ldr + n;
+            rv0[it] = *(const f32x4*)rp; rv1[it] = *(const f32x4*)(rp + 4);
+          }
+        }
 #pragma clang loop unroll(full)
         for (int it = 0; it < NIT2; ++it) {
           const int c = it * 64 + lane;
@@ -618,28 +635,44 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
           const int n = n0 + wc * TN * 16 + un * 8;
           f32x4 d0 = *(const f32x4*)(slab + row * RS + un * 32), d1 = *(const f32x4*)(slab + row * RS + un * 32 + 16);
           if (m < p.M && n < p.N) {                       // N % 8 == 0 (host: wide_ok)
-            if (R) {
-              const float* rp = R + (long)(m % p.res_rows) * p.ldr + n;
-              d0 += *(const f32x4*)rp; d1 += *(const f32x4*)(rp + 4);
-            }
+            if (R) { d0 += rv0[it]; d1 += rv1[it]; }
             zh_store_h8((half_t*)p.C + cb + (long)m * p.ldc + n, p.planeC, d0, d1);
           }
         }
-      } else
+      } else {
+        // fp32 output + residual (out_proj, c_proj, the decoder's output projections): the loop used to load each residual
+        // chunk right where it is added — read slab, ~30 address instructions (an integer modulo among them), ONE load, wait, add,
+        // store — 24 exposed memory latencies per lane in a row: that, not bandwidth, was the 13-us epilogue of a 54-us out_proj
+        // block (tools/gemm_x3_stamp.py).  Now the pass's residual chunks are requested together, branch-free, before the slab is
+        // read, and `m % res_rows` is skipped when the residual has a row of its own for every output row.
+        f32x4 rv[NIT];
+        if (OUT == 0 && R) {
+          auto request = [&](auto nowrap) {
 #pragma clang loop unroll(full)
-      for (int it = 0; it < NIT; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c / CPRW, ch = c - row * CPRW;
-        const int m = m0 + wr * TM * 16 + pass * PR + row;
-        const int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
-        f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
-        if (m < p.M && n < p.N) {
-          // f32 and split-pair outputs: the slab holds fp32, the (row-periodic) residual joins before the one rounding
-          if (OUT != 1 && R) d += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
-          if (OUT == 1) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
-          else if (OUT == 0) *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
-          else {
-            zh_store_h4((half_t*)p.C + cb + (long)m * p.ldc + n, p.planeC, d);
+            for (int it = 0; it < NIT; ++it) {
+              const int c = it * 64 + lane;
+              const int row = c / CPRW, ch = c - row * CPRW;
+              const int m = min(m0 + wr * TM * 16 + pass * PR + row, p.M - 1);
+              int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
+              n = n < p.N ? n : 0;
+              rv[it] = *(const f32x4*)(R + (long)(decltype(nowrap)::value ? m : m % p.res_rows) * p.ldr + n);
+            }
+          };
+          if (res_nowrap) request(std::true_type{});        // wave-uniform: the integer modulo (~20 instructions) only where it is needed
+          else request(std::false_type{});
+        }
+#pragma clang loop unroll(full)
+        for (int it = 0; it < NIT; ++it) {
+          const int c = it * 64 + lane;
+          const int row = c / CPRW, ch = c - row * CPRW;
+          const int m = m0 + wr * TM * 16 + pass * PR + row;
+          const int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
+          f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
+          if (m < p.M && n < p.N) {
+            // f32 output: the slab holds fp32, the residual joins before the store
+            if (OUT == 0 && R) d += rv[it];
+            if (OUT == 1) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
+            else *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
           }
         }
       }
