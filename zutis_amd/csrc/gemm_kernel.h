@@ -583,15 +583,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     constexpr int NIT = PR * CPRW / 64;
     static_assert((PR * CPRW) % 64 == 0, "epilogue slab must divide into full wave reads");
     static_assert(NW * PR * RS <= (int)sizeof(smem), "epilogue slabs exceed the ring");
+    // the TN bias vectors of this lane's columns, requested together and ONCE (they used to be loaded per pass and sub-tile
+    // column behind a branch, each followed by a full wait: 16 exposed load latencies in the epilogue of a 256 x 256 tile)
+    f32x4 bvs[TN];
+    if (p.bias) {                                           // wave-uniform
+      const __attribute__((address_space(1))) float* gb = (const __attribute__((address_space(1))) float*)p.bias;
+#pragma clang loop unroll(full)
+      for (int nt = 0; nt < TN; ++nt) {
+        int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+        n = n < p.N ? n : 0;                                // columns >= N are never stored
+        bvs[nt] = *(const __attribute__((address_space(1))) f32x4*)(gb + n);
+      }
+    } else {
+#pragma clang loop unroll(full)
+      for (int nt = 0; nt < TN; ++nt) bvs[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();                                        // ring no longer read; every LDS-DMA has landed
     char* slab = (char*)smem + wave * (PR * RS);
 #pragma clang loop unroll(full)
     for (int pass = 0; pass < TM / MTP; ++pass) {
 #pragma clang loop unroll(full)
       for (int nt = 0; nt < TN; ++nt) {
-        const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+        const f32x4 bv = bvs[nt];
 #pragma clang loop unroll(full)
         for (int ml = 0; ml < MTP; ++ml) {
           f32x4 v = SPLIT ? acc[nt][pass * MTP + ml] * osc + bv : acc[nt][pass * MTP + ml] + bv;
