@@ -122,19 +122,23 @@ def gemm_roofline(ops, run_once, step_seconds):
     fl = lambda w: w[0] if isinstance(w, tuple) else w
     stats = {k: (len(v), sum(fl(w) for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
     algo_bytes = {k: sum(w[1] for w, _, _ in v if isinstance(w, tuple)) / max(1, len(v)) for k, v in prof.items()}
-    g1, g3 = stats.get("gemm_f16", (0, 0.0, 0.0)), stats.get("gemm_f16x3", (0, 0.0, 0.0))
-    dom = "gemm_f16" if g1[2] >= g3[2] else "gemm_f16x3"               # the kernel family with the larger GPU time
+    fams = {"gemm_f16": 1, "gemm_f16x2": 2, "gemm_f16x3": 3}           # family -> fp16 MFMA products per algorithmic product
+    g3 = stats.get("gemm_f16x3", (0, 0.0, 0.0))
+    dom = max(fams, key=lambda k: stats.get(k, (0, 0.0, 0.0))[2])      # the kernel family with the largest GPU time
     nl, flops_dom, tt = stats[dom]
     ach = flops_dom / tt / 1e12
     # f16x3: every algorithmic product is three fp16 MFMAs (hi*hi + lo*hi + hi*lo), so the ceiling for ALGORITHMIC flops is a
-    # third of the dense fp16 MFMA peak; achieved / peak then equals (MFMA flops issued per second) / 2.5 PF
-    x3 = dom == "gemm_f16x3"
-    peak = MFMA_F16_DENSE_PEAK_TFLOPS / 3.0 if x3 else MFMA_F16_DENSE_PEAK_TFLOPS
-    roof = {"bound": "mfma", "kernel": "gemm_f16_kernel" + ("<SPLIT=1> (zh_gemm_f16x3)" if x3 else " (zh_gemm_f16)"),
+    # third of the dense fp16 MFMA peak; achieved / peak then equals (MFMA flops issued per second) / 2.5 PF.  f16x2 (fp16-valued
+    # weights: the W lo plane is zero and its product is skipped): two MFMAs per product, ceiling = half the peak.
+    npr = fams[dom]
+    x3 = npr > 1
+    peak = MFMA_F16_DENSE_PEAK_TFLOPS / float(npr)
+    kname = {1: " (zh_gemm_f16)", 2: "<SPLIT=2> (zh_gemm_f16x3 with planeW = 0: fp16-valued weights, two products)", 3: "<SPLIT=1> (zh_gemm_f16x3)"}[npr]
+    roof = {"bound": "mfma", "kernel": "gemm_f16_kernel" + kname,
             "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "peak_note": ("algorithmic-flop ceiling of the f16x3 mode = 2500 TFLOP/s dense fp16 MFMA peak / 3 MFMA products per fp32-class "
-                          "product; frac == MFMA flops issued per second / 2500" if x3 else "dense fp16 MFMA peak (MI355X_MICROARCH.md)"),
-            "mfma_issue_tflops": round(ach * (3.0 if x3 else 1.0), 1),
+            "peak_note": (("algorithmic-flop ceiling of the f16x%d mode = 2500 TFLOP/s dense fp16 MFMA peak / %d MFMA products per fp32-class "
+                           "product; frac == MFMA flops issued per second / 2500" % (npr, npr)) if x3 else "dense fp16 MFMA peak (MI355X_MICROARCH.md)"),
+            "mfma_issue_tflops": round(ach * npr, 1),
             "traffic": None, "algorithmic_bytes_per_launch": round(algo_bytes.get(dom, 0.0)), "flops_per_launch": round(flops_dom / nl), "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
             "measured_on": "HIP events around every GEMM launch of an instrumented eager step on one stream (kernels not overlapped)",
             "gemm_share_of_step": round(tt / step_seconds, 3)}
@@ -148,11 +152,11 @@ def gemm_roofline(ops, run_once, step_seconds):
                          "tflops": round(v[1] / v[2] / 1e12, 1), "frac": round(v[1] / v[2] / 1e12 / peak, 3),
                          "share_of_kernel_time": round(v[2] / tt, 3)}
                         for k, v in sorted(by.items(), key=lambda kv: -kv[1][2])[:8]]
-    oth = "gemm_f16x3" if dom == "gemm_f16" else "gemm_f16"
-    if oth in stats:
-        no, fo, to = stats[oth]
-        roof["other_gemm"] = {"kernel": oth, "launches_per_step": no, "algorithmic_tflops": round(fo / to / 1e12, 1),
-                              "share_of_step": round(to / step_seconds, 3)}
+    others = [k for k in fams if k != dom and k in stats]
+    if others:
+        og = [{"kernel": k, "launches_per_step": stats[k][0], "algorithmic_tflops": round(stats[k][1] / stats[k][2] / 1e12, 1),
+               "share_of_step": round(stats[k][2] / step_seconds, 3)} for k in others]
+        roof["other_gemm"] = og[0] if len(og) == 1 else og
     if g3[0]:
         roof["x3_note"] = "zh_gemm_f16x3 issues three MFMAs per algorithmic product: its MFMA-pipe rate is 3x its algorithmic TFLOP/s"
     # flops the engine EXECUTES per step (sum of 2*M*N*K / 4*Tq*Tk*dh over the launches; the pack-time compositions of DESIGN 2a
@@ -195,6 +199,16 @@ def bench_c5(args):
         P[q + "mlp.c_proj.weight"], P[q + "mlp.c_proj.bias"] = w(q + "p", (D, 4 * D), D ** -0.5 * (2 * L) ** -0.5), w(q + "pb", (D,), 0.02)
         for ln in ("ln_1", "ln_2"):
             P[q + ln + ".weight"], P[q + ln + ".bias"] = w(q + ln + "w", (D,), 0.1, 1.0), w(q + ln + "b", (D,), 0.1)
+    # The reference builds this tower with clip.load() (utils/extract_image_embeddings.py:43) = build_model(): convert_weights rounds
+    # every conv / Linear weight and bias, the attention in_proj tensors and `proj` to fp16 (clip_arch.py:566-587,625) — the released
+    # checkpoints hold fp16 values anyway.  Random weights "of that architecture" therefore carry fp16 VALUES in those tensors (stored
+    # as fp32 here, the oracle reads the same numbers); LayerNorm / embedding parameters stay generic fp32.  --c5-fp32-weights keeps
+    # generic fp32 values everywhere (a fine-tuned tower: the three-product kernel).
+    if not args.c5_fp32_weights:
+        for k in list(P):
+            if k.endswith(("conv1.weight", "in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias", "c_fc.weight", "c_fc.bias",
+                           "c_proj.weight", "c_proj.bias")) or k == "visual.proj":
+                P[k] = P[k].to(torch.float16).to(torch.float32)
     enc = ClipImageEncoder(P, p, prefix="visual.", precision=args.precision)
     x = torch.randn((B, 3, 336, 336), generator=torch.Generator(device="cpu").manual_seed(2000 + rank)).to(dev)
     for _ in range(max(1, args.warmup)):
@@ -253,7 +267,11 @@ def bench_c5(args):
             "precision": {"mode": args.precision, "what": PRECISION_TEXT[args.precision]},
             "config": {"workload": f"C5: CLIP ViT-L/14@336 encode_image, {B}x3x336x336 per GPU per step, embeddings fp32 [{B},{E}], "
                                    "one all-gather of the last step's embeddings", "global_batch": world * B, "parallelism": f"dp{world}",
-                       "flops_per_image": flop},
+                       "flops_per_image": flop,
+                       "weights": ("generic fp32 values in every tensor (--c5-fp32-weights)" if args.c5_fp32_weights else
+                                   "fp16-VALUED conv / Linear / attention / proj tensors, as the reference's build_model -> convert_weights "
+                                   "leaves them (clip_arch.py:566-587,625); the engine detects it per weight at pack time and skips the "
+                                   "product with the all-zero lo plane (f16x2: bit-identical to f16x3)")},
             "model_tflops": round(total * flop / elapsed / 1e12 / world, 1), "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "embedding_norm": round(float(emb.norm(dim=1).mean().item()), 6)}), flush=True)
 
@@ -269,6 +287,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2 (default, the headline): ViT-B/16 @336, 81 classes, 32 / GPU.  c4: @518, 920 classes, 8 / GPU "
                          "(BASELINE config 4).  c5: CLIP ViT-L/14@336 image-embedding extraction, 256 / GPU / step (config 5)")
+    ap.add_argument("--c5-fp32-weights", action="store_true", help="c5: generic fp32 values in the GEMM weights instead of the fp16 values the "
+                    "reference's build_model -> convert_weights leaves there (forces the three-product kernel)")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
     ap.add_argument("--precision", default="exact", choices=["fast", "exact", "f16"],
@@ -428,7 +448,7 @@ def main():
         roof = gemm_roofline(ops, one_eager_step, elapsed / args.steps)
         if world == 1 and not args.no_live_traffic:
             extra = ["--precision", args.precision, "--batch", str(B), "--size", str(S), "--classes", str(n), "--no-io-rates"]
-            roof["traffic"], roof["traffic_source"] = live_pmc_traffic(extra, 1 if "f16x3" in roof["kernel"] else 0)
+            roof["traffic"], roof["traffic_source"] = live_pmc_traffic(extra, 1 if "SPLIT=1" in roof["kernel"] else (2 if "SPLIT=2" in roof["kernel"] else 0))
         if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 2)
         roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r03_bench_%s_kernel_stats.csv"

@@ -43,14 +43,14 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 213 /* 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 214 /* 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
 
 /* DEVELOPER entry (tests / tools, not part of the reference's surface): force the GEMM tile variant for the calls that follow.
  * group_m = super-tile height (0 = default 4); tile = tile code for zh_gemm_f16 (64|128|192|256|2064|2128|3064) and
- * zh_gemm_f16x3 (64|96|192|256|448|512|3064), 0 = the cost model's choice; tile_small = the same, applied to M <= 4096 only.  Process-wide;
+ * zh_gemm_f16x3 (64|96|192|256|448|512|3064; 5122 / 5124 = the planeW = 0 form of 512 on two slots / as 2 x 4 waves of 128 x 64), 0 = the cost model's choice; tile_small = the same, applied to M <= 4096 only.  Process-wide;
  * the initial values come from ZH_GEMM_GROUP_M / ZH_GEMM_TILE / ZH_GEMM_TILE_SMALL, read once. */
 int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small);
 
@@ -74,7 +74,11 @@ int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, 
  * (planeA / planeW = element offset of the lo plane); the kernel accumulates Ah.Wh + Ah.Wl + Al.Wh in fp32 (dropped
  * term: 2^-22 relative) and multiplies the accumulator by out_scale (weights are packed as W * 2^s, out_scale = 2^-s,
  * so that lo planes stay normal fp16 numbers) before the bias.  out_kind: 0 = f32 (residual allowed), 1 = f16,
- * 2 = split pair (lo plane at C + planeC). */
+ * 2 = split pair (lo plane at C + planeC).
+ * planeW = 0: W has NO lo plane — every value of W * 2^s is an fp16 number, as for the released CLIP towers, whose weights the
+ * reference's own constructor rounds to fp16 (convert_weights, clip_arch.py:566-587,625) before zutis.py:55 / encode_image use
+ * them: the kernel then issues Ah.Wh + Al.Wh only, bit-identical to the three-product form on a zero lo plane, at 2/3 of the
+ * MFMA work ("f16x2").  A is always a split pair. */
 int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void* W, long ldw, long strideW, long planeW,
                   void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
                   const float* bias, const float* residual, long ldr, long strideR, int res_rows,

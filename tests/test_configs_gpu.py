@@ -232,3 +232,36 @@ def test_encode_image_matches_reference_golden(dev, golden_dir, tag, precision, 
     err = np.abs(got - g[f"{tag}_embeddings"]).max()
     print(f"encode_image {tag}[{precision}]: max err {err:.2e}")
     assert err < tol, err
+
+
+def test_encode_image_fp16_valued_tower_takes_the_two_product_kernel_bitwise(dev):
+    """Config 5 runs the released CLIP tower, whose conv / Linear / attention / proj tensors hold fp16 VALUES (the reference's
+    build_model -> convert_weights, clip_arch.py:566-587,625; utils/extract_image_embeddings.py:43).  The engine packs such a
+    weight as ONE plane and zh_gemm_f16x3 skips the product with the zero lo plane: the embeddings are bit-identical to the
+    three-product kernel's, and they match the fp32 oracle run on the same rounded weights."""
+    from oracle import zutis_ref as O
+    from zutis_amd import detgen, ops
+    from zutis_amd.engine import ClipImageEncoder
+    cfg = detgen.ZutisConfig(width=256, layers=3, patch=14, grid=8, embed_dim=128)
+    sd = {k.replace("encoder.", "visual."): torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items() if k.startswith("encoder.")}
+    for k in list(sd):
+        if k.endswith(("conv1.weight", "in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias", "c_fc.weight", "c_fc.bias",
+                       "c_proj.weight", "c_proj.bias")) or k == "visual.proj":
+            sd[k] = sd[k].to(torch.float16).to(torch.float32)
+    x = torch.from_numpy(detgen.images(3, 112, 112, seed=6))
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    e2 = ClipImageEncoder(sdd, 14, precision="exact")
+    got2 = e2.encode_image(x.to(dev))
+    n_x2 = sum(1 for v in e2._w.values() if isinstance(v, ops.Act) and v.x2)
+    assert n_x2 >= 4 * cfg.layers + 1, n_x2                                  # qkv / out / fc / proj per block + the output projection
+    ops.ALLOW_X2 = False
+    try:
+        e3 = ClipImageEncoder(sdd, 14, precision="exact")
+        got3 = e3.encode_image(x.to(dev))
+        assert not any(isinstance(v, ops.Act) and v.x2 for v in e3._w.values())
+    finally:
+        ops.ALLOW_X2 = True
+    assert torch.equal(got2, got3)
+    with torch.no_grad():
+        ref = O.clip_encode_image({k.replace("visual.", "encoder."): v for k, v in sd.items()}, x, 14)
+    assert float((got2.cpu() - ref).abs().max()) < 2e-6

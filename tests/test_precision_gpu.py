@@ -472,3 +472,99 @@ def test_stress_model_c2(dev, stress, precision, tol_logit, tol_mask):
           f"({n_mis} differ, {n_bad} unexplained, largest reference margin {worst:.2e})")
     assert e_lo < tol_logit and e_pt < tol_logit and e_m < tol_mask, (e_lo, e_pt, e_m)
     assert n_bad == 0, (n_mis, n_bad, worst, e_lo)       # every differing pixel sits on a reference top-2 margin <= 2 x logit error
+
+
+# ---- f16x2: the planeW = 0 form of zh_gemm_f16x3 for fp16-valued weights (the released CLIP towers after the reference's
+#      convert_weights, clip_arch.py:566-587,625): the product with the zero lo plane is skipped, nothing else changes
+def _f16_valued(shape, seed, scale):
+    return (_randn(shape, seed, scale).to(f16)).float()
+
+
+def test_split_weight_packs_fp16_valued_weights_as_one_plane(dev):
+    from zutis_amd import ops
+    W16 = _f16_valued((96, 128), 7, 0.05).to(dev)
+    a = ops.split_weight(W16)
+    assert a.x2 and a.plane == 0 and a.t.shape[0] == 1
+    assert torch.equal(a.hi.float() * a.out_scale, W16)                 # the one plane IS the weight, exactly
+    b = ops.split_weight(W16, allow_x2=False)
+    assert (not b.x2) and b.plane != 0 and not bool(b.t[1].any()) and torch.equal(b.t[0], a.hi)
+    c = ops.split_weight(_randn((96, 128), 8, 0.05).to(dev))             # generic fp32 values keep both planes
+    assert (not c.x2) and c.plane != 0 and bool(c.t[1].any())
+    # fp16 subnormals scale up to normal numbers: still exact, still one plane
+    Wd = (torch.tensor([[2.0 ** -24, 3 * 2.0 ** -24, 2.0 ** -15, 0.5]] * 8).repeat(1, 16)).to(dev)
+    d = ops.split_weight(Wd)
+    assert d.x2 and torch.equal(d.hi.float() * d.out_scale, Wd)
+    # a plain fp16 activation is NOT accepted as the weight operand of the x3 entry (its lo plane was never looked at)
+    with pytest.raises(Exception):
+        ops.gemm_x3(_split_act(_randn((64, 128), 1), dev), ops.Act(W16.to(f16).unsqueeze(0).contiguous()), torch.empty((64, 96), dtype=f32, device=dev))
+
+
+@pytest.mark.parametrize("tile", [0, 64, 96, 192, 256, 512, 448, 3064, 5122, 5124])
+def test_gemm_x2_is_bitwise_the_x3_kernel_on_fp16_valued_weights(dev, tile):
+    """Every tile of the two-product kernel (incl. the three-slot big tiles and their two-slot A/B form) over every K phase,
+    ragged M / N, bias + residual (f32 out), ReLU / QuickGELU split-pair out, fp16 out: bit-identical to the three-product
+    kernel fed the same weight with an explicit zero lo plane, and fp32-class against float64."""
+    from zutis_amd import ops, _lib
+    from zutis_amd.ops import Act
+    L = _lib.load(raw=True)
+    try:
+        for (M, N) in ((333, 328), (700, 520), (4500, 776)):
+            for K in ((64, 128, 192, 256, 320, 448, 512, 1024) if M < 4000 else (64, 128, 192, 768, 1024)):
+                A32, W32 = _randn((M, K), 300 + K, 0.5), _f16_valued((N, K), 400 + K, 0.05)
+                bias, res = _randn((N,), 5), _randn((M, N), 6)
+                A = _split_act(A32, dev)
+                W2, W3 = ops.split_weight(W32.to(dev)), ops.split_weight(W32.to(dev), allow_x2=False)
+                assert W2.x2 and not W3.x2
+                ref = A32.double() @ W32.double().t() + bias.double()
+                bound = float((A32.abs().double() @ W32.abs().double().t()).max())
+
+                def run(W, t):
+                    _lib.check(L.zh_dev_set_gemm_overrides(0, t, 0), "zh_dev_set_gemm_overrides")
+                    o = torch.empty((M, N), dtype=f32, device=dev)
+                    ops.gemm_x3(A, W, o, bias=bias.to(dev), residual=res.to(dev))
+                    sp = Act.empty((M, N), True, dev)
+                    ops.gemm_x3(A, W, sp, bias=bias.to(dev), act=ops.ACT_QUICKGELU if K % 128 else ops.ACT_RELU)
+                    h = Act.empty((M, N), False, dev)
+                    ops.gemm_x3(A, W, h, bias=bias.to(dev))
+                    return o, sp.t.clone(), h.t.clone()
+                o2, sp2, h2 = run(W2, tile)
+                o2b, _, _ = run(W2, tile)
+                o3, sp3, h3 = run(W3, 512 if tile in (5122, 5124) else tile)     # 5122 / 5124 exist for the x2 form only
+                assert torch.equal(o2, o3) and torch.equal(sp2, sp3) and torch.equal(h2, h3), (tile, M, N, K)
+                assert torch.equal(o2, o2b), (tile, M, N, K)
+                assert float((o2.cpu().double() - (ref + res.double())).abs().max()) < 2e-6 * bound + 1e-6, (tile, M, N, K)
+    finally:
+        L.zh_dev_set_gemm_overrides(0, 0, 0)
+
+
+def test_gemm_x2_race_screen_and_pos_tables(dev):
+    """The three-slot big-tile loop of the x2 kernel (counted vmcnt(NP) with one stage in flight, run-time slot index): bitwise
+    repeatable over 12 launches at the model's big shapes, and equal to the x3 kernel; pos tables on both table paths."""
+    from zutis_amd import ops
+    for (M, N, K) in [(4500, 2304, 768), (4200, 768, 3072), (4100, 4608, 256), (5000, 1024, 1024), (4300, 3072, 1024), (8200, 1024, 4096)]:
+        A = _split_act(_randn((M, K), 100 + M), dev)
+        W32 = _f16_valued((N, K), 200 + N, 0.05).to(dev)
+        W2, W3 = ops.split_weight(W32), ops.split_weight(W32, allow_x2=False)
+        outs = []
+        for _ in range(12):
+            o = torch.empty((M, N), dtype=f32, device=dev)
+            ops.gemm_x3(A, W2, o)
+            outs.append(o)
+        o3 = torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm_x3(A, W3, o3)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, o3), (M, N, K)
+    for (hh, ww, N) in ((42, 42, 512), (20, 300, 768)):                   # LDS-staged slice / direct path (wide image)
+        B, K = 3, 256
+        M = B * hh * ww
+        A = _split_act(_randn((M, K), 9), dev)
+        W32 = _f16_valued((N, K), 10, 0.05).to(dev)
+        ty, tx = _randn((hh, N), 11).to(dev), _randn((ww, N), 12).to(dev)
+        o2, o3 = torch.empty((M, N), dtype=f32, device=dev), torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm_x3(A, ops.split_weight(W32), o2, pos=(ty, tx))
+        ops.gemm_x3(A, ops.split_weight(W32, allow_x2=False), o3, pos=(ty, tx))
+        assert torch.equal(o2, o3)
+        pos = (ty[:, None, :] + tx[None, :, :]).reshape(hh * ww, N).repeat(B, 1)
+        ref = (A.t[0].double() + A.t[1].double()) @ W32.double().t() + pos.double()
+        assert float((o2.double() - ref).abs().max()) < 1e-4

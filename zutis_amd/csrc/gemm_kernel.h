@@ -25,6 +25,13 @@
 //    lo = f16(x - hi) (22 significand bits), a K slice stages four row sets (A hi, A lo, W hi, W lo) and every
 //    accumulator gets three MFMAs, hi*hi + lo_w*hi_a + hi_w*lo_a, in fp32 (the dropped lo*lo term is 2^-22 relative).
 //    1.5x the MFMA work per staged byte of the plain kernel; 3-slot ring with prefetch distance 3.
+//  * SPLIT = 2 ("f16x2"): the same mode for a weight whose lo plane is ZERO — every value of W * 2^s is an fp16 number, which
+//    is what the reference's own constructor path produces for the released CLIP towers (`convert_weights` rounds every
+//    Linear / conv / attention weight to fp16 before ZUTIS casts the encoder back to fp32, clip_arch.py:566-587,625 and
+//    zutis.py:55; the index-dataset pipeline, utils/extract_image_embeddings.py, only ever runs such weights).  The W lo rows are
+//    neither staged nor multiplied: two MFMAs per accumulator, hi_w*hi_a + hi_w*lo_a, in the order the SPLIT = 1 kernel issues
+//    its non-zero products — the results are bit-identical to SPLIT = 1 on a zero lo plane (tests/test_kernels_gpu.py), with
+//    2/3 of the MFMA work and 3/4 of the staged bytes.  The host picks it per weight at pack time (ops.split_weight).
 //  * Block ids: XCD-aware bijective remap, then 4-row super-tiles so one XCD's concurrent tiles share panels in
 //    its 4 MiB L2 (measured L2 hit rate 82 %; 4 rows: 5 % less fabric traffic than 8 and +1 % / +3 % on the fast / exact step).
 #pragma once
@@ -91,10 +98,11 @@ __device__ __forceinline__ void wait_stages_barrier(int c) {
 template <int WM, int WN, int TM, int TN, int STAGES, int OUT, int ACT, int VEC, int SPLIT>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM * TN) >= 96 ? 2 : 1)) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
-  constexpr int NPL = SPLIT ? 2 : 1;        // operand planes
+  constexpr int NPL = SPLIT ? 2 : 1;        // planes of A
+  constexpr int NPLW = SPLIT == 1 ? 2 : 1;  // planes of W (SPLIT = 2: W is exactly its hi plane)
   constexpr int OUT_F16 = OUT == 1;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int ROWS = NPL * (BM + BN);     // LDS rows per stage (A planes then W planes), 64 B each
+  constexpr int ROWS = NPL * BM + NPLW * BN;   // LDS rows per stage (A planes then W planes), 64 B each
   constexpr int PIECES = ROWS / 16;         // 1-KiB DMA pieces per stage
   constexpr int NP = (PIECES + NW - 1) / NW;  // DMA issues per wave per stage (duplicates pad uneven splits)
   static_assert(NP >= 2 && NP <= 8 && STAGES >= (SPLIT ? 2 : 3) && STAGES <= 8, "unsupported pieces-per-wave count / ring depth");
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       goff[i] = (unsigned)row * (unsigned)p.lda + c * 8;
     } else {
       const int Rw = R0 - NPL * BM;
-      const int pl = SPLIT ? (Rw >= BN) : 0;
+      const int pl = SPLIT == 1 ? (Rw >= BN) : 0;
       int row = n0 + (Rw - pl * BN) + rl;
       row = row < p.N ? row : p.N - 1;
       gbase[i] = W + pl * p.planeW;
@@ -189,14 +197,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   // rows out of LDS.  The copy's global loads are issued BEFORE the prologue's DMA (vmcnt retires in order: the counted waits
   // of the ring can only over-wait) and stored after it.  Slices that do not fit the slot (wide images) take the direct path.
   constexpr int POS_SLOT_BYTES = STAGE_HALVES * 2, POS_NT = 64 * NW;
-  constexpr int POS_MAXIT = (POS_SLOT_BYTES / 16 + POS_NT - 1) / POS_NT;
+  // (SPLIT = 2: at most 2 passes — more register sets spilled in the 256 x 256 tiles; larger slices take the direct path.  No
+  //  x2 GEMM of the model carries pos tables: the composed K / V weights that do are never fp16-valued.)
+  constexpr int POS_MAXIT_FULL = (POS_SLOT_BYTES / 16 + POS_NT - 1) / POS_NT;
+  constexpr int POS_MAXIT = SPLIT == 2 && POS_MAXIT_FULL > 2 ? 2 : POS_MAXIT_FULL;
+  constexpr int POS_CAP_BYTES = POS_MAXIT * POS_NT * 16 < POS_SLOT_BYTES ? POS_MAXIT * POS_NT * 16 : POS_SLOT_BYTES;
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t pos_v[POS_MAXIT];
   const unsigned pos_q0 = p.pos_y ? (unsigned)m0 % (unsigned)p.pos_hw : 0u;
   const unsigned pos_y0 = p.pos_y ? pos_q0 / (unsigned)p.pos_w : 0u, pos_x0 = pos_q0 - pos_y0 * (unsigned)p.pos_w;
   const int pos_rsb = BN * (p.pos_f16 ? 2 : 4) + 16;                          // LDS row stride of the slice (bytes)
   const int pos_rows = p.pos_y ? p.pos_w + (int)((pos_x0 + BM - 1) / (unsigned)p.pos_w) + 1 : 0;
-  const bool pos_lds = p.pos_y && pos_rows * pos_rsb <= POS_SLOT_BYTES;
+  const bool pos_lds = p.pos_y && pos_rows * pos_rsb <= POS_CAP_BYTES;
   char* const pos_slot = (char*)(smem + (STAGES - 1) * STAGE_HALVES);
   auto pos_fetch_t = [&](auto tag) {                            // global -> registers, one 16-byte chunk per thread and pass
     typedef decltype(tag) T;
@@ -298,7 +310,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const half_t* rdA = smem + (wr * TM * 16) * BK + foff;
   const half_t* rdW = smem + (NPL * BM + wc * TN * 16) * BK + foff;
 
-  if constexpr (SPLIT && STAGES == 2) {
+  constexpr bool BIGT = SPLIT && BM * BN >= 192 * 256;    // the two-slot (SPLIT = 2: three-slot) big tiles
+  static_assert(!SPLIT || BIGT == (STAGES == 2 || (SPLIT == 2 && STAGES == 3 && BM * BN >= 192 * 256)), "big split-pair tiles: 2 slots (x2: 2 or 3)");
+  if constexpr (BIGT) {
     // ---- f16x3 loop, big tile (256 x 256, 8 waves of 128 x 64), TWO 64-KiB slots.  Ablations of the 3-slot 256 x 128 loop
     // (tools/gemm_x3_probe.sh, round 3; QKV shape, model-shaped operands): all 160 us; MFMAs removed 116 us; operand
     // movement removed (no DMA, no fragment reads) 119 us — the LDS-DMA stream (48 KiB per slice and CU, at its request-rate
@@ -338,31 +352,40 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     // scratch).  The A lo fragments therefore REPLACE the A hi ones: the second sweep walks the A fragments in order and, as
     // soon as fragment mt has fed its TN MFMAs, its lo plane is read into the same registers — TM - 1 groups of MFMAs ahead
     // of the third sweep's first use.
-    half8_t fa[TM], fw[2 * TN];
+    // SPLIT = 2 (W has no lo plane): two sweeps, see the loop body; a slot is 48 KiB, so the ring may hold THREE (two slices of
+    // prefetch: a slice is only 64 MFMAs per wave, ~1.2 us).
+    static_assert(TM % 2 == 0, "big split-pair tiles: even TM");
+    half8_t fa[TM], fw[NPLW * TN], fl[SPLIT == 2 ? TM / 2 : 1];
     auto read_hi = [&](int slot) {
       const int so = slot * STAGE_HALVES;
 #pragma unroll
       for (int t = 0; t < TM; ++t) fa[t] = *(const half8_t*)(rdA + so + (t * 16) * BK);
 #pragma unroll
       for (int t = 0; t < TN; ++t) fw[t] = *(const half8_t*)(rdW + so + (t * 16) * BK);
+      if constexpr (SPLIT == 1) {
 #pragma unroll
-      for (int t = 0; t < TN; ++t) fw[TN + t] = *(const half8_t*)(rdW + so + (BN + t * 16) * BK);
+        for (int t = 0; t < TN; ++t) fw[TN + t] = *(const half8_t*)(rdW + so + (BN + t * 16) * BK);
+      } else {
+#pragma unroll
+        for (int t = 0; t < TM / 2; ++t) fl[t] = *(const half8_t*)(rdA + so + (BM + t * 16) * BK);
+      }
     };
     // (Measured and not kept, round 3: the two waves of a SIMD taking their DMA issues at different points of the slice — waves
     //  4 .. 7 after the hi * hi sweep — so that one feeds the MFMA pipe while the other sits in its ~1000 cycles of issue stalls:
     //  QKV 147 -> 153 us, c_fc 189 -> 195, K / V 479 -> 488.  The later issue costs the landing time it was meant to hide.)
-    auto body = [&](int slot, bool prefetch) {
+    // `inflight` = whole stages that may still be in flight at the barrier (0: two slots, 1: the steady state of three)
+    auto body = [&](int slot, int nslot, bool prefetch, auto inflight) {
       const int so = slot * STAGE_HALVES;
 #ifndef ZH_X3_NOBAR
       // lgkmcnt(0) too: hipcc moves the last MFMAs of the previous slice (register-only) below this point and with them the
       // wait for the fragment reads they consume — every read of the slot the DMA below overwrites must have RETURNED first
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(decltype(inflight)::value * NP) : "memory");
 #endif
 #ifndef ZH_X3_NOFRAG
       read_hi(slot);
 #endif
 #ifndef ZH_X3_NODMA
-      if (prefetch) issue2(slot ^ 1);
+      if (prefetch) issue2(nslot);
 #endif
 #ifndef ZH_X3_NOMFMA
 #pragma unroll
@@ -370,34 +393,73 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+      if constexpr (SPLIT == 1) {
 #pragma unroll
-      for (int mt = 0; mt < TM; ++mt) {                // lo_w * hi_a, then this A fragment's lo plane takes its place
+        for (int mt = 0; mt < TM; ++mt) {                // lo_w * hi_a, then this A fragment's lo plane takes its place
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[TN + nt], fa[mt], acc[nt][mt], 0, 0, 0);
+          for (int nt = 0; nt < TN; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[TN + nt], fa[mt], acc[nt][mt], 0, 0, 0);
 #ifndef ZH_X3_NOFRAG
-        fa[mt] = *(const half8_t*)(rdA + so + (BM + mt * 16) * BK);
+          fa[mt] = *(const half8_t*)(rdA + so + (BM + mt * 16) * BK);
 #endif
+        }
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)                  // hi_w * lo_a
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+      } else {
+        // no lo_w sweep to read the A lo fragments under: the first half of them has a register set of its own (the 16 registers
+        // the W lo fragments would take), requested with the hi fragments and landing under the hi * hi sweep; the second half
+        // replaces the first hi fragments as soon as that sweep has issued and lands under the first half's MFMAs.  (Left to
+        // itself hipcc fused the sweeps per A fragment — 2 reads, wait, 8 MFMAs, 8 times per slice: every LDS latency exposed.)
+#ifndef ZH_X3_NOFRAG
+#pragma unroll
+        for (int t = 0; t < TM / 2; ++t) fa[t] = *(const half8_t*)(rdA + so + (BM + (TM / 2 + t) * 16) * BK);
+#endif
+#pragma unroll
+        for (int mt = 0; mt < TM / 2; ++mt)            // hi_w * lo_a, rows of the first half
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fl[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < TM / 2; ++mt)            // hi_w * lo_a, rows of the second half
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+            acc[nt][TM / 2 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][TM / 2 + mt], 0, 0, 0);
       }
-#pragma unroll
-      for (int mt = 0; mt < TM; ++mt)                  // hi_w * lo_a
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
 #else
-      acc[0][0] += (f32x4){(float)fa[0][0], (float)fw[0][1], (float)fa[TM - 1][2], (float)fw[TN][3]};
+      acc[0][0] += (f32x4){(float)fa[0][0], (float)fw[0][1], (float)fa[TM - 1][2], (float)fw[(NPLW - 1) * TN][3]};
 #endif
     };
 #ifdef ZH_X3_NOFRAG
     read_hi(0);
 #endif
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 2) {       // nk is even: two slices per trip keep the slot index a compile-time constant
-      body(0, true);
-      body(1, true);
+    typedef std::integral_constant<int, 0> fl0_t;
+    typedef std::integral_constant<int, 1> fl1_t;
+    if constexpr (STAGES == 2) {
+      int kt = 0;
+      for (; kt + 2 < nk; kt += 2) {       // nk is even: two slices per trip keep the slot index a compile-time constant
+        body(0, 1, true, fl0_t{});
+        body(1, 0, true, fl0_t{});
+      }
+      body(0, 1, true, fl0_t{});
+      body(1, 0, false, fl0_t{});
+    } else {
+      // three slots: slices kt and kt + 1 are in flight when body(kt) starts; slice kt + 2 goes into the slot body(kt - 1) read,
+      // which every wave has left once it passes body(kt)'s barrier.  The slot index is a run-time scalar here (two scalar
+      // adds per slice); the steady loop is branch-free.
+      issue2(1);                           // nk >= 2
+      int slot = 0, nslot = 2;
+      int kt = 0;
+      for (; kt + 2 < nk; ++kt) {
+        body(slot, nslot, true, fl1_t{});
+        slot = slot == 2 ? 0 : slot + 1;
+        nslot = nslot == 2 ? 0 : nslot + 1;
+      }
+      body(slot, 0, false, fl1_t{});
+      body(slot == 2 ? 0 : slot + 1, 0, false, fl0_t{});
     }
-    body(0, true);
-    body(1, false);
   } else if constexpr (SPLIT) {
     // ---- f16x3 loop.  Fragments are single-buffered (hi + lo of both operands = 64 registers at 64x64 per wave; a second
     // set does not fit next to the accumulators at two waves per SIMD): slice kt's fragments are read right after the
@@ -411,7 +473,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     for (int s = 0; s < DISTX; ++s)
       if (s < nk) issue_stage(s);
     pos_after_prologue();
-    half8_t fa[2 * TM], fw[2 * TN];
+    half8_t fa[2 * TM], fw[NPLW * TN];
     int slot = 0, wslot = DISTX % STAGES;
     auto read_frags = [&]() {
       const int so = slot * STAGE_HALVES;
@@ -419,19 +481,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) fa[pl * TM + t] = *(const half8_t*)(rdA + so + (pl * BM + t * 16) * BK);
+        if (pl < NPLW) {
 #pragma unroll
-        for (int t = 0; t < TN; ++t) fw[pl * TN + t] = *(const half8_t*)(rdW + so + (pl * BN + t * 16) * BK);
+          for (int t = 0; t < TN; ++t) fw[pl * TN + t] = *(const half8_t*)(rdW + so + (pl * BN + t * 16) * BK);
+        }
       }
     };
     // three sweeps over the accumulators keep dependent MFMAs TM*TN issues apart: hi*hi, lo_w*hi_a, hi_w*lo_a
     auto sweeps = [&]() {
 #pragma unroll
-      for (int sw = 0; sw < 3; ++sw)
+      for (int sw = 0; sw < 3; ++sw) {
+        if (SPLIT == 2 && sw == 1) continue;           // W has no lo plane
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
           for (int mt = 0; mt < TM; ++mt)
             acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[(sw == 1 ? TN : 0) + nt], fa[(sw == 2 ? TM : 0) + mt], acc[nt][mt], 0, 0, 0);
+      }
     };
     auto advance = [&]() {
       slot = slot + 1 == STAGES ? 0 : slot + 1;
@@ -454,12 +520,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 #ifndef ZH_X3_NOMFMA
       sweeps();
 #else
-      acc[0][0] += (f32x4){(float)fa[0][0], (float)fw[0][1], (float)fa[TM][2], (float)fw[TN][3]};
+      acc[0][0] += (f32x4){(float)fa[0][0], (float)fw[0][1], (float)fa[TM][2], (float)fw[(NPLW - 1) * TN][3]};
 #endif
       // hi fragments first, then 2 MFMAs per lo-fragment read / DMA issue
       __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-      for (int i = 0; i < TM + TN; ++i) {
+      for (int i = 0; i < TM + (NPLW - 1) * TN; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
@@ -476,7 +542,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       sweeps();
       __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-      for (int i = 0; i < TM + TN; ++i) {
+      for (int i = 0; i < TM + (NPLW - 1) * TN; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
@@ -576,7 +642,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     // slab holds fp32 and each lane writes 8 B to the hi plane and 8 B to the lo plane).
     constexpr int ESZ = OUT_F16 ? 2 : 4;
     constexpr int RS = TN * 16 * ESZ + 16;                  // slab row stride (bytes)
-    constexpr int PR0 = (OUT_F16 ? 64 : 32) < TM * 16 ? (OUT_F16 ? 64 : 32) : TM * 16;
+    constexpr int PRW = (OUT_F16 ? 64 : 32) / (TN >= 8 ? 2 : 1);   // wide wave tiles: half the rows per pass (the pass's residual / slab registers)
+    constexpr int PR0 = PRW < TM * 16 ? PRW : TM * 16;
     constexpr int PR = (TM * 16) % PR0 == 0 ? PR0 : (TM * 16 <= 48 ? TM * 16 : 16);       // rows per pass (divides the wave tile)
     constexpr int MTP = PR / 16;
     constexpr int CPRW = TN * 16 * ESZ / 16;                // 16-B chunks per row

@@ -10,24 +10,24 @@
 extern "C" void zh_gemm_x3_set_probe(long long* p) { g_probe = p; }   // developer build (tools/gemm_x3_stamp.py)
 #endif
 
-template <int WM, int WN, int TM, int TN, int STAGES, int VEC>
+template <int WM, int WN, int TM, int TN, int STAGES, int VEC, int SP = 1>
 static bool launch_x3(const GemmArgs& p, int batch, int out_kind, hipStream_t stream) {
   const int key = out_kind * 8 + p.act;
   switch (key) {
-    case 0 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 0, ZH_ACT_NONE, VEC, 1>(p, batch, stream); return true;
-    case 0 + ZH_ACT_SIGMOID: launch_one<WM, WN, TM, TN, STAGES, 0, ZH_ACT_SIGMOID, VEC, 1>(p, batch, stream); return true;
-    case 8 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_NONE, VEC, 1>(p, batch, stream); return true;
-    case 16 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_NONE, VEC, 1>(p, batch, stream); return true;
+    case 0 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 0, ZH_ACT_NONE, VEC, SP>(p, batch, stream); return true;
+    case 0 + ZH_ACT_SIGMOID: launch_one<WM, WN, TM, TN, STAGES, 0, ZH_ACT_SIGMOID, VEC, SP>(p, batch, stream); return true;
+    case 8 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_NONE, VEC, SP>(p, batch, stream); return true;
+    case 16 + ZH_ACT_NONE: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_NONE, VEC, SP>(p, batch, stream); return true;
     default: break;
   }
   if (VEC == 2) {   // activations feeding another GEMM only occur on 16-byte aligned rows
     switch (key) {
-      case 8 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_QUICKGELU, 2, 1>(p, batch, stream); return true;
-      case 8 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_RELU, 2, 1>(p, batch, stream); return true;
-      case 8 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_GELU_ERF, 2, 1>(p, batch, stream); return true;
-      case 16 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_QUICKGELU, 2, 1>(p, batch, stream); return true;
-      case 16 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_RELU, 2, 1>(p, batch, stream); return true;
-      case 16 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_GELU_ERF, 2, 1>(p, batch, stream); return true;
+      case 8 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_QUICKGELU, 2, SP>(p, batch, stream); return true;
+      case 8 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_RELU, 2, SP>(p, batch, stream); return true;
+      case 8 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, STAGES, 1, ZH_ACT_GELU_ERF, 2, SP>(p, batch, stream); return true;
+      case 16 + ZH_ACT_QUICKGELU: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_QUICKGELU, 2, SP>(p, batch, stream); return true;
+      case 16 + ZH_ACT_RELU: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_RELU, 2, SP>(p, batch, stream); return true;
+      case 16 + ZH_ACT_GELU_ERF: launch_one<WM, WN, TM, TN, STAGES, 2, ZH_ACT_GELU_ERF, 2, SP>(p, batch, stream); return true;
       default: break;
     }
   }
@@ -44,7 +44,10 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   ZH_CHECK_ARG(K % 64 == 0, "zh_gemm_f16x3: K=%d must be a multiple of 64", K);
   ZH_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && strideA % 8 == 0 && strideW % 8 == 0 && planeA % 8 == 0 && planeW % 8 == 0,
                "zh_gemm_f16x3: lda/ldw/strides/planes must be multiples of 8 halves (16-byte rows)");
-  ZH_CHECK_ARG(planeA != 0 && planeW != 0, "zh_gemm_f16x3: operands must be split pairs (plane offset of the lo half)");
+  // planeW == 0: W has no lo plane — every packed value is an fp16 number (the released CLIP weights after the reference's
+  // convert_weights) — and the kernel skips the zero product (SPLIT = 2 in gemm_kernel.h: bit-identical results, 2/3 of the MFMAs)
+  ZH_CHECK_ARG(planeA != 0, "zh_gemm_f16x3: A must be a split pair (plane offset of the lo half)");
+  const bool x2 = planeW == 0;
   ZH_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "zh_gemm_f16x3: A/W must be 16-byte aligned");
   ZH_CHECK_ARG(act >= 0 && act <= 4, "zh_gemm_f16x3: bad activation %d", act);
   // the kernel addresses an operand row as base + (32-bit element offset): keep one batch item's A / W below 2^32 elements
@@ -124,9 +127,26 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   if (pick == 64 && (long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch <= 256) pick = 3064;
   const int forced = gemm_dev_overrides().tile;
   if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448 || forced == 3064) pick = forced;
+  if ((forced == 5122 || forced == 5124) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
-  if ((pick == 512 || pick == 448) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
+  if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
   bool ok;
+  if (x2) {
+    // the big tiles stage 48 KiB per slice without the W lo rows: three slots (two slices of prefetch) fit the LDS
+    if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0, 2>(p, batch, out_kind, stream);
+    else if (!wide_ok) ok = launch_x3<2, 2, 4, 2, 3, 1, 2>(p, batch, out_kind, stream);
+    // 256 x 256 as 4 x 2 waves of 64 x 128: an A fragment costs two LDS reads (hi, lo), a W fragment one — 16 reads per slice and wave
+    // instead of the 20 of 128 x 64 waves (5124): L/14 qkv 1604 -> 1568 us, c_proj 2266 -> 2099, c_fc 2219 -> 2204 (same box)
+    else if (pick == 512) ok = launch_x3<4, 2, 4, 8, 3, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 5122) ok = launch_x3<2, 4, 8, 4, 2, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 5124) ok = launch_x3<2, 4, 8, 4, 3, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 448) ok = launch_x3<2, 4, 6, 4, 3, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 4, 2, 2>(p, batch, out_kind, stream);   // 4 slots: the epilogue slabs need 102 KiB
+    else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, 6, 2, 2>(p, batch, out_kind, stream);
+    else ok = launch_x3<2, 2, 4, 2, 3, 2, 2>(p, batch, out_kind, stream);
+  } else
   if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
   else if (!wide_ok) ok = launch_x3<2, 2, 4, 2, 3, 1>(p, batch, out_kind, stream);
   else if (pick == 512) ok = launch_x3<2, 4, 8, 4, 2, 2>(p, batch, out_kind, stream);

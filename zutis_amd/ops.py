@@ -61,14 +61,16 @@ def _chk(t: torch.Tensor, dtype, name: str):
 class Act:
     """An fp16 activation (or weight) tensor, optionally stored as a split pair for the f16x3 precision (zutis_hip.h):
     `t` has shape [P, ...] with P = 1 (plain fp16) or 2 (hi, lo); `hi` = t[0] is the plain fp16 tensor every fp16 consumer
-    reads; `plane` = element offset hi -> lo (0 when not split); `out_scale` = 2^-s for weights packed as W * 2^s."""
-    __slots__ = ("t", "hi", "plane", "out_scale")
+    reads; `plane` = element offset hi -> lo (0 when not split); `out_scale` = 2^-s for weights packed as W * 2^s; `x2`: a
+    split_weight() pack whose lo plane would be all zeros, stored as its hi plane alone."""
+    __slots__ = ("t", "hi", "plane", "out_scale", "x2")
 
     def __init__(self, t: torch.Tensor, out_scale: float = 1.0):
         assert t.dtype == f16 and t.shape[0] in (1, 2)
         self.t, self.hi = t, t[0]
         self.plane = t.stride(0) if t.shape[0] == 2 else 0
         self.out_scale = float(out_scale)
+        self.x2 = False      # set by split_weight(): one plane that IS the fp32 weight (times 2^s) exactly — the f16x2 operand form
 
     @staticmethod
     def empty(shape, split: bool, device) -> "Act":
@@ -77,13 +79,17 @@ class Act:
     def view(self, t_hi: torch.Tensor) -> "Act":
         """The same pair seen through a view of the hi plane (column / row slices keep the plane offset)."""
         a = Act.__new__(Act)
-        a.t, a.hi, a.plane, a.out_scale = self.t, t_hi, self.plane, self.out_scale
+        a.t, a.hi, a.plane, a.out_scale, a.x2 = self.t, t_hi, self.plane, self.out_scale, self.x2
         return a
 
 
-def split_weight(w32: torch.Tensor) -> Act:
+ALLOW_X2 = True     # developer switch (tests / A-B): False packs every weight as two planes, zero lo plane or not
+
+
+def split_weight(w32: torch.Tensor, allow_x2: Optional[bool] = None) -> Act:
     """Pack-time split of an fp32 weight for zh_gemm_f16x3: W * 2^s with s chosen so that max|W| lands in [2^13, 2^14)
-    (hi far from overflow, lo = f16(W*2^s - hi) a normal fp16 number); out_scale = 2^-s is exact."""
+    (hi far from overflow, lo = f16(W*2^s - hi) a normal fp16 number); out_scale = 2^-s is exact.  A weight whose lo plane
+    would be all zeros is packed as ONE plane (the "f16x2" form of zh_gemm_f16x3) unless allow_x2 (default: ALLOW_X2) is False."""
     w = w32.detach().to(f32)
     m = float(w.abs().max()) if w.numel() else 0.0
     s = 0 if m == 0.0 or not math.isfinite(m) else 13 - math.floor(math.log2(m))
@@ -91,6 +97,13 @@ def split_weight(w32: torch.Tensor) -> Act:
     ws = w * (2.0 ** s)
     hi = ws.to(f16)
     lo = (ws - hi.to(f32)).to(f16)
+    if (ALLOW_X2 if allow_x2 is None else allow_x2) and not bool(lo.any()):
+        # every value of W * 2^s is an fp16 number: the released CLIP towers, whose Linear / conv / attention weights the
+        # reference's constructor rounds to fp16 (convert_weights, clip_arch.py:566-587,625) before they are cast back to fp32
+        # (zutis.py:55).  One plane, plane = 0: zh_gemm_f16x3 then skips the product with the zero lo plane (bit-identical).
+        a = Act(hi.unsqueeze(0).contiguous(), out_scale=2.0 ** -s)
+        a.x2 = True
+        return a
     return Act(torch.stack([hi, lo]).contiguous(), out_scale=2.0 ** -s)
 
 
@@ -125,8 +138,8 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
     are split pairs (Act with plane != 0); out is an f32 tensor, an fp16 tensor / plain Act, or a split Act (then the residual is
     added in fp32 before the one rounding, act must be none).  pos: see _pos()."""
     L = _lib.load()
-    if not (isinstance(A, Act) and isinstance(W, Act) and A.plane and W.plane):
-        raise _lib.ZutisHipError("gemm_x3: both operands must be split pairs")
+    if not (isinstance(A, Act) and isinstance(W, Act) and A.plane and (W.plane or W.x2)):
+        raise _lib.ZutisHipError("gemm_x3: A must be a split pair, W a split pair or a one-plane split_weight() pack")
     a, w = A.hi, W.hi
     M = a.shape[-2] if M is None else M
     K = a.shape[-1] if K is None else K
@@ -146,7 +159,10 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
             float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N),
             act, M, N, K, batch, _stream())
     nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 4, 4 if kind == 0 else (4 if kind == 2 else 2), residual is not None)
-    _lib.check(_launch("gemm_f16x3", (2.0 * M * N * K * batch, nbytes, (M, N, K, batch)), lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
+    if not W.plane:                                  # one-plane weight: 2 bytes per element instead of 4
+        nbytes -= N * K * 2.0 * (batch if (strideW or batch == 1) else 1)
+    name = "gemm_f16x3" if W.plane else "gemm_f16x2"
+    _lib.check(_launch(name, (2.0 * M * N * K * batch, nbytes, (M, N, K, batch)), lambda: L.zh_gemm_f16x3(*args)), "zh_gemm_f16x3")
     return out
 
 
