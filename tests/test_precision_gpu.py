@@ -499,7 +499,7 @@ def test_split_weight_packs_fp16_valued_weights_as_one_plane(dev):
         ops.gemm_x3(_split_act(_randn((64, 128), 1), dev), ops.Act(W16.to(f16).unsqueeze(0).contiguous()), torch.empty((64, 96), dtype=f32, device=dev))
 
 
-@pytest.mark.parametrize("tile", [0, 64, 96, 192, 256, 512, 448, 3064, 5122, 5124])
+@pytest.mark.parametrize("tile", [0, 64, 96, 192, 256, 512, 448, 3064, 5122, 5124, 4484])
 def test_gemm_x2_is_bitwise_the_x3_kernel_on_fp16_valued_weights(dev, tile):
     """Every tile of the two-product kernel (incl. the three-slot big tiles and their two-slot A/B form) over every K phase,
     ragged M / N, bias + residual (f32 out), ReLU / QuickGELU split-pair out, fp16 out: bit-identical to the three-product
@@ -529,7 +529,7 @@ def test_gemm_x2_is_bitwise_the_x3_kernel_on_fp16_valued_weights(dev, tile):
                     return o, sp.t.clone(), h.t.clone()
                 o2, sp2, h2 = run(W2, tile)
                 o2b, _, _ = run(W2, tile)
-                o3, sp3, h3 = run(W3, 512 if tile in (5122, 5124) else tile)     # 5122 / 5124 exist for the x2 form only
+                o3, sp3, h3 = run(W3, {5122: 512, 5124: 512, 4484: 448}.get(tile, tile))     # 5122 / 5124 / 4484 exist for the x2 form only
                 assert torch.equal(o2, o3) and torch.equal(sp2, sp3) and torch.equal(h2, h3), (tile, M, N, K)
                 assert torch.equal(o2, o2b), (tile, M, N, K)
                 assert float((o2.cpu().double() - (ref + res.double())).abs().max()) < 2e-6 * bound + 1e-6, (tile, M, N, K)

@@ -3,6 +3,7 @@
 # ZUTIS_HIP_LIB (box-to-box variance on this pool is +-3 %).   usage: tools/build_variant_lib.sh OUT.so "-DFLAG ..." file.hip [file.hip ...]
 set -e
 OUT=$1; FLAGS=$2; shift 2
+mkdir -p "$(dirname "$OUT")"
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d)
 SKIP=""

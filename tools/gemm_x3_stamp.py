@@ -1,7 +1,7 @@
 """Developer: per-block phase timestamps of the f16x3 GEMM's two-slot tiles (a variant library built with -DZH_GEMM_PROBE:
    bash tools/build_variant_lib.sh tools/_abl/libzutis_probe.so -DZH_GEMM_PROBE gemm_x3.hip).  Phases: entry -> first slice issued
 (+ pos tables) -> K loop done -> output stores drained; 100-MHz wall clock and shader cycles.
-   gpurun -- env ZUTIS_HIP_LIB=$PWD/tools/_abl/libzutis_probe.so python tools/gemm_x3_stamp.py"""
+   gpurun -- env ZUTIS_HIP_LIB=$PWD/tools/_abl/libzutis_probe.so python tools/gemm_x3_stamp.py [x2]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C, numpy as np, torch
@@ -12,8 +12,14 @@ raw = _lib.load(raw=True)
 raw.zh_gemm_x3_set_probe.argtypes = [C.c_void_p]
 shapes = [(56448, 4608, 256, "kv-all", "split"), (14144, 2304, 768, "qkv", "split"), (14144, 3072, 768, "fc", "split"), (14144, 768, 768, "out", "f32"),
           (14144, 768, 3072, "proj", "f32")]
+X2 = "x2" in sys.argv[1:]          # fp16-valued weights: the two-product kernel (SPLIT = 2), plus the ViT-L/14 shapes of config 5
+if X2:
+    shapes = shapes[1:] + [(147712, 3072, 1024, "L qkv", "split"), (147712, 1024, 1024, "L out", "f32"), (147712, 4096, 1024, "L fc", "split"),
+                           (147712, 1024, 4096, "L proj", "f32")]
 for M, N, K, name, kind in shapes:
     A32 = torch.randn(M, K, device=dev); W32 = torch.randn(N, K, device=dev) * 0.03
+    if X2:
+        W32 = W32.half().float()
     A = Act.empty((M, K), True, dev); ops.cast_f16(A32, A, M, K)
     W = ops.split_weight(W32)
     out = torch.empty(M, N, device=dev) if kind == "f32" else Act.empty((M, N), True, dev)

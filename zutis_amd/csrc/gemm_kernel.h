@@ -354,8 +354,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     // of the third sweep's first use.
     // SPLIT = 2 (W has no lo plane): two sweeps, see the loop body; a slot is 48 KiB, so the ring may hold THREE (two slices of
     // prefetch: a slice is only 64 MFMAs per wave, ~1.2 us).
-    static_assert(TM % 2 == 0, "big split-pair tiles: even TM");
-    half8_t fa[TM], fw[NPLW * TN], fl[SPLIT == 2 ? TM / 2 : 1];
+    constexpr int H1 = (TM + 1) / 2, H2 = TM - H1;     // SPLIT = 2: A lo fragments with registers of their own / replacing hi fragments
+    half8_t fa[TM], fw[NPLW * TN], fl[SPLIT == 2 ? H1 : 1];
     auto read_hi = [&](int slot) {
       const int so = slot * STAGE_HALVES;
 #pragma unroll
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         for (int t = 0; t < TN; ++t) fw[TN + t] = *(const half8_t*)(rdW + so + (BN + t * 16) * BK);
       } else {
 #pragma unroll
-        for (int t = 0; t < TM / 2; ++t) fl[t] = *(const half8_t*)(rdA + so + (BM + t * 16) * BK);
+        for (int t = 0; t < H1; ++t) fl[t] = *(const half8_t*)(rdA + so + (BM + t * 16) * BK);
       }
     };
     // (Measured and not kept, round 3: the two waves of a SIMD taking their DMA issues at different points of the slice — waves
@@ -415,18 +415,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         // itself hipcc fused the sweeps per A fragment — 2 reads, wait, 8 MFMAs, 8 times per slice: every LDS latency exposed.)
 #ifndef ZH_X3_NOFRAG
 #pragma unroll
-        for (int t = 0; t < TM / 2; ++t) fa[t] = *(const half8_t*)(rdA + so + (BM + (TM / 2 + t) * 16) * BK);
+        for (int t = 0; t < H2; ++t) fa[t] = *(const half8_t*)(rdA + so + (BM + (H1 + t) * 16) * BK);
 #endif
 #pragma unroll
-        for (int mt = 0; mt < TM / 2; ++mt)            // hi_w * lo_a, rows of the first half
+        for (int mt = 0; mt < H1; ++mt)                // hi_w * lo_a, rows of the first half
 #pragma unroll
           for (int nt = 0; nt < TN; ++nt)
             acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fl[mt], acc[nt][mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < TM / 2; ++mt)            // hi_w * lo_a, rows of the second half
+        for (int mt = 0; mt < H2; ++mt)                // hi_w * lo_a, rows of the second half
 #pragma unroll
           for (int nt = 0; nt < TN; ++nt)
-            acc[nt][TM / 2 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][TM / 2 + mt], 0, 0, 0);
+            acc[nt][H1 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nt], fa[mt], acc[nt][H1 + mt], 0, 0, 0);
       }
 #else
       acc[0][0] += (f32x4){(float)fa[0][0], (float)fw[0][1], (float)fa[TM - 1][2], (float)fw[(NPLW - 1) * TN][3]};

@@ -127,9 +127,9 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   if (pick == 64 && (long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch <= 256) pick = 3064;
   const int forced = gemm_dev_overrides().tile;
   if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448 || forced == 3064) pick = forced;
-  if ((forced == 5122 || forced == 5124) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
+  if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
-  if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
+  if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124 || pick == 4484) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
   bool ok;
   if (x2) {
     // the big tiles stage 48 KiB per slice without the W lo rows: three slots (two slices of prefetch) fit the LDS
@@ -140,6 +140,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
     else if (pick == 512) ok = launch_x3<4, 2, 4, 8, 3, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 5122) ok = launch_x3<2, 4, 8, 4, 2, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 5124) ok = launch_x3<2, 4, 8, 4, 3, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 4484) ok = launch_x3<4, 2, 3, 8, 3, 2, 2>(p, batch, out_kind, stream);   // 192 x 256 as 4 x 2 waves of 48 x 128
     else if (pick == 448) ok = launch_x3<2, 4, 6, 4, 3, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 4, 2, 2>(p, batch, out_kind, stream);   // 4 slots: the epilogue slabs need 102 KiB
