@@ -345,6 +345,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       }
     };
     pos_before_prologue();
+    // Three slots: the counted wait of the loop (one stage in flight) only works if the compiler has no vector-memory load of its
+    // own outstanding there.  The pos prefetch registers are consumed under a condition it cannot correlate with the one they
+    // were loaded under, so it kept an `s_waitcnt vmcnt(0)` INSIDE the loop, on the first reuse of such a register — which also
+    // drains every LDS-DMA (they are inline asm, invisible to its counter model) and turns two slices of prefetch into none.
+    // A wait it can see, before the first DMA, retires them here (nothing is outstanding unless the GEMM carries pos tables).
+    if constexpr (STAGES == 3) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
     issue2(0);
     pos_after_prologue();
     ZH_PROBE(1);
