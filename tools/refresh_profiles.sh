@@ -21,7 +21,7 @@ prof bench_exact $Q --inflight 1
 prof bench_exact_inflight $Q
 prof bench_fast $Q --inflight 1 --precision fast
 prof c4 $Q --workload c4
-prof c5 $Q --workload c5
+prof c5 $Q --workload c5 --inflight 1
 python3 bench.py 2> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench.json
 python3 bench.py --workload c4 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c4.json
 python3 bench.py --workload c5 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c5.json
