@@ -568,3 +568,35 @@ def test_gemm_x2_race_screen_and_pos_tables(dev):
         pos = (ty[:, None, :] + tx[None, :, :]).reshape(hh * ww, N).repeat(B, 1)
         ref = (A.t[0].double() + A.t[1].double()) @ W32.double().t() + pos.double()
         assert float((o2.double() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("x2", [False, True])
+def test_gemm_x3_tail_peel_is_bitwise_one_launch(dev, x2):
+    """A big-tile GEMM a few tiles over whole rounds of the chip (257 m-tiles x 4 n-tiles = 4 rounds + 4 tiles) is run as the
+    whole rounds + a small-tile call on the last m-tile row (gemm_x3.hip "tail peel"): bitwise the single forced-tile launch, for
+    the fp32 + residual and the split-pair epilogues, ragged last tile included."""
+    from zutis_amd import ops, _lib
+    from zutis_amd.ops import Act
+    L = _lib.load(raw=True)
+    M, N, K = 257 * 256 - 37, 1024, 128
+    A = _split_act(_randn((M, K), 1, 0.5), dev)
+    W32 = (_f16_valued if x2 else _randn)((N, K), 2, 0.05).to(dev)
+    W = ops.split_weight(W32)
+    assert W.x2 == x2
+    bias, res = _randn((N,), 3).to(dev), _randn((M, N), 4).to(dev)
+
+    def run():
+        o = torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm_x3(A, W, o, bias=bias, residual=res)
+        sp = Act.empty((M, N), True, dev)
+        ops.gemm_x3(A, W, sp, bias=bias, act=ops.ACT_QUICKGELU)
+        return o, sp.t
+    o_p, sp_p = run()                                   # cost model: 256 x 256 tiles, 1028 of them -> peeled
+    try:
+        _lib.check(L.zh_dev_set_gemm_overrides(0, 512, 0), "zh_dev_set_gemm_overrides")
+        o_1, sp_1 = run()                               # forced tile: one launch, no peel
+    finally:
+        L.zh_dev_set_gemm_overrides(0, 0, 0)
+    assert torch.equal(o_p, o_1) and torch.equal(sp_p, sp_1)
+    ref = (A.t[0].double() + A.t[1].double()) @ W32.double().t() + bias.double() + res.double()
+    assert float((o_p.double() - ref).abs().max()) < 1e-4

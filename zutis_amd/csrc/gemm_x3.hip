@@ -130,6 +130,31 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
   if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124 || pick == 4484) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
+  // Tail peel.  A big-tile GEMM whose tile count is a few tiles more than whole rounds of the 256-CU chip pays a full round for
+  // them (config 5's out_proj / c_proj, 147712 x 1024: 2308 tiles of 256 x 256 = 9 rounds + 4 tiles, i.e. 10 rounds: +10 %).  When
+  // the surplus is at most a quarter round, the last m-tile rows that hold it are peeled into a second call on the row range
+  // [M', M) — its own, small-tile choice; same stream, same arithmetic per output element (the K order of a tile does not depend
+  // on the tile shape: results are bitwise those of one launch) — and the main launch is left with whole rounds.
+  // Only where row offsets are plain pointer offsets: no batch, no pos tables, a residual with a row of its own per output row.
+  if ((pick == 512 || pick == 448) && wide_ok && batch == 1 && !pos_y && (!residual || res_rows >= M) && !forced && gemm_dev_overrides().tile_small == 0) {
+    const int BMp = pick == 512 ? 256 : 192;
+    const long nbm = zh_cdiv(M, BMp), nbn = zh_cdiv(N, 256), tiles = nbm * nbn, rem = tiles % 256;
+    if (tiles > 4 * 256 && rem > 0 && rem <= 64) {
+      const long r = (rem + nbn - 1) / nbn;                       // m-tile rows to peel
+      const long M1 = (nbm - r) * BMp;                             // rows that stay: whole tiles, whole rounds (or just under)
+      if (r * nbn <= 64 && M1 > 0 && M1 < M) {
+        const long esz = out_kind == 0 ? 4 : 2;
+        int rc = zh_gemm_f16x3(A, lda, strideA, planeA, W, ldw, strideW, planeW, C, ldc, strideC, planeC, out_kind, out_scale, bias,
+                               residual, ldr, strideR, residual ? res_rows : 0, pos_y, pos_x, ld_pos, pos_h, pos_w, pos_f16, act,
+                               (int)M1, N, K, 1, stream);
+        if (rc != ZH_OK) return rc;
+        return zh_gemm_f16x3((const char*)A + M1 * lda * 2, lda, strideA, planeA, W, ldw, strideW, planeW,
+                             (char*)C + M1 * ldc * esz, ldc, strideC, planeC, out_kind, out_scale, bias,
+                             residual ? residual + M1 * ldr : nullptr, ldr, strideR, residual ? (int)(res_rows - M1) : 0,
+                             pos_y, pos_x, ld_pos, pos_h, pos_w, pos_f16, act, (int)(M - M1), N, K, 1, stream);
+      }
+    }
+  }
   bool ok;
   if (x2) {
     // the big tiles stage 48 KiB per slice without the W lo rows: three slots (two slices of prefetch) fit the LDS
