@@ -129,3 +129,29 @@ def test_split_weight_packing_host_logic():
         assert float((lo[lo > 0] < 6.1e-5).float().mean()) < 0.02          # (almost) no subnormal lo halves
     z = ops.split_weight(torch.zeros((4, 64)))
     assert z.out_scale == 1.0 and float(z.t.abs().max()) == 0.0
+
+
+def test_split_weight_one_plane_for_fp16_valued_weights_host_logic():
+    """The f16x2 operand form (zh_gemm_f16x3 with planeW = 0): a weight whose values are fp16 numbers — what the reference's
+    convert_weights leaves in the CLIP towers, clip_arch.py:566-587 — has an all-zero lo plane at ANY power-of-two scale, so it is
+    packed as its hi plane alone, exactly; a single non-representable value brings the second plane back."""
+    import torch
+    from zutis_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for scale in (0.03, 1.0, 2e-4, 300.0):
+        w = (torch.randn((48, 64), generator=g) * scale).to(torch.float16).to(torch.float32)      # includes fp16 subnormals at 2e-4
+        a = ops.split_weight(w)
+        assert a.x2 and a.plane == 0 and a.t.shape == (1, 48, 64)
+        assert torch.equal(a.hi.to(torch.float64) * a.out_scale, w.to(torch.float64))
+        assert a.view(a.hi[:16]).x2                                                              # row slices keep the marker
+        b = ops.split_weight(w, allow_x2=False)
+        assert (not b.x2) and b.t.shape == (2, 48, 64) and not bool(b.t[1].any()) and torch.equal(b.t[0], a.hi)
+        w2 = w.clone()
+        w2[3, 5] = w2[3, 5] * (1.0 + 2.0 ** -14) + (2.0 ** -30 if w2[3, 5] == 0 else 0.0)          # not an fp16 number any more
+        c = ops.split_weight(w2)
+        assert (not c.x2) and c.plane != 0 and int((c.t[1] != 0).sum()) == 1
+    ops.ALLOW_X2 = False
+    try:
+        assert not ops.split_weight(torch.ones((4, 64))).x2
+    finally:
+        ops.ALLOW_X2 = True
