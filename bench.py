@@ -294,6 +294,139 @@ def bench_c5(args):
             "embedding_norm": round(float(emb.norm(dim=1).mean().item()), 6)}), flush=True)
 
 
+def bench_c3(args):
+    """Config 3: COCO-20K-style instance segmentation at its own shape and batch — coco20k_eval.py:241-268 evaluates image
+    by image — through the drop-in `networks.zutis.ZUTIS`: a step = ONE 480x640 image, forward + predict(mask_type="instance",
+    nms_type="hard", size=(H, W)) down to the list of COCO prediction dicts (RLE strings, boxes: host objects, as in the
+    reference).  Weights / text rows / threshold are the config-3 fixture's (tests/golden/c3_vitb16.npz: 100 candidates, 9 categories,
+    17 hard-NMS survivors — generated from the reference), so the step's predictions are checked against the reference's own.
+    The second half of the config, the bilateral-solver refinement (utils/bilateral_solver.py; 512x683 as in the pseudo-label
+    pipeline), is timed as its own object with an HBM roofline.  Ranks evaluate independent images: no collective in the path."""
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    import numpy as np
+    root = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(root, "zutis_amd", "dropin"))
+    from zutis_amd import detgen, ops, rle
+    from networks.zutis import ZUTIS
+    cfg = detgen.VIT_B16
+    g = np.load(os.path.join(root, "tests", "golden", "c3_vitb16.npz"))
+    H, W, thr = 480, 640, detgen.C3_THRESHOLD
+    tag = f"{H}x{W}"
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the constructor prints "clip is loaded." like the reference's (zutis.py:105): keep stdout to the one JSON line
+        net = ZUTIS(categories=[f"c{i}" for i in range(81)], clip_arch="ViT-B/16", device=dev, text_embeddings=torch.from_numpy(g["text"]))
+    sd = {k: torch.from_numpy(v) for k, v in detgen.c3_state_dict(cfg).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval().requires_grad_(False)
+    net.precision = args.precision
+    x = torch.from_numpy(detgen.images(1, H, W, seed=21)).to(dev)
+
+    def step():
+        out = net(x)
+        return net.predict(out, mask_type="instance", threshold=thr, size=(H, W), image_ids=[7], nms_type="hard")
+    for _ in range(max(3, args.warmup)):
+        preds = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    roof = cpu = parity = solver = None
+    if rank == 0:
+        roof = gemm_roofline(ops, step, elapsed / args.steps)
+        # parity with the reference's own predictions for this image (fixture generated by oracle/gen_golden.py from /root/reference)
+        ref_cat, ref_score, ref_area = g[f"{tag}_cat"], g[f"{tag}_score"], g[f"{tag}_area"]
+        cats = [p["category_id"] for p in preds]
+        areas = [int(rle.decode(p["segmentation"]).sum()) for p in preds]
+        same_list = cats == list(ref_cat)
+        parity = {"predictions": len(preds), "reference_predictions": int(len(ref_cat)), "category_list_identical": bool(same_list),
+                  "score_max_abs_err": (float(np.abs(np.array([p["score"] for p in preds]) - ref_score).max()) if same_list else None),
+                  "mask_area_max_abs_diff_sorted_per_category": (int(max(abs(a - b) for c in set(cats) for a, b in zip(
+                      sorted(a for a, cc in zip(areas, cats) if cc == c), sorted(int(a) for a, cc in zip(ref_area, ref_cat) if cc == c)))) if same_list else None),
+                  "against": "tests/golden/c3_vitb16.npz: the reference's ZUTIS.forward + predict(instance, hard NMS) on the same image and weights "
+                             "(tests/test_configs_gpu.py::test_c3_native_resolution_instance_predict holds scores to 5e-4, areas to 8 px)"}
+    if rank == 0 and world == 1:
+        # ---- bilateral solver at the pseudo-label size: one image per call and 8 per call (zh_bilateral_solve_batch)
+        Hs, Ws = 512, 683
+        yy, xx = np.mgrid[:Hs, :Ws]
+        solver = {"size": [Hs, Ws], "unit": "ms per image", "bound": "hbm", "peak_TBps": 8.0,
+                  "algorithmic_bytes_note": "N*(3+1+8+16) + V*250*(25 CG + 11 bistochastisation iterations) per image (SURVEY 8d)"}
+        for Bs in (1, 8):
+            rgb = torch.from_numpy(np.stack([detgen.selfmask_like_rgb(Hs, Ws, seed=3 + i) for i in range(Bs)])).to(dev)
+            tg = torch.from_numpy(np.stack([(((yy - 250) ** 2 + (xx - 300 - 3 * i) ** 2) < 150 ** 2).astype(np.uint8) for i in range(Bs)])).to(dev)
+            soft, stats = ops.bilateral_solve(rgb, tg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                ops.bilateral_solve(rgb, tg)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 20
+            V = float(stats[:, 0].float().mean().item())
+            byts = Hs * Ws * (3 + 1 + 8 + 16) + V * 250 * 36
+            solver[f"batch{Bs}"] = {"ms_per_image": round(dt / Bs * 1e3, 4), "vertices": round(V), "achieved_TBps": round(byts * Bs / dt / 1e12, 3),
+                                    "frac": round(byts * Bs / dt / 8e12, 3), "cg_iterations": [int(v) for v in stats[:, 1].tolist()[:2]]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import torch.nn.functional as F
+        from oracle import zutis_ref as O
+        from oracle import bilateral_ref as OB
+        torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+        Pc = O.to_torch_params(detgen.c3_state_dict(cfg))
+        textc = torch.from_numpy(g["text"])
+        xc = x.cpu()
+
+        def cpu_step():
+            o = O.zutis_forward(Pc, xc, cfg.patch, cfg.dec_heads)
+            mp = o["mask_proposals"][:, -1]
+            _, cat, score = O.instance_scores(o["mask_proposals"], o["patch_tokens"], textc, threshold=thr)
+            masks = (F.interpolate(mp, size=(H, W), mode="bilinear") > thr).numpy()
+            kept = O.mask_nms(masks[0], score[0], cat[0], "hard")
+            return [rle.encode(np.asfortranarray(masks[0][m]).astype(np.uint8)) for _, m, _ in kept]
+        with torch.no_grad():
+            cpu_step()
+            times = []
+            for _ in range(3):
+                t1 = time.perf_counter(); kept = cpu_step(); times.append(time.perf_counter() - t1)
+        dt = sorted(times)[1]
+        cpu = {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"the step's image, oracle forward + instance predict + hard NMS + RLE ({len(kept)} kept), median of 3 passes "
+                         f"({', '.join('%.1f' % t for t in times)} s); host has {os.cpu_count()} hardware threads"}
+        if solver is not None:
+            rgb1 = detgen.selfmask_like_rgb(512, 683, seed=3)
+            tg1 = (((yy - 250) ** 2 + (xx - 300) ** 2) < 150 ** 2).astype(np.uint8)
+            t1 = time.perf_counter(); OB.bilateral_solver_output(rgb1, tg1); dts = time.perf_counter() - t1
+            solver["cpu_baseline"] = {"ms_per_image": round(dts * 1e3, 1), "kind": "port", "cores": 1,
+                                      "sample": "oracle/bilateral_ref.py (numpy / scipy.sparse restatement of utils/bilateral_solver.py), one 512x683 image"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        total = world * args.steps
+        print(json.dumps({
+            "metric": "images/sec, COCO-20K-shaped instance segmentation, ViT-B/16, one 480x640 image per step: ZUTIS forward + instance predict "
+                      "with hard mask NMS to COCO RLE dicts (BASELINE config 3)", "value": round(total / elapsed, 1),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
+            "precision": {"mode": args.precision, "what": PRECISION_TEXT[args.precision]},
+            "config": {"workload": f"C3: batch 1, {H}x{W}, 81 categories, 100 queries, threshold {thr}, hard NMS; drop-in networks.zutis.ZUTIS "
+                                   "(coco20k_eval.py:241-268 evaluates image by image)", "global_batch": world, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "bilateral_solver": solver}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,9 +435,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE config[1]: batch 32)")
     ap.add_argument("--size", type=int, default=336)
     ap.add_argument("--classes", type=int, default=81)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, the headline): ViT-B/16 @336, 81 classes, 32 / GPU.  c4: @518, 920 classes, 8 / GPU "
-                         "(BASELINE config 4).  c5: CLIP ViT-L/14@336 image-embedding extraction, 256 / GPU / step (config 5)")
+                         "(BASELINE config 4).  c5: CLIP ViT-L/14@336 image-embedding extraction, 256 / GPU / step (config 5).  "
+                         "c3: instance segmentation image by image at 480x640 + the bilateral solver at 512x683 (config 3)")
     ap.add_argument("--c5-fp32-weights", action="store_true", help="c5: generic fp32 values in the GEMM weights instead of the fp16 values the "
                     "reference's build_model -> convert_weights leaves there (forces the three-product kernel)")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
@@ -336,6 +470,8 @@ def main():
             args.batch = 8
     if args.workload == "c5":
         return bench_c5(args)
+    if args.workload == "c3":
+        return bench_c3(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

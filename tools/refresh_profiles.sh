@@ -25,7 +25,8 @@ prof c5 $Q --workload c5 --inflight 1
 python3 bench.py 2> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench.json
 python3 bench.py --workload c4 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c4.json
 python3 bench.py --workload c5 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c5.json
+python3 bench.py --workload c3 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c3.json
 python3 bench.py --inflight 1 --no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision --no-io-rates 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_inflight1.json
 head -c 600 gpurun_out/${R}_bench.json; echo
-for f in gpurun_out/${R}_bench_c4.json gpurun_out/${R}_bench_c5.json gpurun_out/${R}_bench_inflight1.json; do python3 -c "
+for f in gpurun_out/${R}_bench_c3.json gpurun_out/${R}_bench_c4.json gpurun_out/${R}_bench_c5.json gpurun_out/${R}_bench_inflight1.json; do python3 -c "
 import json,sys; d=json.load(open('$f')); print('$f', d['value'], d['unit'], d['ms_per_step'], d.get('roofline',{}) and d['roofline'].get('achieved'))"; done
