@@ -425,6 +425,32 @@ def test_mask_runs_device_rle_matches_host_encoder(dev):
     assert rles2[0] == rle.encode(masks[0])
 
 
+@pytest.mark.parametrize("H,W", [(480, 640), (427, 640), (700, 96), (3, 1000), (333, 64)])
+def test_mask_runs_panel_blocks_at_evaluation_sizes(dev, H, W):
+    """zh_mask_runs runs one block per (mask, 64-column panel): blob masks at the COCO-20K evaluation sizes (ten panels, the
+    16-byte load path), a tall narrow, a 3-row and a one-panel mask: RLE strings, boxes and areas equal the host encoder's;
+    masks whose runs straddle every panel boundary (horizontal stripes) and empty / full masks included."""
+    from zutis_amd import rle
+    from zutis_amd.engine import ZutisEngine
+    rng = np.random.default_rng(H * 1000 + W)
+    yy, xx = np.mgrid[:H, :W]
+    masks = []
+    for i in range(6):                                     # blobs: a few hundred runs, like thresholded mask proposals
+        cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(0.1, 0.5) * max(H, W)
+        masks.append((((yy - cy) ** 2 + (xx - cx) ** 2) < r ** 2) & (rng.random((H, W)) > 0.02))
+    stripes = np.zeros((H, W), bool); stripes[::3] = True
+    masks += [stripes, np.zeros((H, W), bool), np.ones((H, W), bool), rng.random((H, W)) > 0.5]
+    m8 = np.stack(masks).astype(np.uint8)
+    dm = torch.from_numpy(m8).to(dev)
+    sel = np.arange(len(masks), dtype=np.int32)[::-1].copy()
+    rles, boxes, areas = ZutisEngine.encode_masks(None, dm, sel, max_runs=H * W + 1)
+    for j, q in enumerate(sel):
+        assert areas[j] == int(m8[q].sum()), (q, areas[j])
+        assert rles[j] == rle.encode(m8[q]), q
+        if m8[q].any():
+            assert boxes[j] == rle.mask_to_box(m8[q]), q
+
+
 def test_retrieval_shard_merge_equals_unsharded(dev):
     """Per-shard device top-k + merge_topk (what retrieve_topk_sharded does after its all-gather) == retrieve_topk over all
     images, including an exact cross-shard score tie (smaller global index first) and a shard shorter than k."""

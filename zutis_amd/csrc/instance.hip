@@ -218,87 +218,148 @@ extern "C" int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels
 
 // ---- run-length transitions + box + area of selected masks ON THE DEVICE (replaces the B x Q x H x W mask D2H in front of
 //      pycocotools.mask.encode / masks_to_boxes, networks/zutis.py:288-294,446-452).  COCO RLE runs are column-major:
-//      a block owns one mask, walks it in 64-column panels staged through LDS (coalesced row reads), counts the value
-//      changes per column, prefix-sums them, and writes the column-major pixel positions where the value changes.
+//      the mask is cut into 64-column panels staged through LDS (coalesced row reads); the value changes per column segment are
+//      counted, prefix-summed, and the column-major pixel positions where the value changes are written.
 //      counts = diff([0, positions..., H*W]) with a leading 0-run inserted when pixel 0 is set (host, tiny).
-// PANEL = columns per pass: 256 (every thread owns a column; the panel [H][256] must fit the LDS: H <= ~620) or 64 (taller masks).
-// Round 3: the 64-column form kept 64 of 256 threads busy and staged the panel with byte loads — 0.75 ms for 17 masks of
-// 480 x 640 at batch 1 (a fifth of the instance predict).
-template <int PANEL>
+// One block per (mask, 64-column panel) — round 3: one block per mask walked its 480 x 640 pixels with one thread per column, twice,
+// 17 blocks on 256 CUs: 194 us, a sixth of the batch-1 instance predict.  A panel's block
+//   1. counts the transitions in the columns LEFT of its panel straight from global memory, row-major and coalesced (a vertical
+//      transition is a difference between a row and the row above it; plus the H-1 -> 0 wrap between neighbouring columns): the
+//      offset of its first run in the mask's position list, no workspace and no second launch;
+//   2. stages its panel [H][64] in LDS, four threads per column (a quarter of the rows each) count their segment's transitions,
+//      a 256-entry scan in (column, segment) order places them, a second walk writes the column-major positions;
+//   3. the block of the LAST panel also knows the total and scans the whole mask once more (row-major) for the box and the area.
+#define RUNS_PANEL 64
+#define RUNS_SEG 4
+__device__ __forceinline__ unsigned zh_nz_bytes(unsigned w) {   // 0x01 in every byte of w that is non-zero
+  const unsigned t = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w;
+  return (t >> 7) & 0x01010101u;
+}
 __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* masks, const int* sel, int H, int W, int max_runs,
                                                         int* positions, int* nruns, int* box_area) {
-  extern __shared__ unsigned char sm[];                    // [H][PANEL] panel, then int colcnt[PANEL + 1]
-  __shared__ int s_base, s_first, s_minx, s_maxx, s_miny, s_maxy, s_area;
-  const unsigned char* m = masks + (long)sel[blockIdx.x] * H * W;
-  int* pos = positions + (long)blockIdx.x * max_runs;
-  int* colcnt = (int*)(sm + (((long)H * PANEL + 15) & ~15L));
-  if (threadIdx.x == 0) { s_base = 0; s_first = m[0] != 0; s_minx = W; s_maxx = -1; s_miny = H; s_maxy = -1; s_area = 0; }
-  __syncthreads();
+  extern __shared__ unsigned char sm[];                    // [H][64] panel
+  __shared__ int s_red[256];
+  __shared__ int s_minx, s_maxx, s_miny, s_maxy, s_area;
+  const int tid = threadIdx.x, mi = blockIdx.x, pnl = blockIdx.y;
+  const unsigned char* m = masks + (long)sel[mi] * H * W;
+  int* pos = positions + (long)mi * max_runs;
+  const int x0 = pnl * RUNS_PANEL, pw = min(RUNS_PANEL, W - x0);
   const bool vec = (W % 16 == 0) && (((uintptr_t)m & 15) == 0);
-  for (int x0 = 0; x0 < W; x0 += PANEL) {
-    const int pw = min(PANEL, W - x0);
-    if (vec && pw % 16 == 0) {                             // 16 columns per load: rows are 16-byte aligned
-      const int cpr = PANEL / 16;
-      for (int i = threadIdx.x; i < H * cpr; i += 256) {
-        const int y = i / cpr, c16 = i - y * cpr;
-        uint4 v = {0u, 0u, 0u, 0u};
-        if (c16 * 16 < pw) v = *(const uint4*)(m + (long)y * W + x0 + c16 * 16);
-        // != 0 per byte: a byte is nonzero iff (b | (b + 0x7f)) has its top bit set (for b in 0..255 taken bytewise without carries)
-        auto nz = [](unsigned w) { const unsigned t = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w; return (t >> 7) & 0x01010101u; };
-        uint4 o = {nz(v.x), nz(v.y), nz(v.z), nz(v.w)};
-        *(uint4*)(sm + (long)y * PANEL + c16 * 16) = o;
+  // ---- 1. transitions in columns [0, x0)
+  int cnt = 0;
+  if (x0 > 0) {
+    if (vec) {                                             // x0 % 64 == 0: whole 16-column chunks
+      const int cpr = x0 / 16;
+      for (int i = tid; i < (H - 1) * cpr; i += 256) {
+        const int y = 1 + i / cpr, c16 = i % cpr;
+        const uint4 a = *(const uint4*)(m + (long)y * W + c16 * 16), b = *(const uint4*)(m + (long)(y - 1) * W + c16 * 16);
+        cnt += __popc(zh_nz_bytes(a.x) ^ zh_nz_bytes(b.x)) + __popc(zh_nz_bytes(a.y) ^ zh_nz_bytes(b.y)) +
+               __popc(zh_nz_bytes(a.z) ^ zh_nz_bytes(b.z)) + __popc(zh_nz_bytes(a.w) ^ zh_nz_bytes(b.w));
       }
     } else {
-      for (int i = threadIdx.x; i < H * PANEL; i += 256) {
-        const int y = i / PANEL, c = i - y * PANEL;
-        sm[i] = c < pw ? (m[(long)y * W + x0 + c] != 0) : 0;
+      for (long i = tid; i < (long)(H - 1) * x0; i += 256) {
+        const int y = 1 + (int)(i / x0), x = (int)(i % x0);
+        cnt += (m[(long)y * W + x] != 0) != (m[(long)(y - 1) * W + x] != 0);
       }
     }
-    __syncthreads();
-    // pass 1: transitions per column (a column's first pixel is compared with the previous column's last pixel)
-    if (threadIdx.x < PANEL) {
-      const int c = threadIdx.x;
-      int cnt = 0;
-      if (c < pw) {
-        unsigned char prev = c > 0 ? sm[(H - 1) * PANEL + c - 1] : (x0 > 0 ? (m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0]);
-        int area = 0, ymin = H, ymax = -1;
-        for (int y = 0; y < H; ++y) {
-          const unsigned char v = sm[y * PANEL + c];
-          cnt += v != prev;
-          prev = v;
-          if (v) { ++area; ymin = min(ymin, y); ymax = y; }
-        }
-        if (area) {
-          atomicAdd(&s_area, area); atomicMin(&s_minx, x0 + c); atomicMax(&s_maxx, x0 + c);
-          atomicMin(&s_miny, ymin); atomicMax(&s_maxy, ymax);
-        }
-      }
-      colcnt[c] = cnt;
+    for (int x = 1 + tid; x < x0; x += 256)                // the wrap from the bottom of column x - 1 to the top of column x
+      cnt += (m[x] != 0) != (m[(long)(H - 1) * W + x - 1] != 0);
+  }
+  s_red[tid] = cnt;
+  // ---- 2. the panel
+  if (vec && pw % 16 == 0) {
+    constexpr int cpr = RUNS_PANEL / 16;
+    for (int i = tid; i < H * cpr; i += 256) {
+      const int y = i / cpr, c16 = i - y * cpr;
+      uint4 v = {0u, 0u, 0u, 0u};
+      if (c16 * 16 < pw) v = *(const uint4*)(m + (long)y * W + x0 + c16 * 16);
+      uint4 o = {zh_nz_bytes(v.x), zh_nz_bytes(v.y), zh_nz_bytes(v.z), zh_nz_bytes(v.w)};
+      *(uint4*)(sm + (long)y * RUNS_PANEL + c16 * 16) = o;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {                               // exclusive scan of <= PANEL counts
-      int acc = s_base;
-      for (int c = 0; c < PANEL; ++c) { const int t = colcnt[c]; colcnt[c] = acc; acc += t; }
-      s_base = acc;
+  } else {
+    for (int i = tid; i < H * RUNS_PANEL; i += 256) {
+      const int y = i / RUNS_PANEL, c = i - y * RUNS_PANEL;
+      sm[i] = c < pw ? (m[(long)y * W + x0 + c] != 0) : 0;
     }
-    __syncthreads();
-    // pass 2: write positions
-    if (threadIdx.x < pw) {
-      const int c = threadIdx.x;
-      unsigned char prev = c > 0 ? sm[(H - 1) * PANEL + c - 1] : (x0 > 0 ? (m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0]);
-      int o = colcnt[c];
-      for (int y = 0; y < H; ++y) {
-        const unsigned char v = sm[y * PANEL + c];
-        if (v != prev) { if (o < max_runs) pos[o] = (x0 + c) * H + y; ++o; }
-        prev = v;
-      }
-    }
+  }
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {                   // block sum of the left-hand count
+    if (tid < st) s_red[tid] += s_red[tid + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    nruns[blockIdx.x * 2] = s_base;                        // number of transitions (may exceed max_runs => host fallback)
-    nruns[blockIdx.x * 2 + 1] = s_first;                   // value of pixel 0
-    int* b = box_area + blockIdx.x * 5;
+  const int base = s_red[0];
+  __syncthreads();
+  // thread = (column c, segment sg) in the order the positions are emitted: entry e = c * RUNS_SEG + sg == tid
+  const int c = tid / RUNS_SEG, sg = tid % RUNS_SEG;
+  const int hs = (H + RUNS_SEG - 1) / RUNS_SEG, y0 = min(H, sg * hs), y1 = min(H, y0 + hs);
+  unsigned char prev0 = 0;
+  int mine = 0;
+  if (c < pw && y0 < y1) {
+    if (y0 > 0) prev0 = sm[(y0 - 1) * RUNS_PANEL + c];
+    else if (c > 0) prev0 = sm[(H - 1) * RUNS_PANEL + c - 1];
+    else prev0 = x0 > 0 ? (unsigned char)(m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0];   // pixel 0 starts the list: no transition
+    unsigned char prev = prev0;
+    for (int y = y0; y < y1; ++y) {
+      const unsigned char v = sm[y * RUNS_PANEL + c];
+      mine += v != prev;
+      prev = v;
+    }
+  }
+  s_red[tid] = mine;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {                      // inclusive scan (Hillis - Steele)
+    const int t = tid >= d ? s_red[tid - d] : 0;
+    __syncthreads();
+    s_red[tid] += t;
+    __syncthreads();
+  }
+  const int total = base + s_red[255];
+  if (mine) {
+    int o = base + s_red[tid] - mine;
+    unsigned char prev = prev0;
+    for (int y = y0; y < y1; ++y) {
+      const unsigned char v = sm[y * RUNS_PANEL + c];
+      if (v != prev) { if (o < max_runs) pos[o] = (x0 + c) * H + y; ++o; }
+      prev = v;
+    }
+  }
+  // ---- 3. totals, box and area (the last panel's block)
+  if (pnl != (int)gridDim.y - 1) return;
+  if (tid == 0) { s_minx = W; s_maxx = -1; s_miny = H; s_maxy = -1; s_area = 0; }
+  __syncthreads();
+  int area = 0, minx = W, maxx = -1, miny = H, maxy = -1;
+  if (vec) {
+    const int cpr = W / 16;
+    for (int i = tid; i < H * cpr; i += 256) {
+      const int y = i / cpr, c16 = i - y * cpr;
+      const uint4 v = *(const uint4*)(m + (long)y * W + c16 * 16);
+      const unsigned w4[4] = {zh_nz_bytes(v.x), zh_nz_bytes(v.y), zh_nz_bytes(v.z), zh_nz_bytes(v.w)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (w4[k]) {
+          area += __popc(w4[k]);
+          const int xb = c16 * 16 + k * 4;
+          minx = min(minx, xb + (__ffs(w4[k]) - 1) / 8);
+          maxx = max(maxx, xb + (31 - __clz(w4[k])) / 8);
+          miny = min(miny, y); maxy = max(maxy, y);
+        }
+    }
+  } else {
+    for (long i = tid; i < (long)H * W; i += 256) {
+      if (m[i]) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        ++area; minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
+      }
+    }
+  }
+  if (area) {
+    atomicAdd(&s_area, area); atomicMin(&s_minx, minx); atomicMax(&s_maxx, maxx); atomicMin(&s_miny, miny); atomicMax(&s_maxy, maxy);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    nruns[mi * 2] = total;                                 // number of transitions (may exceed max_runs => host fallback)
+    nruns[mi * 2 + 1] = m[0] != 0;                         // value of pixel 0
+    int* b = box_area + mi * 5;
     b[0] = s_minx; b[1] = s_miny; b[2] = s_maxx; b[3] = s_maxy; b[4] = s_area;
   }
 }
@@ -307,18 +368,12 @@ extern "C" int zh_mask_runs(const unsigned char* masks, const int* sel, int n_se
                             int* positions, int* nruns, int* box_area, hipStream_t stream) {
   ZH_CHECK_ARG(masks && sel && positions && nruns && box_area && n_sel > 0 && H > 0 && W > 0 && max_runs > 0, "zh_mask_runs: bad arguments");
   ZH_CHECK_ARG((long)H * W < (1L << 31), "zh_mask_runs: mask too large");
-  auto lds_of = [&](int panel) { return (((size_t)H * panel + 15) & ~(size_t)15) + (panel + 1) * sizeof(int); };
-  const size_t cap = 160 * 1024 - 64;
-  if (lds_of(256) <= cap) {
-    const size_t lds = lds_of(256);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mask_runs_kernel<256>, dim3(n_sel), dim3(256), lds, stream, masks, sel, H, W, max_runs, positions, nruns, box_area);
-  } else {
-    const size_t lds = lds_of(64);
-    ZH_CHECK_ARG(lds <= cap, "zh_mask_runs: H=%d too tall for the LDS panel", H);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mask_runs_kernel<64>, dim3(n_sel), dim3(256), lds, stream, masks, sel, H, W, max_runs, positions, nruns, box_area);
-  }
+  const size_t lds = ((size_t)H * RUNS_PANEL + 15) & ~(size_t)15;
+  ZH_CHECK_ARG(lds <= 150 * 1024, "zh_mask_runs: H=%d too tall for the LDS panel", H);
+  const int npanel = zh_cdiv(W, RUNS_PANEL);
+  ZH_CHECK_ARG(npanel <= 65535, "zh_mask_runs: mask too wide");
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(mask_runs_kernel, dim3(n_sel, npanel), dim3(256), lds, stream, masks, sel, H, W, max_runs, positions, nruns, box_area);
   ZH_CHECK_LAUNCH("zh_mask_runs");
   return ZH_OK;
 }

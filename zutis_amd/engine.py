@@ -325,12 +325,16 @@ class ZutisEngine(_EngineBase):
             ops.mask_iou_counts(m[b], Q, H * W, inter[b], uni[b])
         idx, sc, cat, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma,
                                          threshold)
-        cnt_h, idx_h, sc_h, cat_h = cnt.cpu().numpy(), idx.cpu().numpy(), sc.cpu().numpy(), cat.cpu().numpy()
+        # ONE device -> host copy for the five small results (every copy synchronises the stream): indices, categories and counts are
+        # small integers, exact in float64 next to the float64 scores
+        f64 = torch.float64
+        packed = torch.cat([idx.to(f64), sc.to(f64), cat.to(f64), category_ids.to(f64), cnt.to(f64).view(B, 1)], dim=1).cpu().numpy()
+        idx_h, sc_h, cat_h = packed[:, :Q], packed[:, Q:2 * Q], packed[:, 2 * Q:3 * Q]    # entries past cnt are uninitialised: read per element
+        all_cat, cnt_h = packed[:, 3 * Q:4 * Q].astype(np.int64), packed[:, 4 * Q].astype(np.int64)
         # The kernel walks the categories in ascending id; the reference walks `set(category_ids_per_image)` (zutis.py:237-238), i.e.
         # CPython's iteration order of a set of numpy int64 scalars — ascending only while every id is below the hash table's
         # size.  Re-create that very set on the host (Q ids per image) and order the per-category groups by it (stable: the
         # selection order inside a category is the kernel's, which is the reference's).
-        all_cat = category_ids.cpu().numpy()
         out = []
         for b in range(B):
             rank = {int(c): i for i, c in enumerate(set(all_cat[b]))}
@@ -348,7 +352,8 @@ class ZutisEngine(_EngineBase):
             return [], [], []
         sel_dev = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32)).to(masks_u8.device)
         pos, nr, ba = ops.mask_runs(masks_u8.contiguous(), sel_dev, max_runs)
-        nr_h, ba_h = nr.cpu().numpy(), ba.cpu().numpy()
+        nb_h = torch.cat([nr, ba], dim=1).cpu().numpy()           # one copy (= one stream synchronisation) for both small tables
+        nr_h, ba_h = nb_h[:, :2], nb_h[:, 2:]
         keep = int(min(max_runs, max(1, nr_h[:, 0].max())))
         pos_h = pos[:, :keep].cpu().numpy()
         rles, boxes, areas = [], [], []
