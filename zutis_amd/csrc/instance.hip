@@ -173,7 +173,24 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const unsigned char* mas
   const unsigned char* m = masks + n * P + w * 64;
   unsigned long long bits = 0;
   const long lim = P - w * 64 < 64 ? P - w * 64 : 64;
-  for (long i = 0; i < lim; ++i) bits |= (unsigned long long)(m[i] != 0) << i;
+  if (lim == 64 && (((uintptr_t)m) & 15) == 0) {
+    // four 16-byte loads instead of 64 byte loads (66 us for 100 masks of 480 x 640 at batch 1): a word of four {0,1} bytes
+    // b0..b3 times 0x01020408 has b0 | b1 << 1 | b2 << 2 | b3 << 3 in bits 24..27 (the other partial products land on
+    // distinct lower bits: no carries)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = *(const uint4*)(m + q * 16);
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned t = ((w4[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w4[k];
+        const unsigned nz = (t >> 7) & 0x01010101u;
+        bits |= (unsigned long long)(((nz * 0x01020408u) >> 24) & 0xFu) << (q * 16 + k * 4);
+      }
+    }
+  } else {
+    for (long i = 0; i < lim; ++i) bits |= (unsigned long long)(m[i] != 0) << i;
+  }
   packed[idx] = bits;
 }
 
@@ -228,7 +245,8 @@ extern "C" int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels
 //      offset of its first run in the mask's position list, no workspace and no second launch;
 //   2. stages its panel [H][64] in LDS, four threads per column (a quarter of the rows each) count their segment's transitions,
 //      a 256-entry scan in (column, segment) order places them, a second walk writes the column-major positions;
-//   3. the block of the LAST panel also knows the total and scans the whole mask once more (row-major) for the box and the area.
+//   3. the block of the LAST panel also knows the total; the block of the FIRST panel (nothing to its left) scans the whole mask once
+//      more (row-major) for the box and the area.
 #define RUNS_PANEL 64
 #define RUNS_SEG 4
 __device__ __forceinline__ unsigned zh_nz_bytes(unsigned w) {   // 0x01 in every byte of w that is non-zero
@@ -250,7 +268,8 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
   if (x0 > 0) {
     if (vec) {                                             // x0 % 64 == 0: whole 16-column chunks
       const int cpr = x0 / 16;
-      for (int i = tid; i < (H - 1) * cpr; i += 256) {
+#pragma unroll 8
+      for (int i = tid; i < (H - 1) * cpr; i += 256) {              // independent iterations: eight pairs of loads in flight
         const int y = 1 + i / cpr, c16 = i % cpr;
         const uint4 a = *(const uint4*)(m + (long)y * W + c16 * 16), b = *(const uint4*)(m + (long)(y - 1) * W + c16 * 16);
         cnt += __popc(zh_nz_bytes(a.x) ^ zh_nz_bytes(b.x)) + __popc(zh_nz_bytes(a.y) ^ zh_nz_bytes(b.y)) +
@@ -269,6 +288,7 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
   // ---- 2. the panel
   if (vec && pw % 16 == 0) {
     constexpr int cpr = RUNS_PANEL / 16;
+#pragma unroll 8
     for (int i = tid; i < H * cpr; i += 256) {
       const int y = i / cpr, c16 = i - y * cpr;
       uint4 v = {0u, 0u, 0u, 0u};
@@ -299,6 +319,7 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
     else if (c > 0) prev0 = sm[(H - 1) * RUNS_PANEL + c - 1];
     else prev0 = x0 > 0 ? (unsigned char)(m[(long)(H - 1) * W + x0 - 1] != 0) : sm[0];   // pixel 0 starts the list: no transition
     unsigned char prev = prev0;
+#pragma unroll 8
     for (int y = y0; y < y1; ++y) {
       const unsigned char v = sm[y * RUNS_PANEL + c];
       mine += v != prev;
@@ -317,19 +338,26 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
   if (mine) {
     int o = base + s_red[tid] - mine;
     unsigned char prev = prev0;
+#pragma unroll 8
     for (int y = y0; y < y1; ++y) {
       const unsigned char v = sm[y * RUNS_PANEL + c];
       if (v != prev) { if (o < max_runs) pos[o] = (x0 + c) * H + y; ++o; }
       prev = v;
     }
   }
-  // ---- 3. totals, box and area (the last panel's block)
-  if (pnl != (int)gridDim.y - 1) return;
+  // ---- 3. the total (known to the last panel's block); box and area from one more row-major scan of the whole mask — by the
+  //         FIRST panel's block, which had no columns to its left to count (the last one had all of them)
+  if (pnl == (int)gridDim.y - 1 && tid == 0) {
+    nruns[mi * 2] = total;                                 // number of transitions (may exceed max_runs => host fallback)
+    nruns[mi * 2 + 1] = m[0] != 0;                         // value of pixel 0
+  }
+  if (pnl != 0) return;
   if (tid == 0) { s_minx = W; s_maxx = -1; s_miny = H; s_maxy = -1; s_area = 0; }
   __syncthreads();
   int area = 0, minx = W, maxx = -1, miny = H, maxy = -1;
   if (vec) {
     const int cpr = W / 16;
+#pragma unroll 8
     for (int i = tid; i < H * cpr; i += 256) {
       const int y = i / cpr, c16 = i - y * cpr;
       const uint4 v = *(const uint4*)(m + (long)y * W + c16 * 16);
@@ -357,8 +385,6 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
   }
   __syncthreads();
   if (tid == 0) {
-    nruns[mi * 2] = total;                                 // number of transitions (may exceed max_runs => host fallback)
-    nruns[mi * 2 + 1] = m[0] != 0;                         // value of pixel 0
     int* b = box_area + mi * 5;
     b[0] = s_minx; b[1] = s_miny; b[2] = s_maxx; b[3] = s_maxy; b[4] = s_area;
   }
