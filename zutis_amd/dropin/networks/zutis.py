@@ -204,7 +204,9 @@ class ZUTIS(nn.Module):
         self._engine: Optional[ZutisEngine] = None
         # "fast" | "exact" | "f16" (zutis_amd.engine): exact = every contraction in the reference-equivalent f16x3 mode
         self.precision: str = "exact"
-        self.cross_attention_key_split: int = 2      # engine_base._decoder: this module serves batch-1 evaluation loops
+        # engine_base._decoder: this module serves batch-1 evaluation loops (coco20k_eval.py:241-268), where the decoder's cross-attention is
+        # 8 workgroups per launch unless its keys are split: forward at 480x640 4.25 / 3.56 / 3.21 / 3.04 / 2.97 ms for splits 1 / 2 / 4 / 8 / 16
+        self.cross_attention_key_split: int = 8
         self.use_hip_graph: bool = False       # opt-in: forward() of batches <= 4 replays a hipGraph captured per input shape
 
     # ------------------------------------------------------------------ plumbing

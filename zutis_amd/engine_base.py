@@ -303,7 +303,8 @@ class _EngineBase:
         # + predict 2.99 / 2.73 / 2.60 / 2.54 ms for splits 1 / 2 / 4 / 8; the batch-32 step with three batches in flight loses
         # 0.3 - 1 % with a split of 2 (2825 / 2842 against 2852 / 2851 images/s, same box: the partials' round trip costs more than
         # the extra occupancy gives there).  The split is a property of the ENGINE INSTANCE (throughput: 1, the engine's default
-        # and what bench.py runs; the drop-in modules set 2, they serve batch-1 evaluation loops) and never of the batch — image
+        # and what bench.py runs; the drop-in modules set 8, they serve batch-1 evaluation loops — at the COCO-20K shape, 480x640 = 4800
+        # keys, the forward is 4.25 / 3.56 / 3.04 ms for splits 1 / 2 / 8) and never of the batch — image
         # i's result is bitwise the same alone and inside a batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
         ksplit = self.cross_ksplit if (Q <= 128 and M >= 1024) else 1
         ktiles = -(-M // (32 if xk else 64))               # key tiles of the kernel (32 keys for split pairs, 64 for fp16)
