@@ -79,13 +79,17 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
 // runtime count of whole stages (0 .. MAXC) that may stay in flight, NP DMA issues each
 template <int NP, int MAXC>
 __device__ __forceinline__ void wait_stages_barrier(int c) {
-  static_assert(MAXC <= 5, "extend the switch");
+  static_assert(MAXC <= 9, "extend the switch");
   switch (c) {
     case 0: wait_vmcnt_barrier<0>(); break;
     case 1: wait_vmcnt_barrier<NP>(); break;
     case 2: if (MAXC >= 2) { wait_vmcnt_barrier<(MAXC >= 2 ? 2 : 0) * NP>(); break; }
     case 3: if (MAXC >= 3) { wait_vmcnt_barrier<(MAXC >= 3 ? 3 : 0) * NP>(); break; }
     case 4: if (MAXC >= 4) { wait_vmcnt_barrier<(MAXC >= 4 ? 4 : 0) * NP>(); break; }
+    case 5: if (MAXC >= 5) { wait_vmcnt_barrier<(MAXC >= 5 ? 5 : 0) * NP>(); break; }
+    case 6: if (MAXC >= 6) { wait_vmcnt_barrier<(MAXC >= 6 ? 6 : 0) * NP>(); break; }
+    case 7: if (MAXC >= 7) { wait_vmcnt_barrier<(MAXC >= 7 ? 7 : 0) * NP>(); break; }
+    case 8: if (MAXC >= 8) { wait_vmcnt_barrier<(MAXC >= 8 ? 8 : 0) * NP>(); break; }
     default: wait_vmcnt_barrier<MAXC * NP>(); break;
   }
 }

@@ -6,6 +6,9 @@
 // Weights are packed as W * 2^s (s chosen per matrix so that lo stays a normal fp16 number); `out_scale` = 2^-s is applied
 // to the accumulator before the bias.  Kernel: gemm_kernel.h with SPLIT = 1.
 #include "gemm_kernel.h"
+#ifndef RING64
+#define RING64 6      // ring depth of the 64 x 64 tile (developer A/B, round 3: -DRING64=8 — config 3 forward 3.02 ms either way, batch-1 336 px 2.50 vs 2.55 ms: not bound by the slices in flight)
+#endif
 #ifdef ZH_GEMM_PROBE
 extern "C" void zh_gemm_x3_set_probe(long long* p) { g_probe = p; }   // developer build (tools/gemm_x3_stamp.py)
 #endif
@@ -170,7 +173,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
     else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 4, 2, 2>(p, batch, out_kind, stream);   // 4 slots: the epilogue slabs need 102 KiB
     else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2, 2>(p, batch, out_kind, stream);
-    else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, 6, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2, 2>(p, batch, out_kind, stream);
     else ok = launch_x3<2, 2, 4, 2, 3, 2, 2>(p, batch, out_kind, stream);
   } else
   if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
@@ -180,7 +183,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2>(p, batch, out_kind, stream);   // 8 waves of 32 x 48
-  else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, 6, 2>(p, batch, out_kind, stream);   // 64 x 64, 6-deep ring
+  else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2>(p, batch, out_kind, stream);   // 64 x 64, deep ring
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16x3");
