@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float* tokens, c
     sm[q][m] = (q < nq && m < mc) ? binary[((long)b * Q + q0 + q) * M + m0 + m] : 0;
   }
   __syncthreads();
+#pragma unroll 8                                         // eight rows of loads in flight (same summation order per accumulator)
   for (int m = 0; m < mc; ++m) {
     float v[CPT];
 #pragma unroll
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void masked_mean_reduce_kernel(const float* pa
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * E) return;
   float s = 0.f;
+#pragma unroll 8
   for (int z = 0; z < chunks; ++z) s += partial[(long)z * rows * E + i];
   avg[i] = s * (1.0f / (sizes[i / E] + 1e-7f));
 }
@@ -133,13 +135,25 @@ __global__ __launch_bounds__(256) void instance_classify_kernel(const float* avg
   const float inv = 1.0f / (sqrtf((red[0] + red[1]) + (red[2] + red[3])) + 1e-7f);
   float bv = -1.f;
   int bi = 0x7fffffff;
-  for (int cls = wave; cls < n; cls += 4) {
-    const float* t = text + (long)cls * E;
-    float d = 0.f;
-    for (int c = lane; c < E; c += 64) d += t[c] * (sv[c] * inv);
-    d = wave_sum(d);
-    const float pr = 1.0f / (1.0f + expf(-temperature * d));
-    if (pr > bv) { bv = pr; bi = cls; }          // classes ascend within a wave -> first max kept
+  // three classes per pass (cls, cls + 4, cls + 8): their rows are loaded together — one class at a time was 21 dependent passes of
+  // load -> reduce -> exp per wave, 48 us for 100 queries x 81 classes at batch 1.  Each class's dot product keeps its summation
+  // order and the classes are compared in ascending order, as before: bit-identical categories and scores.
+  for (int cls = wave; cls < n; cls += 12) {
+    const float* t[3];
+    float d[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[j] = text + (long)(cls + 4 * j < n ? cls + 4 * j : cls) * E;
+    for (int c = lane; c < E; c += 64) {
+      const float x = sv[c] * inv;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) d[j] += t[j][c] * x;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float dj = wave_sum(d[j]);
+      const float pr = 1.0f / (1.0f + expf(-temperature * dj));
+      if (cls + 4 * j < n && pr > bv) { bv = pr; bi = cls + 4 * j; }          // classes ascend within a wave -> first max kept
+    }
   }
   if (lane == 0) { bestv[wave] = bv; besti[wave] = bi; }
   __syncthreads();
