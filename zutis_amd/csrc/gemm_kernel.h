@@ -476,6 +476,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     // barrier of iteration kt, hi planes first, and the first sweep of MFMAs (hi*hi) starts as soon as those arrive while
     // the lo planes and the DMA issues of slice kt+DIST trickle in underneath.  A slice carries 3*TM*TN MFMAs (~770 cycles
     // per wave), so two slices of prefetch cover ~1.5 us of load latency with a 3-slot ring.
+    // (Measured and not kept, round 3: register double-buffered fragments for the 64 x 64 tile — slice kt + 1's reads and the DMA issue
+    //  under slice kt's MFMAs, bit-identical — config-3 forward 3.00 vs 2.98 ms, batch-1 336 px 2.51 vs 2.50: those few-tile GEMMs
+    //  cost ~7.5 us of launch + first-bytes + epilogue and only ~0.24 us per K slice; the loop is not what bounds them.)
     constexpr int DISTX = STAGES - 1, AHEADX = STAGES - 2;
     static_assert(AHEADX >= 1 && AHEADX * NP < 64, "ring too shallow / vmcnt overflow");
     pos_before_prologue();
