@@ -36,19 +36,6 @@ __device__ __forceinline__ double blur_gather(const double* __restrict__ x, cons
   }
   return out;
 }
-__device__ __forceinline__ double blur_gather_scaled(const double* __restrict__ x, const double* __restrict__ s,
-                                                     const int* __restrict__ nb, double xv) {  // blur(s .* x)
-  double out = 10.0 * xv;
-#pragma unroll
-  for (int d = 0; d < 5; ++d) {
-    const int lo = nb[2 * d], hi = nb[2 * d + 1];
-    double t = lo >= 0 ? s[lo] * x[lo] : 0.0;
-    if (hi >= 0) t = t + s[hi] * x[hi];
-    out = out + t;
-  }
-  return out;
-}
-
 // ---- de-normalise: fp32 x*std + mean, *255, clip, TRUNCATE (utils/utils.py:269-272).  x [3,H,W] -> rgb u8 [H,W,3]
 __global__ __launch_bounds__(256) void denorm_kernel(const float* x, unsigned char* rgb, long HW, float m0, float m1, float m2,
                                                      float s0, float s1, float s2) {
@@ -340,7 +327,7 @@ __global__ __launch_bounds__(256) void bg_bisto_final(const double* n, const int
 // ---- PCG (scipy.sparse.linalg.cg semantics, Jacobi preconditioner; bilateral_solver.py:133-147)
 struct CgPtrs {
   const double *n, *m, *wsplat, *b; const int* nbr; const int* nv;
-  double *minv, *x, *r, *z, *p, *q;
+  double *minv, *x, *r, *z, *p, *p2, *q;   // p / p2: search direction, ping-pong by iteration parity (see cg_phase_pq)
   double *part_rz, *part_rr, *part_pq;   // per-block partial sums; three arrays => no cross-block WAR
   double* sc;                            // scalars: [0],[1] rho ping-pong, [2] atol, [3] converged flag, [4] iterations
   double lam, a_diag_min, rtol;
@@ -348,19 +335,13 @@ struct CgPtrs {
 __device__ __forceinline__ CgPtrs cg_img(CgPtrs c, const BgBatch& bt) {
   c.n = ws_img(c.n, bt); c.m = ws_img(c.m, bt); c.wsplat = ws_img(c.wsplat, bt); c.b = ws_img(c.b, bt); c.nbr = ws_img(c.nbr, bt);
   c.nv = ws_img(c.nv, bt); c.minv = ws_img(c.minv, bt); c.x = ws_img(c.x, bt); c.r = ws_img(c.r, bt); c.z = ws_img(c.z, bt);
-  c.p = ws_img(c.p, bt); c.q = ws_img(c.q, bt); c.part_rz = ws_img(c.part_rz, bt); c.part_rr = ws_img(c.part_rr, bt);
+  c.p = ws_img(c.p, bt); c.p2 = ws_img(c.p2, bt); c.q = ws_img(c.q, bt); c.part_rz = ws_img(c.part_rz, bt); c.part_rr = ws_img(c.part_rr, bt);
   c.part_pq = ws_img(c.part_pq, bt); c.sc = ws_img(c.sc, bt);
   return c;
 }
 // blocks that hold vertices: the launch grid is sized for the worst case (one vertex per pixel); everything past this exits
 __device__ __forceinline__ int cg_active_blocks(const CgPtrs& c) { return (*c.nv + 255) >> 8; }
 
-__device__ __forceinline__ double matvec_row(const CgPtrs& c, const double* y, int v) {
-  // A y = lam * (m*y - n * blur(n .* y)) + wsplat*y
-  const double ny = c.n[v] * y[v];
-  const double bl = blur_gather_scaled(y, c.n, c.nbr + v * 10, ny);
-  return c.lam * (c.m[v] * y[v] - c.n[v] * bl) + c.wsplat[v] * y[v];
-}
 __device__ __forceinline__ double block_sum(double s, double* red) {   // deterministic: fixed tree, fixed order
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -382,13 +363,6 @@ __global__ __launch_bounds__(256) void bg_fill_kernel(double* x, double val, con
     if (v < *nv) x[v] = val;
   }
 }
-__global__ __launch_bounds__(256) void cg_y0_kernel(CgPtrs c0, BgBatch bt) {          // flat initialisation y0 = splat(xw) / splat(w)
-  const CgPtrs c = cg_img(c0, bt);
-  FOR_VERTEX_BLOCKS(vb, c.nv) {
-    const int v = vb * 256 + threadIdx.x;
-    if (v < *c.nv) c.x[v] = c.b[v] / c.wsplat[v];
-  }
-}
 __global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c0, BgBatch bt) {
   __shared__ double red[4];
   const CgPtrs c = cg_img(c0, bt);
@@ -399,7 +373,22 @@ __global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c0, BgBatch bt) {
       const double diag = c.lam * (c.m[v] - c.n[v] * 10.0 * c.n[v]) + c.wsplat[v];
       const double mi = 1.0 / fmax(diag, c.a_diag_min);
       c.minv[v] = mi;
-      const double r = c.b[v] - matvec_row(c, c.x, v);
+      // the flat initialisation y0 = splat(xw) / splat(w) (bilateral_solver.py:141) formed here — for the vertex and, on the fly, for
+      // its neighbours (the same division: the same double) — instead of by a launch of its own in front of this one
+      auto xval = [&](int j) { return c.b[j] / c.wsplat[j]; };
+      const double xv = xval(v);
+      c.x[v] = xv;
+      const int* nb10 = c.nbr + v * 10;
+      const double ny = c.n[v] * xv;
+      double bl = 10.0 * ny;
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const int lo = nb10[2 * d], hi = nb10[2 * d + 1];
+        double t = lo >= 0 ? c.n[lo] * xval(lo) : 0.0;
+        if (hi >= 0) t = t + c.n[hi] * xval(hi);
+        bl = bl + t;
+      }
+      const double r = c.b[v] - (c.lam * (c.m[v] * xv - c.n[v] * bl) + c.wsplat[v] * xv);
       c.r[v] = r;
       const double z = mi * r;
       c.z[v] = z;
@@ -415,11 +404,15 @@ __global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c0, BgBatch bt) {  
   const double bb = sum_partials(c.part_pq, cg_active_blocks(c), red);
   if (threadIdx.x == 0) { c.sc[2] = c.rtol * sqrt(bb); c.sc[3] = 0.0; c.sc[4] = 0.0; }
 }
-// The three phases of one PCG iteration as device functions, parametrised by (g, G) = this block's index among the G blocks of its
-// image (the per-phase kernels below call them; so did the persistent single-launch experiments of round 3, see further down).
-// phase 1: convergence test at the top of iteration `it` (every block re-derives it from the same partials: deterministic, no flag
-// race), then p = z + beta p.  Returns false when converged (||r|| < atol).
-__device__ __forceinline__ bool cg_phase_p(const CgPtrs& c, int it, int nb, double rho_prev, double& rho, double* red, int g, int G) {
+// One PCG iteration = TWO launches (it was three: p update, matvec, x / r / z update — a solve at 512 x 683 is ~100 launches of
+// ~1 us of work each, i.e. launch-latency bound, and 75 of them were these).  The p update needs a grid-wide barrier before the
+// matvec only because the matvec reads its neighbours' p: here every thread forms p_new = z + beta p_old for its vertex AND for its
+// (up to) ten neighbours on the fly — the same expression, evaluated without contraction, so every copy of a value is the same
+// double — and p ping-pongs between two buffers by iteration parity so that no thread reads a p another one has already replaced.
+// Results are bitwise those of the three-launch form (goldens: iteration counts exact, batched == single bitwise).
+// phases 1 + 2: convergence test at the top of iteration `it` (every block re-derives it from the same partials: deterministic, no
+// flag race), p_new, q = A p_new, per-block partials of p.q.  Returns false when converged (||r|| < atol).
+__device__ __forceinline__ bool cg_phase_pq(const CgPtrs& c, int it, int nb, double rho_prev, double& rho, double* red, int g, int G) {
   rho = sum_partials(c.part_rz, nb, red);
   const double rr = sum_partials(c.part_rr, nb, red);
   if (sqrt(rr) < c.sc[2]) {
@@ -427,31 +420,47 @@ __device__ __forceinline__ bool cg_phase_p(const CgPtrs& c, int it, int nb, doub
     return false;
   }
   const double beta = it == 0 ? 0.0 : rho / rho_prev;
-  FOR_VERTEX_BLOCKS_G(vb, c.nv, g, G) {
-    const int v = vb * 256 + threadIdx.x;
-    if (v < *c.nv) c.p[v] = it == 0 ? c.z[v] : c.z[v] + beta * c.p[v];
-  }
-  return true;
-}
-// phase 2: q = A p, per-block partials of p.q
-__device__ __forceinline__ void cg_phase_q(const CgPtrs& c, double* red, int g, int G) {
+  const bool first = it == 0;
+  const double* __restrict__ po = (it & 1) ? c.p : c.p2;      // p of iteration it - 1 (never read when it == 0)
+  double* __restrict__ pn = (it & 1) ? c.p2 : c.p;
+  const double* __restrict__ z = c.z;
+  const double* __restrict__ n = c.n;
+  auto pval = [&](int j) { return first ? z[j] : z[j] + beta * po[j]; };
   FOR_VERTEX_BLOCKS_G(vb, c.nv, g, G) {
     const int v = vb * 256 + threadIdx.x;
     double pq = 0.0;
-    if (v < *c.nv) { const double q = matvec_row(c, c.p, v); c.q[v] = q; pq = c.p[v] * q; }
+    if (v < *c.nv) {
+      // q = A p = lam * (m*p - n * blur(n .* p)) + wsplat*p   (p formed on the fly)
+      const double pv = pval(v);
+      const int* nb10 = c.nbr + v * 10;
+      const double ny = n[v] * pv;
+      double bl = 10.0 * ny;
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const int lo = nb10[2 * d], hi = nb10[2 * d + 1];
+        double t = lo >= 0 ? n[lo] * pval(lo) : 0.0;
+        if (hi >= 0) t = t + n[hi] * pval(hi);
+        bl = bl + t;
+      }
+      const double q = c.lam * (c.m[v] * pv - n[v] * bl) + c.wsplat[v] * pv;
+      pn[v] = pv;
+      c.q[v] = q;
+      pq = pv * q;
+    }
     const double s = block_sum(pq, red);
     if (threadIdx.x == 0) c.part_pq[vb] = s;
   }
+  return true;
 }
 // phase 3: x += alpha p, r -= alpha q, z = M^-1 r, per-block partials of r.z and r.r
-__device__ __forceinline__ void cg_phase_x(const CgPtrs& c, int nb, double rho, double* red, int g, int G) {
+__device__ __forceinline__ void cg_phase_x(const CgPtrs& c, const double* p, int nb, double rho, double* red, int g, int G) {
   const double pq = sum_partials(c.part_pq, nb, red);
   const double alpha = rho / pq;
   FOR_VERTEX_BLOCKS_G(vb, c.nv, g, G) {
     const int v = vb * 256 + threadIdx.x;
     double rz = 0.0, rr = 0.0;
     if (v < *c.nv) {
-      c.x[v] += alpha * c.p[v];
+      c.x[v] += alpha * p[v];
       const double r = c.r[v] - alpha * c.q[v];
       c.r[v] = r;
       const double z = c.minv[v] * r;
@@ -463,28 +472,22 @@ __device__ __forceinline__ void cg_phase_x(const CgPtrs& c, int nb, double rho, 
   }
 }
 
-__global__ __launch_bounds__(256) void cg_pupdate_kernel(CgPtrs c0, int it, BgBatch bt) {
+__global__ __launch_bounds__(256) void cg_pq_kernel(CgPtrs c0, int it, BgBatch bt) {
   __shared__ double red[4];
   const CgPtrs c = cg_img(c0, bt);
   const int nb = cg_active_blocks(c);
   if ((int)blockIdx.x >= nb) return;
   double rho;
-  if (!cg_phase_p(c, it, nb, it == 0 ? 1.0 : c.sc[(it - 1) & 1], rho, red, blockIdx.x, gridDim.x)) return;   // once converged the partials are frozen: the
-  if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;                          // decision repeats for all later iterations
-}
-__global__ __launch_bounds__(256) void cg_matvec_kernel(CgPtrs c0, BgBatch bt) {
-  __shared__ double red[4];
-  const CgPtrs c = cg_img(c0, bt);
-  if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
-  cg_phase_q(c, red, blockIdx.x, gridDim.x);
+  if (!cg_phase_pq(c, it, nb, it == 0 ? 1.0 : c.sc[(it - 1) & 1], rho, red, blockIdx.x, gridDim.x)) return;   // once converged the partials are
+  if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;                           // frozen: the decision repeats for all later iterations
 }
 __global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBatch bt) {
   __shared__ double red[4];
   const CgPtrs c = cg_img(c0, bt);
   const int nb = cg_active_blocks(c);
   if ((int)blockIdx.x >= nb) return;
-  if (c.sc[3] != 0.0) return;
-  cg_phase_x(c, nb, c.sc[it & 1], red, blockIdx.x, gridDim.x);
+  if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
+  cg_phase_x(c, (it & 1) ? c.p2 : c.p, nb, c.sc[it & 1], red, blockIdx.x, gridDim.x);
 }
 
 // (Round 3 measured two persistent single-launch forms of this loop — all iterations in one kernel with image-local barriers
@@ -647,15 +650,13 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
   // PCG
   CgPtrs c;
   c.n = ncur; c.m = m; c.wsplat = wsplat; c.b = bsplat; c.nbr = nbr; c.nv = nv;
-  c.minv = D[6]; c.x = D[7]; c.r = D[8]; c.z = D[9]; c.p = D[10]; c.q = D[11];
+  c.minv = D[6]; c.x = D[7]; c.r = D[8]; c.z = D[9]; c.p = D[10]; c.q = D[11]; c.p2 = D[12];
   c.part_rz = part; c.part_rr = part + (size_t)L.nblocks; c.part_pq = part + 2 * (size_t)L.nblocks; c.sc = sc;
   c.lam = lam; c.a_diag_min = a_diag_min; c.rtol = cg_tol;
-  hipLaunchKernelGGL(cg_y0_kernel, gV, blk, 0, stream, c, bt);
   hipLaunchKernelGGL(cg_init_kernel, gV, blk, 0, stream, c, bt);
   hipLaunchKernelGGL(cg_atol_kernel, g1, blk, 0, stream, c, bt);
   for (int it = 0; it < cg_maxiter; ++it) {
-    hipLaunchKernelGGL(cg_pupdate_kernel, gV, blk, 0, stream, c, it, bt);
-    hipLaunchKernelGGL(cg_matvec_kernel, gV, blk, 0, stream, c, bt);
+    hipLaunchKernelGGL(cg_pq_kernel, gV, blk, 0, stream, c, it, bt);
     hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it, bt);
   }
   hipLaunchKernelGGL(bg_slice_kernel, gN, blk, 0, stream, c.x, pix2v, N, out_soft, bt);
