@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 214 /* 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 215 /* 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -290,6 +290,12 @@ const char* zh_plan_op_name(int op);
 
 /* HOST helper: RLE string from run lengths (pycocotools rleToString). */
 long zh_rle_counts_to_string_host(const long long* counts, long n, char* out, long cap);
+/* HOST.  The RLE strings of n masks from zh_mask_runs' output in one call: positions int32 [n, stride], nruns int32 [n, 2]
+ * (transitions, value of pixel 0), HW pixels per mask; strings back to back in `out` (cap bytes), offsets int64 [n + 1]; a mask
+ * with more transitions than `stride` gets an empty string (the caller re-encodes it from the mask).  Returns the total length,
+ * -1 when cap is too small.  Replaces pycocotools.mask.encode per kept mask (networks/zutis.py:290,448). */
+long zh_rle_from_transitions_host(const int* positions, long stride, const int* nruns, long n, long HW, char* out, long cap,
+                                  long long* offsets);
 
 /* HOST helper (no GPU): COCO RLE string of one u8 [H,W] mask = pycocotools.mask.encode(np.asfortranarray(m))["counts"]
  * (zutis.py:290,448; datasets/index_dataset.py:219).  Returns the length, -1 if cap is too small. */

@@ -81,3 +81,32 @@ def test_rle_hand_derived_format_vectors(golden_dir):
         assert rle.encode(m)["size"] == v["size"]
         assert np.array_equal(rle.decode({"size": v["size"], "counts": want}), m), v["name"]
         assert rle._from_string(want) == v["runs_colmajor"], v["name"]
+
+
+def test_batched_rle_from_transitions_host_entry():
+    """zh_rle_from_transitions_host (all kept masks' strings in one C call, from the device's transition positions) == the per-mask
+    path == the mask encoder: random, empty, full, a rectangle, a mask with pixel 0 set; a mask over the position capacity is
+    reported as None (the caller re-encodes it)."""
+    import numpy as np
+    from zutis_amd import rle
+    rng = np.random.default_rng(0)
+    H, W = 37, 53
+    masks = [(rng.random((H, W)) > 0.5).astype(np.uint8), np.zeros((H, W), np.uint8), np.ones((H, W), np.uint8)]
+    m = np.zeros((H, W), np.uint8); m[5:20, 10:30] = 1; masks.append(m)
+    m = np.zeros((H, W), np.uint8); m[0, 0] = 1; masks.append(m)
+    pos, nr = [], []
+    for m in masks:
+        f = m.reshape(-1, order="F")
+        t = np.flatnonzero(f[1:] != f[:-1]) + 1
+        pos.append(t); nr.append((len(t), int(f[0])))
+    keep = max(1, max(len(t) for t in pos))
+    P = np.zeros((len(masks), keep), np.int32)
+    for i, t in enumerate(pos):
+        P[i, :len(t)] = t
+    NR = np.array(nr, np.int32)
+    out = rle.rles_from_transitions(P, NR, H, W)
+    for i, m in enumerate(masks):
+        assert out[i] == rle.encode(m) == rle.rle_from_transitions(pos[i], nr[i][1], H, W), i
+        assert (rle.decode(out[i]) == m).all()
+    short = rle.rles_from_transitions(P[:, :3], NR, H, W)
+    assert short[0] is None and short[1] == rle.encode(masks[1])

@@ -93,3 +93,47 @@ extern "C" long zh_rle_counts_to_string_host(const long long* counts, long n, ch
   }
   return len;
 }
+
+// HOST: the RLE strings of n masks straight from zh_mask_runs' output, one call (rle_from_transitions was one numpy diff + one
+// ctypes call per mask: 18 us each, 0.3 ms of a 0.7-ms batch-1 instance predict for 17 kept masks).  positions int32 [n, stride]
+// (column-major pixel indices where the value changes, the first nruns[2 i] of row i), nruns int32 [n, 2] = {transitions, value of
+// pixel 0}; counts = diff([0, positions..., HW]) with a leading empty zero-run when pixel 0 is set (pycocotools starts with zeros).
+// Strings are written back to back into `out`; offsets int64 [n + 1].  Masks with more than `stride` transitions get an empty
+// string (offsets equal): the caller falls back to the mask encoder.  Returns the total length or -1 when `cap` is too small.
+extern "C" long zh_rle_from_transitions_host(const int* positions, long stride, const int* nruns, long n, long HW, char* out, long cap,
+                                             long long* offsets) {
+  long len = 0;
+  for (long i = 0; i < n; ++i) {
+    offsets[i] = len;
+    const long nt = nruns[2 * i];
+    if (nt > stride) continue;
+    const int* p = positions + i * stride;
+    const bool lead = nruns[2 * i + 1] != 0;
+    const long nc = nt + 1 + (lead ? 1 : 0);              // number of runs
+    long c1 = 0, c2 = 0;                                   // counts[k - 1], counts[k - 2]
+    for (long k = 0; k < nc; ++k) {
+      long cnt;
+      if (lead && k == 0) cnt = 0;
+      else {
+        const long e = k - (lead ? 1 : 0);                 // run e spans [edge(e), edge(e + 1))
+        const long lo = e == 0 ? 0 : p[e - 1], hi = e == nt ? HW : p[e];
+        cnt = hi - lo;
+      }
+      long x = cnt;
+      if (k > 2) x -= c2;
+      bool more = true;
+      while (more) {
+        long ch = x & 0x1f;
+        x >>= 5;
+        more = (ch & 0x10) ? x != -1 : x != 0;
+        if (more) ch |= 0x20;
+        if (len >= cap) return -1;
+        out[len++] = (char)(ch + 48);
+      }
+      c2 = c1; c1 = cnt;
+    }
+  }
+  offsets[n] = len;
+  return len;
+}
+

@@ -356,15 +356,12 @@ class ZutisEngine(_EngineBase):
         nr_h, ba_h = nb_h[:, :2], nb_h[:, 2:]
         keep = int(min(max_runs, max(1, nr_h[:, 0].max())))
         pos_h = pos[:, :keep].cpu().numpy()
-        rles, boxes, areas = [], [], []
+        rles = rle.rles_from_transitions(pos_h, nr_h, H, W)      # all strings in one C call (was one numpy diff + ctypes call per mask)
         for j, q in enumerate(sel):
-            cnt, first = int(nr_h[j, 0]), int(nr_h[j, 1])
-            if cnt > max_runs:                                   # pathological mask: fall back to the host encoder
-                rles.append(rle.encode(masks_u8[int(q)].cpu().numpy()))
-            else:
-                rles.append(rle.rle_from_transitions(pos_h[j, :cnt], first, H, W))
-            boxes.append([float(v) for v in ba_h[j, :4]])
-            areas.append(int(ba_h[j, 4]))
+            if rles[j] is None:                                  # pathological mask (> max_runs transitions): the host encoder
+                rles[j] = rle.encode(masks_u8[int(q)].cpu().numpy())
+        boxes = [[float(v) for v in row[:4]] for row in ba_h]
+        areas = [int(row[4]) for row in ba_h]
         return rles, boxes, areas
 
 

@@ -122,3 +122,23 @@ def rle_from_transitions(positions: np.ndarray, first_value: int, h: int, w: int
     n = _lib.load().zh_rle_counts_to_string_host(counts.ctypes.data, counts.size, C.addressof(buf), cap)
     assert n >= 0
     return {"size": [int(h), int(w)], "counts": buf.raw[:n]}
+
+
+def rles_from_transitions(positions: np.ndarray, nruns: np.ndarray, h: int, w: int):
+    """The COCO RLE dicts of all n masks from zh_mask_runs' host copies in ONE C call (zh_rle_from_transitions_host): positions int32
+    [n, keep], nruns int32 [n, 2] = (transitions, value of pixel 0).  Entry i is None when mask i has more transitions than `keep`
+    (the caller re-encodes it from the mask itself)."""
+    import ctypes as C
+    from . import _lib
+    pos = np.ascontiguousarray(positions, dtype=np.int32)
+    nr = np.ascontiguousarray(nruns, dtype=np.int32)
+    n, keep = pos.shape
+    cap = int(8 * (np.minimum(nr[:, 0], keep).astype(np.int64) + 3).sum() + 16)
+    buf = C.create_string_buffer(cap)
+    off = np.empty(n + 1, dtype=np.int64)
+    total = _lib.load().zh_rle_from_transitions_host(pos.ctypes.data, keep, nr.ctypes.data, n, h * w, C.addressof(buf), cap, off.ctypes.data)
+    assert total >= 0
+    raw = buf.raw
+    size = [int(h), int(w)]
+    return [({"size": size, "counts": raw[off[i]:off[i + 1]]} if nr[i, 0] <= keep else None) for i in range(n)]
+
