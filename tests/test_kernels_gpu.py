@@ -527,3 +527,23 @@ def test_device_mask_nms_matches_reference_control_flow(dev, nms_type):
     else:
         assert np.abs(got_s - ref_s).max() < 1e-12
     assert len(eng_kept) > 20
+
+
+@pytest.mark.parametrize("h,w,H,W", [(120, 160, 480, 640), (107, 160, 427, 640), (30, 40, 123, 164), (21, 21, 336, 336), (9, 13, 50, 1030)])
+def test_thresholded_mask_upsample_rows_kernel_is_bitwise_the_flat_kernel(dev, h, w, H, W):
+    """Instance masks (zutis.py:422-423: F.interpolate(mask_proposals, size, 'bilinear') > threshold): the mask-only call takes the
+    row-wise kernel (one block row per output row, 4 pixels per store, W % 4 == 0); it must equal the flat kernel's float output
+    compared with the threshold, pixel for pixel, and ATen's interpolate (values within an ulp of the threshold may differ there)."""
+    import torch.nn.functional as F
+    from zutis_amd import ops
+    planes, thr = 7, 0.5
+    x = torch.rand((planes, h, w), generator=torch.Generator().manual_seed(h * W)).to(dev)
+    out = torch.empty((planes, H, W), dtype=torch.float32, device=dev)
+    m_flat = torch.empty((planes, H, W), dtype=torch.uint8, device=dev)
+    ops.upsample_bilinear_nchw(x, planes, h, w, H, W, out=out, mask_u8=m_flat, threshold=thr)       # float output requested: flat kernel
+    m_rows = torch.full((planes, H, W), 7, dtype=torch.uint8, device=dev)
+    ops.upsample_bilinear_nchw(x, planes, h, w, H, W, mask_u8=m_rows, threshold=thr)                # mask only: row-wise kernel
+    assert torch.equal(m_rows, m_flat)
+    assert torch.equal(m_rows.bool(), out > thr)
+    ref = F.interpolate(x[None].cpu(), size=(H, W), mode="bilinear")[0]
+    assert torch.equal(out.cpu(), ref)                                                               # ATen-exact arithmetic
