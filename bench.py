@@ -204,6 +204,7 @@ def bench_c5(args):
     # checkpoints hold fp16 values anyway.  Random weights "of that architecture" therefore carry fp16 VALUES in those tensors (stored
     # as fp32 here, the oracle reads the same numbers); LayerNorm / embedding parameters stay generic fp32.  --c5-fp32-weights keeps
     # generic fp32 values everywhere (a fine-tuned tower: the three-product kernel).
+    P_generic = dict(P)
     if not args.c5_fp32_weights:
         for k in list(P):
             if k.endswith(("conv1.weight", "in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias", "c_fc.weight", "c_fc.bias",
@@ -272,6 +273,24 @@ def bench_c5(args):
         got = enc.encode_image(x[:ns]).cpu()
         parity = {"embedding_max_abs_err": float((got - ref).abs().max()), "tolerance": 1e-3,
                   "against": "fp32 oracle on the same %d images (unit-norm embeddings)" % ns}
+    generic = None
+    if rank == 0 and world == 1 and not args.c5_fp32_weights and not args.no_second_precision:
+        # the same tower with generic fp32 VALUES in the GEMM weights (a fine-tuned tower): every weight keeps its lo plane, the
+        # three-product kernel runs — reported next to the headline so that both cases are on the line
+        del lanes, embs
+        enc3 = ClipImageEncoder(P_generic, p, prefix="visual.", precision=args.precision)
+        enc3.encode_image(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n3 = max(2, min(5, args.steps))
+        for _ in range(n3):
+            e3 = enc3.encode_image(x)
+        torch.cuda.synchronize()
+        dt3 = (time.perf_counter() - t1) / n3
+        generic = {"value": round(B / dt3, 1), "unit": "images/s", "ms_per_step": round(dt3 * 1e3, 3), "steps": n3,
+                   "what": "generic fp32 values in every GEMM weight (--c5-fp32-weights): zh_gemm_f16x3 with both weight planes, three MFMA "
+                           "products per accumulator"}
+        del enc3, e3
     if world > 1:
         dist.barrier()                    # rank 0 measured the roofline after the timed region: leave together
         dist.destroy_process_group()
@@ -291,6 +310,7 @@ def bench_c5(args):
                                    "leaves them (clip_arch.py:566-587,625); the engine detects it per weight at pack time and skips the "
                                    "product with the all-zero lo plane (f16x2: bit-identical to f16x3)")},
             "model_tflops": round(total * flop / elapsed / 1e12 / world, 1), "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "generic_fp32_weights": generic,
             "embedding_norm": round(float(emb.norm(dim=1).mean().item()), 6)}), flush=True)
 
 
