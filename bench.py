@@ -465,6 +465,39 @@ def bench_c3(args):
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "bilateral_solver": solver}), flush=True)
 
 
+def rank_launch_command(n_gpus: int, argv, port: int):
+    """The command line `python bench.py --gpus N` runs as a child: one rank per GPU under torch.distributed.run, rendezvous on
+    127.0.0.1 (the container hostname may not resolve) — the same form the driver uses for its own N > 1 launches."""
+    child_args = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + child_args
+
+
+def launch_ranks(n_gpus: int, argv, dry: bool) -> int:
+    """`python bench.py --gpus N` without a rank environment: start N ranks as a CHILD process tree and forward rank 0's JSON line.
+    Nothing here touches the GPU (torch.cuda.device_count() does not initialise HIP on this image; a process that has must never
+    exec or be replaced), so the children are the first to do so; the parent only waits and passes the exit code on."""
+    import socket
+    import subprocess
+    if n_gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = rank_launch_command(n_gpus, argv, port)
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    if dry:
+        print(json.dumps({"cmd": cmd, "n_ranks": n_gpus, "env": {"HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"]}}), flush=True)
+        return 0
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        sys.stderr.write(f"bench.py: --gpus {n_gpus} but only {have} device(s) visible\n")
+        return 3
+    if n_gpus == 1:
+        raise AssertionError("launch_ranks is for N > 1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -500,8 +533,14 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16, help="images in the CPU-baseline sample (timed three times)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch intra-op threads of the CPU baseline (16 was the fastest of 8..128 on the 2x64-core GPU box)")
+    ap.add_argument("--dry-launch", action="store_true", help="print the rank launcher's command line (JSON) for --gpus N and exit; no GPU is touched")
     args = ap.parse_args()
     args.inflight_given = any(a == "--inflight" or a.startswith("--inflight=") for a in sys.argv[1:])
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        return launch_ranks(args.gpus, sys.argv[1:], args.dry_launch)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and not args.force_dist:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with "
+                         f"--nproc-per-node {args.gpus} (or run plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)")
     if args.workload == "c4":
         args.size, args.classes = 518, 920
         if args.batch == 32:
@@ -780,4 +819,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
