@@ -196,3 +196,47 @@ def test_pseudo_mask_batched_driver_matches_batch1(dev, tmp_path):
     pseudo_masks.generate_pseudo_masks_batched(eng, imgs, sizes_out, pb, batch_size=4)
     for a, b in zip(pa, pb):
         assert open(a).read() == open(b).read()
+
+
+def test_dataset_method_adapter_writes_the_same_files(dev, tmp_path):
+    """`generate_pseudo_masks(self, p_images, dir_dataset, n_workers, bilateral_solver)` with the dataset method's own signature
+    (datasets/index_dataset.py:177-226) over the batched device path: same paths, byte-identical JSON to the batch-1 driver."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin"))
+    from networks.selfmask.selfmask import SelfMask
+    from zutis_amd import detgen, pseudo_masks
+    net = SelfMask()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.selfmask_state_dict().items()}, strict=True)
+    sizes_in = [(72, 100), (72, 100), (64, 64), (72, 100), (72, 100), (72, 100)]
+    root = tmp_path / "pass" / "images"
+    root.mkdir(parents=True)
+    p_images = []
+    for i, (h, w) in enumerate(sizes_in):
+        p = str(root / f"im{i}.npy")
+        np.save(p, detgen.images(1, h, w, seed=60 + i)[0])
+        p_images.append(p)
+
+    class MaskDataset(torch.utils.data.Dataset):                  # stands in for the dataset module's own loader (PIL / torchvision absent here)
+        def __init__(self, p_images):
+            self.p_images = p_images
+
+        def __len__(self):
+            return len(self.p_images)
+
+        def __getitem__(self, i):
+            return {"image": torch.from_numpy(np.load(self.p_images[i])), "p_image": self.p_images[i]}
+
+    class FakeIndexDataset:
+        device = dev
+
+        def _convert_p_image_to_p_pseudo_mask(self, p_image):       # the "/pass/" branch of index_dataset.py:250-255
+            d = "/".join(p_image.split("/")[:-1]).replace("/images", "") + "/pseudo_masks_selfmask"
+            return f"{d}/{p_image.split('/')[-1].replace('npy', 'json')}"
+    FakeIndexDataset.generate_pseudo_masks = pseudo_masks.dataset_generate_pseudo_masks
+    ds = FakeIndexDataset()
+    size_of = lambda p: tuple(2 * s + 1 for s in np.load(p).shape[1:])
+    ds.generate_pseudo_masks(p_images, str(tmp_path / "pass"), 0, True, batch_size=4, network=net, mask_dataset_cls=MaskDataset, image_size_fn=size_of)
+    eng = net._get_engine()
+    ref_paths = [str(tmp_path / "ref" / f"{i}.json") for i in range(len(p_images))]
+    pseudo_masks.generate_pseudo_masks(eng, [torch.from_numpy(np.load(p)).to(dev) for p in p_images], [size_of(p) for p in p_images], ref_paths, n_streams=1)
+    for p, r in zip(p_images, ref_paths):
+        assert open(ds._convert_p_image_to_p_pseudo_mask(p)).read() == open(r).read()

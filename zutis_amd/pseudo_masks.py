@@ -132,3 +132,62 @@ def generate_pseudo_masks(engine: SelfMaskEngine, images: Sequence[torch.Tensor]
     while pending:
         finish(pending.popleft())
     return list(out_paths)
+
+
+# ------------------------------------------------------------------------------------- the dataset method's own signature
+def _image_size_hw(p_image: str) -> Tuple[int, int]:
+    """(H, W) of the image file — `W, H = Image.open(p_image).size` (index_dataset.py:214)."""
+    from PIL import Image
+    with Image.open(p_image) as im:
+        w, h = im.size
+    return h, w
+
+
+@torch.no_grad()
+def dataset_generate_pseudo_masks(self, p_images: List[str], dir_dataset: str, n_workers: int = 4, bilateral_solver: bool = True, *,
+                                  batch_size: int = 8, network=None, mask_dataset_cls=None, image_size_fn=None) -> None:
+    """`IndexDataset.generate_pseudo_masks(self, p_images, dir_dataset, n_workers, bilateral_solver)` (datasets/index_dataset.py:177-226;
+    the same method exists in datasets/imagenet.py and datasets/pass.py) over the batched device path.  Bind it in place of the
+    reference's method — `IndexDataset.generate_pseudo_masks = zutis_amd.pseudo_masks.dataset_generate_pseudo_masks` — and the
+    unchanged caller (`_get_pseudo_masks`, :263) runs SelfMask + bilateral solver + nearest resize on the GPU, batched by image
+    shape, and writes the same JSON files to the same paths.
+
+    What it takes from `self`, exactly as the reference's method does: `self.device` and `self._convert_p_image_to_p_pseudo_mask`.
+    The loader is the dataset module's own `MaskDataset` (same resize / normalisation); the network is the `selfmask` of
+    `utils.utils.get_network` (the overlay's drop-in SelfMask when it is installed) unless `network=` is given.  The keyword-only
+    arguments are not in the reference's signature: `batch_size` (images of one shape solved together; 1 = the reference's loop),
+    and the injection points the tests use."""
+    import sys
+    from torch.utils.data import DataLoader
+    if network is None:
+        from utils.utils import get_network                       # the reference's factory (utils/utils.py), as :184 calls it
+        network = get_network(network_name="selfmask")
+    network = network.to(self.device)
+    network.eval()
+    engine = network._get_engine() if hasattr(network, "_get_engine") else network
+    if not isinstance(engine, SelfMaskEngine):
+        raise TypeError("dataset_generate_pseudo_masks needs the MI355X drop-in SelfMask (networks/selfmask/selfmask.py of the overlay) "
+                        "or a SelfMaskEngine: there is no torch / CPU fallback")
+    if mask_dataset_cls is None:
+        mask_dataset_cls = getattr(sys.modules[type(self).__module__], "MaskDataset")
+    size_of = image_size_fn or _image_size_hw
+    loader = DataLoader(dataset=mask_dataset_cls(p_images=p_images), batch_size=1, num_workers=n_workers, pin_memory=True)   # :187-188
+
+    images: List[torch.Tensor] = []
+    sizes: List[Tuple[int, int]] = []
+    paths: List[str] = []
+
+    def flush():
+        if images:
+            generate_pseudo_masks_batched(engine, images, sizes, paths, bilateral_solver=bilateral_solver, batch_size=batch_size)
+            images.clear(); sizes.clear(); paths.clear()
+
+    for dict_data in loader:                                        # :191-194: image 1 x 3 x H x W, p_image [str]
+        image, p_image = dict_data["image"], dict_data["p_image"][0]
+        if images and (tuple(image.shape[1:]) != tuple(images[0].shape) or len(images) >= batch_size):
+            flush()                                                 # a group = consecutive images of one shape
+        images.append(image[0].to(self.device, non_blocking=True).float())
+        sizes.append(size_of(p_image))                              # :214 the file's own resolution
+        paths.append(self._convert_p_image_to_p_pseudo_mask(p_image=p_image))   # :209
+    flush()
+    print(f"Pseudo-masks are saved in {dir_dataset}.")              # :226
