@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 215 /* 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 217 /* 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -91,7 +91,7 @@ int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void
  * probabilities are split in registers, O += Vh.Ph + Vl.Ph + Vh.Pl (fp32-class).  planeO != 0: O is written as a split pair.
  * Replaces nn.MultiheadAttention core at clip_arch.py:314-316, transformer.py:272-286,
  * selfmask/vision_transformer.py:110-133 (which materialises [B,heads,T,T]). */
-/* The same attention with the KEYS split over `ksplit` (2..16) workgroups per (image, head, 128-query block) and one merge launch:
+/* The same attention with the KEYS split over `ksplit` (2..64) workgroups per (image, head, 128-query block) and one merge launch:
  * for few queries against many keys (the decoder's cross-attention, transformer.py:281-286: 100 queries x 1764 keys).  Partials
  * (unnormalised fp32 O, running max, row sum) go through `workspace` (zh_attention_splitk_workspace_size bytes, 16-byte aligned). */
 size_t zh_attention_splitk_workspace_size(int batch, int heads, int Tq, int head_dim, int ksplit);
@@ -132,6 +132,22 @@ int zh_layernorm_f32(const float* x, long in_group_rows, long in_group_stride, l
                      const float* gamma, const float* beta, float eps,
                      float* out_f32, void* out_f16, void* out_f16_plus, float* out_f32_plus,
                      const float* add, int add_rows, int rows, int D, long lo_plane, zh_stream_t stream);
+
+/* Split-K combine + bias + residual + LayerNorm (+ a second, chained LayerNorm) in one pass over each row (round 4):
+ *   x = ((parts[0] + ... + parts[n_parts-1]) + bias) + residual      parts f32 [n_parts][rows, D] at part_stride, in plane order
+ *   out_sum[r] = x                                                  (may alias residual: `x = x + attn(...)`, clip_arch.py:318-321)
+ *   y = LN(x; gamma, beta, eps)   -> out_f32 / out_f16 at out_row(r) = (r / out_group_rows) * out_group_stride + out_offset + r % out_group_rows,
+ *                                    not written for r % out_group_rows == 0 when skip_first_in_group (ln_post drops cls, clip_arch.py:403-404)
+ *   z = LN(y; gamma2, beta2, eps2) -> out2_* at out2_row(r)         (norm3 -> decoder.norm, transformer.py:140-150,291)
+ * Replaces the fp32 epilogue of the N = D GEMMs whose K was split over workgroups (zh_gemm_f16x3 with batch = S over K slabs) and the
+ * LayerNorm launch that followed them.  gamma NULL: only out_sum.  Any output may be NULL. */
+int zh_sum_layernorm_f32(const float* parts, int n_parts, long part_stride, const float* bias, const float* residual,
+                         float* out_sum, const float* gamma, const float* beta, float eps,
+                         float* out_f32, void* out_f16, long lo_plane,
+                         long out_group_rows, long out_group_stride, long out_offset, int skip_first_in_group,
+                         const float* gamma2, const float* beta2, float eps2, float* out2_f32, void* out2_f16, long lo_plane2,
+                         long out2_group_rows, long out2_group_stride, long out2_offset,
+                         int rows, int D, zh_stream_t stream);
 
 /* cat(class_embedding, patch_emb) + pos_embed, then ln_pre: clip_arch.py:384-397.  out [B,T,D] f32.
  * gamma = beta = NULL: no LayerNorm (DINO ViT prepare_tokens, selfmask/vision_transformer.py:269-281). */
@@ -207,7 +223,9 @@ int zh_confusion_hist(const long long* label_true, const long long* label_pred, 
 /* binary = p > threshold; size = sum(binary); confidence = sum(p*binary)/(size+1e-7)   (zutis.py:390-397).
  * mask_proposals f32: image b at + b*stride_image, [Q, M] contiguous inside (last decoder layer slice). */
 int zh_instance_mask_stats(const float* mask_proposals, long stride_image, float threshold, int B, int Q, int M,
-                           float* sizes, float* confidence, unsigned char* binary, zh_stream_t stream);
+                           float* sizes, float* confidence, unsigned char* binary, int* range_flag, zh_stream_t stream);
+/* range_flag (may be NULL; zero it first): bit 0 is OR-ed in when a proposal is outside [0, 1] or a NaN — the reference's range asserts
+ * (zutis.py:385-386) without a reduction and a device -> host copy of their own. */
 /* avg[b,q,:] = sum_m binary[b,q,m]*tokens[b,m,:] / (size+1e-7)  (zutis.py:404-406; the reference materialises
  * B x Q x hw x E).  Pixels are processed in chunks of 128 by separate workgroups; per-chunk partial sums go through `workspace`
  * (zh_masked_mean_workspace_size bytes) and are added in chunk order. */
@@ -269,7 +287,10 @@ int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, const lo
  * order; empty masks skipped): out_index int32 [B,Q], out_score f64 [B,Q], out_category int64 [B,Q], out_count int32 [B]. */
 int zh_mask_nms(const int* inter, const int* uni, const float* scores, const long long* category_ids, int B, int Q,
                 int nms_type, double nms_threshold, double sigma, double score_threshold,
-                int* out_index, double* out_score, long long* out_category, int* out_count, zh_stream_t stream);
+                int* out_index, double* out_score, long long* out_category, int* out_count, double* packed, const int* range_flag,
+                zh_stream_t stream);
+/* packed (may be NULL): f64 [B, 4Q + 2] = per image [out_index (-1 past the count) | out_score | out_category | category_ids | count,
+ * *range_flag] — everything the host needs in one device -> host copy. */
 
 /* Device-side run extraction for COCO RLE + boxes + areas of selected masks (masks u8 [n,H,W] row-major; sel int32
  * [n_sel] mask indices): positions int32 [n_sel, max_runs] = column-major pixel indices where the value changes;
@@ -277,6 +298,10 @@ int zh_mask_nms(const int* inter, const int* uni, const float* scores, const lon
  * Replaces the mask D2H in front of pycocotools.mask.encode / masks_to_boxes, zutis.py:288-294,446-452. */
 int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, int W, int max_runs,
                  int* positions, int* nruns, int* box_area, zh_stream_t stream);
+/* The same for the queries zh_mask_nms kept, straight from its device outputs (masks u8 [B,Q,H,W]; kept_index int32 [B,Q], kept_count
+ * int32 [B]): row b*Q + j of positions / nruns / box_area describes image b's j-th kept mask; rows j >= kept_count[b] are not written. */
+int zh_mask_runs_kept(const unsigned char* masks, const int* kept_index, const int* kept_count, int B, int Q, int H, int W, int max_runs,
+                      int* positions, int* nruns, int* box_area, zh_stream_t stream);
 
 /* Native launch plans (zutis_amd/plan.py): replay n recorded calls of the entry points above (op id + 24 argument words
  * each; dispatcher generated from this header) in one C loop; zh_plan_run2 alternates two plans on two streams. */

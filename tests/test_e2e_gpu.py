@@ -401,22 +401,37 @@ def test_forward_graphed_shape_a_b_a_and_fork(dev):
 
 
 def test_batch_invariance_full_size(dev):
-    """Size-independent property at the BASELINE geometry (ViT-B/16 @336): images are independent, so image i's outputs
-    are BITWISE the same whether it is evaluated alone or inside a batch (every reduction runs over K / keys / one image
-    in a fixed order) — this is what makes rank-sharded evaluation reproduce the single-GPU result exactly."""
+    """Size-independent property at the BASELINE geometry (ViT-B/16 @336): images are independent, and every reduction runs over K /
+    keys / one image in an order fixed by the shape, so image i's outputs are BITWISE the same at any position of a batch and in
+    batches of different sizes that select the same kernels (here 3 and 4 images: what makes rank-sharded evaluation with equal
+    shards reproduce the single-GPU result exactly).  Kernel selection has three thresholds — split-K of the N = D GEMMs up to 2048
+    token rows, the key split of self-attention up to 128 (image, head, query block) items, the few-row GEMM kernel up to 128 rows
+    (engine_base._splitk / _vit_blocks, gemm_skinny.h) — and across them (one image alone) the sums are re-associated: fp32-class
+    agreement, checked against the same tolerances as the oracle comparison."""
     from zutis_amd import detgen
     cfg = detgen.VIT_B16
     eng = _engine(cfg, dev)
-    x = torch.from_numpy(detgen.images(3, 336, 336, seed=4)).to(dev)
+    x = torch.from_numpy(detgen.images(4, 336, 336, seed=4)).to(dev)
     text = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim)).to(dev)
-    full = eng.forward(x)
-    full = {k: v.clone() for k, v in full.items()}
+    full = {k: v.clone() for k, v in eng.forward(x).items()}
     lab_full = eng.predict_semantic(full["patch_tokens"], text, (336, 336)).clone()
-    for i in (0, 2):
+    perm = [2, 0, 1]                                                   # three of the four, in another order
+    sub = {k: v.clone() for k, v in eng.forward(x[perm].contiguous()).items()}
+    lab_sub = eng.predict_semantic(sub["patch_tokens"], text, (336, 336)).clone()
+    for j, i in enumerate(perm):
+        assert torch.equal(sub["mask_proposals"][j], full["mask_proposals"][i])
+        assert torch.equal(sub["patch_tokens"][j], full["patch_tokens"][i])
+        assert torch.equal(lab_sub[j], lab_full[i])
+    again = eng.forward(x)
+    assert torch.equal(again["mask_proposals"], full["mask_proposals"]) and torch.equal(again["patch_tokens"], full["patch_tokens"])
+    for i in (0, 3):                                                   # one image alone: other kernels, the same numbers to fp32 re-association
         one = eng.forward(x[i:i + 1].contiguous())
-        assert torch.equal(one["mask_proposals"][0], full["mask_proposals"][i])
-        assert torch.equal(one["patch_tokens"][0], full["patch_tokens"][i])
-        assert torch.equal(eng.predict_semantic(one["patch_tokens"], text, (336, 336))[0], lab_full[i])
+        # two fp32-class evaluations of the same function: each is within 2e-4 (masks) / 2e-5 (unit-norm tokens) of the fp32 oracle
+        # (test_engine_matches_reference_golden), so they are within the sum of each other
+        assert float((one["mask_proposals"][0] - full["mask_proposals"][i]).abs().max()) < 4e-4
+        assert float((one["patch_tokens"][0] - full["patch_tokens"][i]).abs().max()) < 1e-5
+        lab = eng.predict_semantic(one["patch_tokens"], text, (336, 336))[0]
+        assert float((lab != lab_full[i]).float().mean()) < 1e-3       # argmax flips only on fp32-level ties between two classes
     pt = full["patch_tokens"]
     assert (pt.norm(dim=-1) - 1).abs().max().item() < 1e-5
     assert 0 <= full["mask_proposals"].min().item() and full["mask_proposals"].max().item() <= 1

@@ -527,6 +527,34 @@ def test_device_mask_nms_matches_reference_control_flow(dev, nms_type):
     else:
         assert np.abs(got_s - ref_s).max() < 1e-12
     assert len(eng_kept) > 20
+    # the chained form the drop-in's predict uses (NMS -> run extraction from the loop's device outputs, one host round trip): the
+    # same kept list, and RLE / boxes / areas identical to the two-step path (instance_nms -> host -> encode_masks)
+    md = torch.from_numpy(masks).to(dev)
+    flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+    kept2, rles2, boxes2, areas2, bad = ZutisEngine.instance_nms_encode(None, md, torch.from_numpy(scores).to(dev), torch.from_numpy(cats).to(dev),
+                                                                        nms_type, range_flag=flag)
+    assert not bad and kept2 == eng_kept
+    sel = np.array([b * Q + q for b, _, q, _ in eng_kept], dtype=np.int32)
+    rles1, boxes1, areas1 = ZutisEngine.encode_masks(None, md.view(B * Q, H, W), sel)
+    assert rles2 == rles1 and boxes2 == boxes1 and areas2 == areas1
+
+
+def test_range_flag_of_the_instance_statistics(dev):
+    """The reference asserts 0 <= mask_proposals <= 1 (zutis.py:385-386): zh_instance_mask_stats raises a device flag for a value
+    outside the range or a NaN, and leaves it alone otherwise."""
+    from zutis_amd import ops
+    B, Q, M = 2, 7, 300
+    mp = torch.rand((B, Q, M), generator=torch.Generator().manual_seed(3))
+    for bad, val in ((False, None), (True, 1.0001), (True, -1e-6), (True, float("nan"))):
+        x = mp.clone()
+        if bad:
+            x[1, 5, 299] = val
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        sizes, conf = torch.empty((B * Q,), device=dev), torch.empty((B * Q,), device=dev)
+        binary = torch.empty((B, Q, M), dtype=torch.uint8, device=dev)
+        ops.instance_mask_stats(x.to(dev), Q * M, 0.5, B, Q, M, sizes, conf, binary, flag)
+        assert bool(flag.item()) == bad
+        assert torch.equal(binary.cpu(), (x > 0.5).to(torch.uint8))
 
 
 @pytest.mark.parametrize("h,w,H,W", [(120, 160, 480, 640), (107, 160, 427, 640), (30, 40, 123, 164), (21, 21, 336, 336), (9, 13, 50, 1030)])

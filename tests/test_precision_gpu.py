@@ -204,7 +204,7 @@ def test_gemm_x3_row_periodic_table_before_rounding(dev, kind):
     assert float((got - ref).abs().max()) < tol, float((got - ref).abs().max())
 
 
-@pytest.mark.parametrize("tile", [64, 96, 192, 256, 512, 448, 3064])
+@pytest.mark.parametrize("tile", [64, 96, 192, 256, 512, 448, 3064, 32, 1284, 1288, 965, 9612, 1608])
 def test_gemm_x3_every_tile_variant(dev, tile):
     """Every x3 tile (128x64, 192x128, 256x128 on the 3-slot ring; 256x256 on the two-slot ring with the SGPR-base LDS-DMA and
     the in-place A lo fragments), forced through zh_dev_set_gemm_overrides, over K = 64 .. 1024 (every prologue / steady / tail
@@ -600,3 +600,115 @@ def test_gemm_x3_tail_peel_is_bitwise_one_launch(dev, x2):
     assert torch.equal(o_p, o_1) and torch.equal(sp_p, sp_1)
     ref = (A.t[0].double() + A.t[1].double()) @ W32.double().t() + bias.double() + res.double()
     assert float((o_p.double() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(100, 768, 768, 1), (100, 2304, 768, 1), (100, 768, 2048, 1), (20, 384, 384, 1), (7, 8, 64, 1), (128, 260, 320, 3), (97, 36, 1024, 2)])
+def test_gemm_x3_few_row_kernel(dev, M, N, K, batch):
+    """The few-row kernel behind zh_gemm_f16x3 (M <= 128: operands straight into fragments, K split over the four waves of a block,
+    gemm_skinny.h) on the decoder's batch-1 shapes and ragged ones: fp32-class against float64 for every output kind and epilogue
+    piece, the fp16-valued-weight (two-product) form bitwise equal to the three-product form on a zero lo plane, repeatable."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    A32 = _randn((batch, M, K), 70, 0.7) * torch.exp(_randn((batch, M, K), 71) * 1.2)
+    W32 = _randn((batch, N, K), 72, 0.04) * torch.exp(_randn((batch, N, K), 73))
+    bias, res = _randn((N,), 74), _randn((25, N), 75)
+    A = Act(torch.stack([A32.to(f16), (A32 - A32.to(f16).float()).to(f16)]).contiguous().to(dev))
+    Wt = ops.split_weight(W32.to(dev) if batch > 1 else W32[0].to(dev))          # one scale for the whole (batched) weight
+    ref = torch.einsum("bmk,bnk->bmn", A32.double(), W32.double())
+    bound = torch.einsum("bmk,bnk->bmn", A32.abs().double(), W32.abs().double())
+    kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldc=N, batch=batch, strideA=M * K, strideW=N * K, strideC=M * N) if batch > 1 else {}
+    o32 = torch.empty((batch, M, N), dtype=f32, device=dev)
+    ops.gemm_x3(A if batch > 1 else A.view(A.hi[0]), Wt, o32, bias=bias.to(dev), residual=res.to(dev), res_rows=25, **kw)
+    want = ref + bias.double() + res.double()[torch.arange(M) % 25]
+    assert float(((o32.cpu().double() - want).abs() / (bound + 1e-3)).max()) < 2e-6
+    o2 = torch.empty_like(o32)
+    ops.gemm_x3(A if batch > 1 else A.view(A.hi[0]), Wt, o2, bias=bias.to(dev), residual=res.to(dev), res_rows=25, **kw)
+    assert torch.equal(o32, o2)
+    osp = Act.empty((batch, M, N), True, dev)
+    ops.gemm_x3(A if batch > 1 else A.view(A.hi[0]), Wt, osp if batch > 1 else osp.view(osp.hi[0]), bias=bias.to(dev), act=ops.ACT_RELU, **kw)
+    got = osp.t[0].float().cpu().double() + osp.t[1].float().cpu().double()
+    wr = torch.relu(ref + bias.double())
+    assert float(((got - wr).abs() / (bound + 1e-3 + wr.abs())).max()) < 2e-6
+    o16 = Act.empty((batch, M, N), False, dev)
+    ops.gemm_x3(A if batch > 1 else A.view(A.hi[0]), Wt, o16 if batch > 1 else o16.view(o16.hi[0]), bias=bias.to(dev), act=ops.ACT_QUICKGELU, **kw)
+    y = ref + bias.double()
+    assert torch.allclose(o16.t[0].float().cpu().double(), y * torch.sigmoid(1.702 * y), atol=4e-3, rtol=2e-3)
+    if batch == 1:                                                   # fp16-valued weight: one plane (x2 form) == two planes with a zero lo plane
+        Wh = W32[0].to(f16).float()
+        w1, w2 = ops.split_weight(Wh.to(dev)), ops.split_weight(Wh.to(dev), allow_x2=False)
+        assert w1.x2 and not w2.x2
+        a, b = torch.empty((M, N), dtype=f32, device=dev), torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm_x3(A.view(A.hi[0]), w1, a, bias=bias.to(dev))
+        ops.gemm_x3(A.view(A.hi[0]), w2, b, bias=bias.to(dev))
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D,S", [(768, 1), (768, 4), (384, 2), (1024, 3), (192, 8)])
+def test_sum_layernorm(dev, D, S):
+    """zh_sum_layernorm_f32: planes + bias + residual -> sum (in place over the residual), LN -> fp32 / split pair with the drop-first
+    row map (ln_post), chained second LN with the stacked row map (norm3 -> decoder.norm)."""
+    import torch.nn.functional as F
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    B, T = 3, 13
+    R = B * T
+    parts = _randn((S, R, D), 80)
+    bias, res = _randn((D,), 81), _randn((R, D), 82) * 3 + 0.5
+    g1, b1, g2, b2 = _randn((D,), 83) * 0.1 + 1, _randn((D,), 84) * 0.1, _randn((D,), 85) * 0.2 + 1, _randn((D,), 86) * 0.1
+    x = parts[0].clone()
+    for s_ in range(1, S):
+        x = x + parts[s_]
+    x = (x + bias) + res                                             # the kernel's order: fp32, plane order, bias, residual
+    y = F.layer_norm(x.double(), (D,), g1.double(), b1.double(), 1e-5)
+    z = F.layer_norm(y, (D,), g2.double(), b2.double(), 1e-6)
+    xs = res.clone().to(dev)
+    o32 = torch.empty((R, D), dtype=f32, device=dev)
+    o16 = Act.empty((R, D), True, dev)
+    z32 = torch.zeros((B, 2, T, D), dtype=f32, device=dev)
+    z16 = Act(torch.zeros((2, B * 2 * T, D), dtype=f16, device=dev))
+    ops.sum_layernorm(parts.to(dev), S, R, D, bias=bias.to(dev), residual=xs, out_sum=xs, gamma=g1.to(dev), beta=b1.to(dev), eps=1e-5,
+                      out_f32=o32, out_f16=o16, gamma2=g2.to(dev), beta2=b2.to(dev), eps2=1e-6, out2_f32=z32, out2_f16=z16,
+                      out2_group_rows=T, out2_group_stride=2 * T, out2_offset=T)
+    assert torch.equal(xs.cpu(), x)                                  # the sum is the fp32 sum in the stated order, bit for bit
+    assert float((o32.cpu().double() - y).abs().max()) < 2e-5
+    assert float(((o16.t[0].float() + o16.t[1].float()).cpu().double() - y).abs().max()) < 2e-5
+    assert torch.equal(o16.t[0].cpu(), o32.cpu().to(f16))
+    assert float((z32.cpu()[:, 1].reshape(R, D).double() - z).abs().max()) < 4e-5 and torch.all(z32[:, 0] == 0)
+    zz = (z16.t[0].float() + z16.t[1].float()).cpu().view(B, 2, T, D)
+    assert float((zz[:, 1].reshape(R, D).double() - z).abs().max()) < 4e-5 and torch.all(zz[:, 0] == 0)
+    # ln_post's row map: the first row of every group of T (cls) is dropped, the rest packed [B, T-1]
+    tok = torch.full((B * (T - 1), D), 7.0, dtype=f32, device=dev)
+    ops.sum_layernorm(parts.to(dev), S, R, D, bias=bias.to(dev), residual=res.to(dev), gamma=g1.to(dev), beta=b1.to(dev), eps=1e-5, out_f32=tok,
+                      out_group_rows=T, out_group_stride=T - 1, out_offset=-1, skip_first_in_group=True)
+    assert float((tok.cpu().double() - y.view(B, T, D)[:, 1:].reshape(-1, D)).abs().max()) < 2e-5
+    # sum only
+    xo = torch.empty((R, D), dtype=f32, device=dev)
+    ops.sum_layernorm(parts.to(dev), S, R, D, bias=bias.to(dev), residual=res.to(dev), out_sum=xo)
+    assert torch.equal(xo.cpu(), x)
+
+
+def test_split_k_planes_plus_sum_layernorm_equals_gemm_plus_layernorm(dev):
+    """The few-row regime of a transformer block: the N = D GEMM as a batched GEMM over K slabs (fp32 planes) + zh_sum_layernorm_f32
+    against the one-launch GEMM (bias + residual epilogue) + LayerNorm: same numbers up to fp32 re-association, fp32-class vs float64."""
+    import torch.nn.functional as F
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    R, D, K, S = 1201, 768, 3072, 4
+    A32, W32 = _randn((R, K), 90, 0.5), _randn((D, K), 91, 0.02)
+    bias, X0 = _randn((D,), 92), _randn((R, D), 93)
+    g, b = _randn((D,), 94) * 0.1 + 1, _randn((D,), 95) * 0.1
+    A, W = _split_act(A32, dev), ops.split_weight(W32.to(dev))
+    X1 = X0.clone().to(dev)
+    ops.gemm_x3(A, W, X1, bias=bias.to(dev), residual=X1)
+    Y1 = Act.empty((R, D), True, dev)
+    ops.layernorm(X1, g.to(dev), b.to(dev), 1e-5, R, D, out_f16=Y1)
+    parts = torch.empty((S, R, D), dtype=f32, device=dev)
+    ops.gemm_x3(A, W, parts, M=R, N=D, K=K // S, lda=K, ldw=K, ldc=D, batch=S, strideA=K // S, strideW=K // S, strideC=R * D)
+    X2 = X0.clone().to(dev)
+    Y2 = Act.empty((R, D), True, dev)
+    ops.sum_layernorm(parts, S, R, D, bias=bias.to(dev), residual=X2, out_sum=X2, gamma=g.to(dev), beta=b.to(dev), eps=1e-5, out_f16=Y2)
+    ref = A32.double() @ W32.double().t() + bias.double() + X0.double()
+    assert float((X2.cpu().double() - ref).abs().max()) < 3e-6 and float((X1.cpu().double() - ref).abs().max()) < 3e-6
+    yr = F.layer_norm(ref, (D,), g.double(), b.double(), 1e-5)
+    for Y in (Y1, Y2):
+        assert float(((Y.t[0].float() + Y.t[1].float()).cpu().double() - yr).abs().max()) < 5e-6

@@ -16,7 +16,16 @@ X2 = "x2" in sys.argv[1:]          # fp16-valued weights: the two-product kernel
 if X2:
     shapes = shapes[1:] + [(147712, 3072, 1024, "L qkv", "split"), (147712, 1024, 1024, "L out", "f32"), (147712, 4096, 1024, "L fc", "split"),
                            (147712, 1024, 4096, "L proj", "f32")]
-for M, N, K, name, kind in shapes:
+B1 = "b1" in sys.argv[1:]          # batch-1 evaluation shapes (config 3: T = 1201 tokens), forced tile codes: b1 [tile ...]
+if B1:
+    shapes = [(1201, 2304, 768, "qkv", "split"), (1201, 3072, 768, "fc", "split"), (1201, 768, 768, "out", "f32"), (1201, 768, 3072, "proj", "f32"),
+              (100, 768, 768, "dec", "f32")]
+    tiles = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]
+    shapes = [s + (t,) for s in shapes for t in tiles]
+for sh in shapes:
+    M, N, K, name, kind = sh[:5]
+    if len(sh) > 5:
+        _lib.check(raw.zh_dev_set_gemm_overrides(0, sh[5], 0)); name = f"{name}/t{sh[5]}"
     A32 = torch.randn(M, K, device=dev); W32 = torch.randn(N, K, device=dev) * 0.03
     if X2:
         W32 = W32.half().float()
@@ -34,6 +43,9 @@ for M, N, K, name, kind in shapes:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
     raw.zh_gemm_x3_set_probe(probe.data_ptr())
+    if B1:                                  # the probed launch reads a weight that was never touched: from HBM, as in the model
+        W = ops.split_weight(torch.randn(N, K, device=dev) * 0.03)
+        junk = torch.empty(300 << 20, dtype=torch.uint8, device=dev); junk.fill_(1); torch.cuda.synchronize()
     run(); torch.cuda.synchronize()
     raw.zh_gemm_x3_set_probe(None)
     r = probe.cpu().numpy().reshape(-1, 8)

@@ -41,6 +41,7 @@ _SIGS = {
     "zh_eot_rows_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "zh_group_mean_l2norm": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "zh_layernorm_f32": (_i, [_vp, _l, _l, _l, _l, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
+    "zh_sum_layernorm_f32": (_i, [_vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _l, _l, _l, _l, _i, _vp, _vp, _f, _vp, _vp, _l, _l, _l, _l, _i, _i, _vp]),
     "zh_assemble_tokens_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "zh_l2norm_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _l, _vp]),
     "zh_global_ln_l2_workspace_size": (_sz, [_i, _i, _i]),
@@ -58,11 +59,12 @@ _SIGS = {
     "zh_confusion_hist": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "zh_topk_rows": (_i, [_vp, _l, _i, _l, _i, _vp, C.c_longlong, _vp, _vp, _l, _vp]),
     "zh_mask_runs": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "zh_mask_runs_kept": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "zh_rle_counts_to_string_host": (C.c_long, [_vp, C.c_long, _vp, C.c_long]),
     "zh_rle_from_transitions_host": (C.c_long, [_vp, C.c_long, _vp, C.c_long, C.c_long, _vp, C.c_long, _vp]),
     "zh_rle_encode_host": (C.c_long, [_vp, _i, _i, _vp, C.c_long]),
     "zh_resize_nearest_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
-    "zh_instance_mask_stats": (_i, [_vp, _l, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "zh_instance_mask_stats": (_i, [_vp, _l, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "zh_masked_mean_workspace_size": (_sz, [_i, _i, _i, _i]),
     "zh_masked_mean_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "zh_instance_classify": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
@@ -76,7 +78,7 @@ _SIGS = {
     "zh_plan_run": (_i, [_vp, _i, _vp]),
     "zh_plan_run_multi": (_i, [_vp, _vp, _vp, _i]),
     "zh_plan_run2": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
-    "zh_mask_nms": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),
+    "zh_mask_nms": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zh_mask_iou_workspace_size": (_sz, [_i, _l]),
     "zh_mask_iou_counts": (_i, [_vp, _i, _l, _vp, _vp, _vp, _sz, _vp]),
 }

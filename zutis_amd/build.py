@@ -37,7 +37,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_kernel.h"),
+    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "gemm_skinny.h"),
                         os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -56,6 +56,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         deps = [src, os.path.join(CSRC, "common.h")]
         if os.path.basename(src).startswith("gemm"):
             deps.append(os.path.join(CSRC, "gemm_kernel.h"))
+            deps.append(os.path.join(CSRC, "gemm_skinny.h"))
         if os.path.basename(src) in ("plan.hip", "capi.hip"):       # the dispatcher generated from the header / ZH_ABI_VERSION
             deps.append(os.path.join(os.path.dirname(HERE), "include", "zutis_hip.h"))
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):

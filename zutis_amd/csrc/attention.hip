@@ -120,21 +120,22 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
 #ifdef ZH_ATTN_STAMP
   const long long st_e0 = __builtin_amdgcn_s_memtime(), st_re0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2, so the query
-  // blocks of one (image, head) — which all stream the same K / V — get ids that are congruent mod 8 and meet in one L2:
-  // id = ((group / 8) * nqb + qb) * 8 + group % 8, group = img * heads + head.  The grid is padded to a multiple of 8 groups.
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  The work items
+  // (group = image * heads + head, query block, key split) are numbered group-major and every XCD takes a CONTIGUOUS eighth of
+  // that list: the query blocks / key splits of one (image, head) — which stream the same K / V — meet in one L2 (two at a range
+  // boundary), and the XCDs' shares differ by at most one workgroup.  (Round 3 dealt whole groups, group % 8 -> XCD: with the 12
+  // heads of one image four XCDs got two heads and four got one — the batch-1 encoder ran at the pace of the loaded half.)
   const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int per_group = p.nqb * p.ksplit;
 #ifdef ZH_ATTN_PLAIN_ORDER                               // developer A/B build: query blocks of a group on consecutive ids
-  const int rr = id;
-  const int qb = rr % p.nqb, ks = 0;
-  const int group = rr / p.nqb;
+  const int item = id;
 #else
-  const int rr = id >> 3;
-  const int qbs = rr % (p.nqb * p.ksplit);
-  const int qb = qbs / p.ksplit, ks = qbs - qb * p.ksplit;
-  const int group = (rr / (p.nqb * p.ksplit)) * 8 + (id & 7);
+  const int item = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);   // the grid is 8 x (items per XCD)
 #endif
-  if (group >= p.groups) return;                        // padding blocks (whole workgroup, before any barrier)
+  if (item >= p.groups * per_group) return;             // surplus workgroups of the last XCD share (whole workgroup, before any barrier)
+  const int group = item / per_group;
+  const int qbs = item - group * per_group;
+  const int qb = qbs / p.ksplit, ks = qbs - qb * p.ksplit;
   const int head = group % p.H, img = group / p.H;
   const int q0 = qb * (32 * NWAVE) + wave * 32;
   const int ql = lane & 31, hh = lane >> 5;
@@ -630,7 +631,7 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   p.stamp = g_attn_stamp;
 #endif
   if (ksplit > 1) {
-    ZH_CHECK_ARG(!causal && ksplit <= 16, "zh_attention_f16_splitk: ksplit %d not in 1..16 (and not for the causal form)", ksplit);
+    ZH_CHECK_ARG(!causal && ksplit <= 64, "zh_attention_f16_splitk: ksplit %d not in 1..64 (and not for the causal form)", ksplit);
     const int ktt = x3 ? 32 : 64;
     p.ksplit = ksplit;
     p.kchunk = zh_cdiv(zh_cdiv(Tk, ktt), ksplit) * ktt;
@@ -640,7 +641,9 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
                  "zh_attention_f16_splitk: workspace too small or misaligned (%zu < %zu)", workspace_bytes, (no + 2 * nm) * 4);
     p.part_o = (float*)workspace; p.part_m = p.part_o + no; p.part_l = p.part_m + nm;
   }
-  const long nblk = (long)zh_cdiv(p.groups, 8) * 8 * p.nqb * p.ksplit;  // decoded XCD-aware in the kernel
+  const long items = (long)p.groups * p.nqb * p.ksplit;
+  ZH_CHECK_ARG(items < (1L << 31) - 8, "zh_attention_f16: grid too large");
+  const long nblk = (long)zh_cdiv(items, 8) * 8;        // decoded XCD-aware in the kernel: XCD x takes items [x * nblk / 8, (x + 1) * nblk / 8)
   ZH_CHECK_ARG(nblk < (1L << 31), "zh_attention_f16: grid too large");
   dim3 grid((unsigned)nblk);
   // Split-pair kernels: the software-pipelined loop (K.Q^T of tile t+1 issued in among the softmax of tile t; bit-identical

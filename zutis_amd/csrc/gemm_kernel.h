@@ -486,6 +486,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     for (int s = 0; s < DISTX; ++s)
       if (s < nk) issue_stage(s);
     pos_after_prologue();
+    ZH_PROBE(1);
     half8_t fa[2 * TM], fw[NPLW * TN];
     int slot = 0, wslot = DISTX % STAGES;
     auto read_frags = [&]() {

@@ -6,8 +6,12 @@
 // Weights are packed as W * 2^s (s chosen per matrix so that lo stays a normal fp16 number); `out_scale` = 2^-s is applied
 // to the accumulator before the bias.  Kernel: gemm_kernel.h with SPLIT = 1.
 #include "gemm_kernel.h"
+#include "gemm_skinny.h"
 #ifndef RING64
 #define RING64 6      // ring depth of the 64 x 64 tile (developer A/B, round 3: -DRING64=8 — config 3 forward 3.02 ms either way, batch-1 336 px 2.50 vs 2.55 ms: not bound by the slices in flight)
+#endif
+#ifndef ZH_SKINNY_MAX_ROWS
+#define ZH_SKINNY_MAX_ROWS 128
 #endif
 #ifdef ZH_GEMM_PROBE
 extern "C" void zh_gemm_x3_set_probe(long long* p) { g_probe = p; }   // developer build (tools/gemm_x3_stamp.py)
@@ -102,6 +106,18 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   //  at TM = 7): under the power limit a round that leaves CUs idle lets the others clock higher.  Touching the tile's residual
   //  lines eight slices before the end of the K loop, so that the fp32-residual epilogue finds them in the L2: out_proj 58.1 ->
   //  63 - 65 us, c_proj 175 -> 179 — the loads stall the slice that retires them and the residual was cache-resident anyway.)
+  // few-row GEMMs (the decoder at batch 1, ffn2, SelfMask's 20 queries): gemm_skinny.h — operands straight into fragments, K split
+  // over the four waves of a block, no ring.  Tile code 32 forces it for any M (tests), any other forced code disables it.
+  {
+    const int forced_tile = gemm_dev_overrides().tile;
+    const int max_rows = forced_tile == 32 ? (1 << 30) : (forced_tile ? 0 : ZH_SKINNY_MAX_ROWS);
+    if (gemm_skinny_ok(p, batch, p.vec_ok, max_rows)) {
+      if (x2) launch_skinny<1>(p, batch, out_kind, stream);
+      else launch_skinny<2>(p, batch, out_kind, stream);
+      ZH_CHECK_LAUNCH("zh_gemm_f16x3");
+      return ZH_OK;
+    }
+  }
   const double c256 = tiling_cost(M, N, batch, 256, 128, 1, 1.0);
   const double c192 = tiling_cost(M, N, batch, 192, 128, 1, 0.95);
   const double c64 = tiling_cost(M, N, batch, 128, 64, 2, 0.7);
@@ -130,6 +146,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   if (pick == 64 && (long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch <= 256) pick = 3064;
   const int forced = gemm_dev_overrides().tile;
   if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448 || forced == 3064) pick = forced;
+  if (forced == 1284 || forced == 1288 || forced == 965 || forced == 9612 || forced == 1608) pick = forced;   // round-4 candidates for M ~ 1200 rows
   if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
   if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124 || pick == 4484) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
@@ -184,6 +201,11 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2>(p, batch, out_kind, stream);   // 8 waves of 32 x 48
   else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2>(p, batch, out_kind, stream);   // 64 x 64, deep ring
+  else if (pick == 1284) ok = launch_x3<2, 2, 4, 4, 4, 2>(p, batch, out_kind, stream);   // 128 x 128, 4 waves of 64 x 64, 4 slots
+  else if (pick == 1288) ok = launch_x3<4, 2, 2, 4, 4, 2>(p, batch, out_kind, stream);   // 128 x 128, 8 waves of 32 x 64, 4 slots
+  else if (pick == 965) ok = launch_x3<4, 2, 2, 3, 5, 2>(p, batch, out_kind, stream);    // 128 x 96, 5 slots
+  else if (pick == 9612) ok = launch_x3<2, 2, 3, 4, 5, 2>(p, batch, out_kind, stream);   // 96 x 128, 5 slots
+  else if (pick == 1608) ok = launch_x3<2, 4, 5, 2, 4, 2>(p, batch, out_kind, stream);   // 160 x 128 (8 waves of 80 x 32), 4 slots
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16x3");

@@ -5,16 +5,20 @@
 #include "common.h"
 
 // ---- per (image, query): size = #(p > thr), conf = sum(p * (p > thr)) / (size + 1e-7)   (zutis.py:390-397)
+// range_flag (optional): bit 0 is set when any proposal lies outside [0, 1] (or is a NaN) — the reference's two asserts on the
+// mask proposals (zutis.py:385-386), checked by the host at the predict's one synchronisation instead of with a reduction + copy of its own
 __global__ __launch_bounds__(256) void instance_stats_kernel(const float* mp, long stride_b, float thr, long rows, int Q, int M,
-                                                             float* sizes, float* conf, unsigned char* binary) {
+                                                             float* sizes, float* conf, unsigned char* binary, int* range_flag) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // r = b*Q + q
   if (r >= rows) return;
   const int b = (int)(r / Q), q = (int)(r % Q);
   const float* p = mp + (long)b * stride_b + (long)q * M;
   float cnt = 0.f, s = 0.f;
+  bool bad = false;
   for (int m = lane; m < M; m += 64) {
     const float v = p[m];
+    bad |= !(v >= 0.f && v <= 1.f);
     const bool on = v > thr;
     cnt += on ? 1.f : 0.f;
     s += on ? v : 0.f;
@@ -23,14 +27,15 @@ __global__ __launch_bounds__(256) void instance_stats_kernel(const float* mp, lo
   cnt = wave_sum(cnt);
   s = wave_sum(s);
   if (lane == 0) { sizes[r] = cnt; conf[r] = s / (cnt + 1e-7f); }
+  if (range_flag && __ballot(bad) != 0ull && lane == 0) atomicOr(range_flag, 1);
 }
 
 extern "C" int zh_instance_mask_stats(const float* mask_proposals, long stride_image, float threshold, int B, int Q, int M,
-                                      float* sizes, float* confidence, unsigned char* binary, hipStream_t stream) {
+                                      float* sizes, float* confidence, unsigned char* binary, int* range_flag, hipStream_t stream) {
   ZH_CHECK_ARG(mask_proposals && sizes && confidence && binary && B > 0 && Q > 0 && M > 0, "zh_instance_mask_stats: bad arguments");
   const long rows = (long)B * Q;
   hipLaunchKernelGGL(instance_stats_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, mask_proposals, stride_image, threshold, rows, Q, M,
-                     sizes, confidence, binary);
+                     sizes, confidence, binary, range_flag);
   ZH_CHECK_LAUNCH("zh_instance_mask_stats");
   return ZH_OK;
 }
@@ -267,13 +272,16 @@ __device__ __forceinline__ unsigned zh_nz_bytes(unsigned w) {   // 0x01 in every
   const unsigned t = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w;
   return (t >> 7) & 0x01010101u;
 }
-__global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* masks, const int* sel, int H, int W, int max_runs,
+// count != NULL (zh_mask_runs_kept): entry mi = b * Q + j is the j-th kept query of image b — sel[mi] is its query index (zh_mask_nms'
+// out_index), entries j >= count[b] do nothing: the NMS result never visits the host before the runs are extracted.
+__global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* masks, const int* sel, const int* count, int Q, int H, int W, int max_runs,
                                                         int* positions, int* nruns, int* box_area) {
   extern __shared__ unsigned char sm[];                    // [H][64] panel
   __shared__ int s_red[256];
   __shared__ int s_minx, s_maxx, s_miny, s_maxy, s_area;
   const int tid = threadIdx.x, mi = blockIdx.x, pnl = blockIdx.y;
-  const unsigned char* m = masks + (long)sel[mi] * H * W;
+  if (count && mi % Q >= count[mi / Q]) return;           // whole workgroup, before any barrier
+  const unsigned char* m = masks + (count ? (long)(mi / Q) * Q + sel[mi] : (long)sel[mi]) * H * W;
   int* pos = positions + (long)mi * max_runs;
   const int x0 = pnl * RUNS_PANEL, pw = min(RUNS_PANEL, W - x0);
   const bool vec = (W % 16 == 0) && (((uintptr_t)m & 15) == 0);
@@ -413,8 +421,23 @@ extern "C" int zh_mask_runs(const unsigned char* masks, const int* sel, int n_se
   const int npanel = zh_cdiv(W, RUNS_PANEL);
   ZH_CHECK_ARG(npanel <= 65535, "zh_mask_runs: mask too wide");
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(mask_runs_kernel, dim3(n_sel, npanel), dim3(256), lds, stream, masks, sel, H, W, max_runs, positions, nruns, box_area);
+  hipLaunchKernelGGL(mask_runs_kernel, dim3(n_sel, npanel), dim3(256), lds, stream, masks, sel, (const int*)nullptr, 1, H, W, max_runs, positions, nruns, box_area);
   ZH_CHECK_LAUNCH("zh_mask_runs");
+  return ZH_OK;
+}
+
+extern "C" int zh_mask_runs_kept(const unsigned char* masks, const int* kept_index, const int* kept_count, int B, int Q, int H, int W, int max_runs,
+                                 int* positions, int* nruns, int* box_area, hipStream_t stream) {
+  ZH_CHECK_ARG(masks && kept_index && kept_count && positions && nruns && box_area && B > 0 && Q > 0 && H > 0 && W > 0 && max_runs > 0,
+               "zh_mask_runs_kept: bad arguments");
+  ZH_CHECK_ARG((long)H * W < (1L << 31) && (long)B * Q < (1L << 31), "zh_mask_runs_kept: mask / batch too large");
+  const size_t lds = ((size_t)H * RUNS_PANEL + 15) & ~(size_t)15;
+  ZH_CHECK_ARG(lds <= 150 * 1024, "zh_mask_runs_kept: H=%d too tall for the LDS panel", H);
+  const int npanel = zh_cdiv(W, RUNS_PANEL);
+  ZH_CHECK_ARG(npanel <= 65535, "zh_mask_runs_kept: mask too wide");
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(mask_runs_kernel, dim3(B * Q, npanel), dim3(256), lds, stream, masks, kept_index, kept_count, Q, H, W, max_runs, positions, nruns, box_area);
+  ZH_CHECK_LAUNCH("zh_mask_runs_kept");
   return ZH_OK;
 }
 
@@ -434,7 +457,8 @@ extern "C" int zh_mask_runs(const unsigned char* masks, const int* sel, int n_se
 #define NMS_MAXQ 1024
 __global__ __launch_bounds__(256) void mask_nms_kernel(const int* inter, const int* uni, const float* scores, const long long* cats,
                                                        int Q, int nms_type, double thr, double sigma, double score_thr,
-                                                       int* out_idx, double* out_score, long long* out_cat, int* out_count) {
+                                                       int* out_idx, double* out_score, long long* out_cat, int* out_count,
+                                                       double* packed, const int* range_flag) {
   __shared__ double s_sc[NMS_MAXQ];
   __shared__ long long s_cat[NMS_MAXQ];
   __shared__ unsigned char s_act[NMS_MAXQ];
@@ -509,17 +533,32 @@ __global__ __launch_bounds__(256) void mask_nms_kernel(const int* inter, const i
     }
   }
   if (tid == 0) out_count[img] = s_n;
+  // packed (optional): everything the host needs from this image in ONE row of float64 — [index | score | category | every query's
+  // category | count, range flag] (small integers are exact in float64) — so that one device -> host copy fetches it
+  if (packed) {
+    __syncthreads();
+    double* row = packed + (long)img * (4 * Q + 2);
+    const int n = s_n;
+    for (int q = tid; q < Q; q += 256) {
+      row[q] = q < n ? (double)out_idx[q] : -1.0;
+      row[Q + q] = q < n ? out_score[q] : 0.0;
+      row[2 * Q + q] = q < n ? (double)out_cat[q] : 0.0;
+      row[3 * Q + q] = (double)s_cat[q];
+    }
+    if (tid == 0) { row[4 * Q] = (double)n; row[4 * Q + 1] = range_flag ? (double)*range_flag : 0.0; }
+  }
 }
 
 extern "C" int zh_mask_nms(const int* inter, const int* uni, const float* scores, const long long* category_ids, int B, int Q,
                            int nms_type, double nms_threshold, double sigma, double score_threshold,
-                           int* out_index, double* out_score, long long* out_category, int* out_count, hipStream_t stream) {
+                           int* out_index, double* out_score, long long* out_category, int* out_count, double* packed, const int* range_flag,
+                           hipStream_t stream) {
   ZH_CHECK_ARG(inter && uni && scores && category_ids && out_index && out_score && out_category && out_count,
                "zh_mask_nms: null pointer");
   ZH_CHECK_ARG(B > 0 && Q > 0 && Q <= NMS_MAXQ, "zh_mask_nms: need 0 < Q <= %d", NMS_MAXQ);
   ZH_CHECK_ARG(nms_type >= 0 && nms_type <= 2, "zh_mask_nms: nms_type %d not in {0 hard, 1 linear, 2 gaussian}", nms_type);
   hipLaunchKernelGGL(mask_nms_kernel, dim3(B), dim3(256), 0, stream, inter, uni, scores, category_ids, Q, nms_type, nms_threshold, sigma,
-                     score_threshold, out_index, out_score, out_category, out_count);
+                     score_threshold, out_index, out_score, out_category, out_count, packed, range_flag);
   ZH_CHECK_LAUNCH("zh_mask_nms");
   return ZH_OK;
 }

@@ -88,6 +88,104 @@ extern "C" int zh_layernorm_f32(const float* x, long in_group_rows, long in_grou
   return ZH_OK;
 }
 
+// ---- split-K combine + bias + residual + LayerNorm (+ a second, chained LayerNorm) in one pass over the row.
+//   x = ((parts[0] + parts[1] + ... ) + bias) + residual           (the order of the GEMM epilogue it replaces)
+//   out_sum = x;  y = LN(x; gamma, beta, eps) -> out_f32 / out_f16 at out_row(r);  z = LN(y; gamma2, beta2, eps2) -> out2_* at out2_row(r)
+// Batch-1 evaluation (configs/*: val batch_size 1; trainer.py:328-345): the N = 768 GEMMs of a block (out_proj, c_proj,
+// clip_arch.py:318-321) have 60 tiles for 256 CUs unless K is split; their fp32 partial planes are summed HERE, by the kernel
+// that had to read the sum anyway (the next LayerNorm), in plane order — deterministic.  The decoder's norm3 -> decoder.norm
+// pair (transformer.py:140-150,291) is the chained form.
+struct SumLnArgs {
+  const float* parts; int n_parts; long part_stride;
+  const float* bias; const float* residual; float* out_sum;
+  const float* gamma; const float* beta; float eps;
+  float* out_f32; half_t* out_f16; long lo_plane;
+  long og_rows, og_stride, og_offset; int skip_first;              // out_row(r) = (r / og_rows) * og_stride + og_offset + r % og_rows; skip r % og_rows == 0
+  const float* gamma2; const float* beta2; float eps2;
+  float* out2_f32; half_t* out2_f16; long lo_plane2;
+  long og2_rows, og2_stride, og2_offset;
+  int rows, D;
+};
+
+__global__ __launch_bounds__(256) void sum_layernorm_kernel(SumLnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.rows) return;
+  const int nv = p.D >> 2;
+  LnRow row;
+  const f32x4* p0 = (const f32x4*)(p.parts + r * p.D);
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j)
+    if (lane + 64 * j < nv) row.v[j] = p0[lane + 64 * j];
+  for (int s = 1; s < p.n_parts; ++s) {
+    const f32x4* ps = (const f32x4*)(p.parts + (long)s * p.part_stride + r * p.D);
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j)
+      if (lane + 64 * j < nv) row.v[j] += ps[lane + 64 * j];
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nv) {
+      if (p.bias) row.v[j] += ((const f32x4*)p.bias)[c];
+      if (p.residual) row.v[j] += ((const f32x4*)(p.residual + r * p.D))[c];
+      if (p.out_sum) ((f32x4*)(p.out_sum + r * p.D))[c] = row.v[j];
+    }
+  }
+  if (!p.gamma) return;
+  ln_normalize(row, nv, lane, p.D, p.eps);
+  const long g = r / p.og_rows, w = r % p.og_rows;
+  const bool emit = !(p.skip_first && w == 0);
+  const long ob = (g * p.og_stride + p.og_offset + w) * p.D;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nv) {
+      row.v[j] = row.v[j] * ((const f32x4*)p.gamma)[c] + ((const f32x4*)p.beta)[c];
+      if (emit) {
+        if (p.out_f32) ((f32x4*)(p.out_f32 + ob))[c] = row.v[j];
+        if (p.out_f16) zh_store_h4(p.out_f16 + ob + 4 * c, p.lo_plane, row.v[j]);
+      }
+    }
+  }
+  if (!p.gamma2) return;
+  ln_normalize(row, nv, lane, p.D, p.eps2);
+  const long ob2 = ((r / p.og2_rows) * p.og2_stride + p.og2_offset + (r % p.og2_rows)) * p.D;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nv) {
+      const f32x4 z = row.v[j] * ((const f32x4*)p.gamma2)[c] + ((const f32x4*)p.beta2)[c];
+      if (p.out2_f32) ((f32x4*)(p.out2_f32 + ob2))[c] = z;
+      if (p.out2_f16) zh_store_h4(p.out2_f16 + ob2 + 4 * c, p.lo_plane2, z);
+    }
+  }
+}
+
+extern "C" int zh_sum_layernorm_f32(const float* parts, int n_parts, long part_stride, const float* bias, const float* residual,
+                                    float* out_sum, const float* gamma, const float* beta, float eps,
+                                    float* out_f32, void* out_f16, long lo_plane,
+                                    long out_group_rows, long out_group_stride, long out_offset, int skip_first_in_group,
+                                    const float* gamma2, const float* beta2, float eps2, float* out2_f32, void* out2_f16, long lo_plane2,
+                                    long out2_group_rows, long out2_group_stride, long out2_offset,
+                                    int rows, int D, hipStream_t stream) {
+  ZH_CHECK_ARG(parts && n_parts >= 1 && rows > 0, "zh_sum_layernorm_f32: bad input");
+  ZH_CHECK_ARG(n_parts == 1 || part_stride >= (long)rows * D, "zh_sum_layernorm_f32: part_stride %ld < rows * D", part_stride);
+  ZH_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV && D > 0, "zh_sum_layernorm_f32: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXV);
+  ZH_CHECK_ARG(part_stride % 4 == 0 && lo_plane % 4 == 0 && lo_plane2 % 4 == 0, "zh_sum_layernorm_f32: strides / planes must be multiples of 4 elements");
+  ZH_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (gamma2 == nullptr) == (beta2 == nullptr), "zh_sum_layernorm_f32: gamma and beta go together");
+  ZH_CHECK_ARG(gamma || !(out_f32 || out_f16 || gamma2), "zh_sum_layernorm_f32: LayerNorm outputs need gamma / beta");
+  ZH_CHECK_ARG(gamma || out_sum, "zh_sum_layernorm_f32: nothing to write");
+  ZH_CHECK_ARG(!gamma || (out_group_rows > 0 && (out_f32 || out_f16 || gamma2)), "zh_sum_layernorm_f32: first LayerNorm needs an output and out_group_rows > 0");
+  ZH_CHECK_ARG(!gamma2 || (out2_group_rows > 0 && (out2_f32 || out2_f16)), "zh_sum_layernorm_f32: second LayerNorm needs an output and out2_group_rows > 0");
+  SumLnArgs p{parts, n_parts, part_stride, bias, residual, out_sum, gamma, beta, eps, out_f32, (half_t*)out_f16, lo_plane,
+              out_group_rows, out_group_stride, out_offset, skip_first_in_group, gamma2, beta2, eps2, out2_f32, (half_t*)out2_f16, lo_plane2,
+              out2_group_rows, out2_group_stride, out2_offset, rows, D};
+  hipLaunchKernelGGL(sum_layernorm_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, p);
+  ZH_CHECK_LAUNCH("zh_sum_layernorm_f32");
+  return ZH_OK;
+}
+
 // ---- token assembly + ln_pre: networks/clip_arch.py:384-397
 //   t[b,0] = class_embedding + pos[0];  t[b,1+i] = patch[b,i] + pos[1+i];  X = LN(t)
 struct AsmArgs {

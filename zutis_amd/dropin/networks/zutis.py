@@ -274,32 +274,34 @@ class ZUTIS(nn.Module):
         mask_proposals: torch.Tensor = dict_outputs["mask_proposals"]
         if len(mask_proposals.shape) == 5:
             mask_proposals = mask_proposals[:, -1, ...]
-        # the reference's two range asserts (zutis.py:385-386) as ONE reduction and ONE device -> host copy (each copy is a stream
-        # synchronisation: ~25 us of a 1.2-ms batch-1 predict, and there were thirteen of them)
-        lo_hi = torch.stack(torch.aminmax(mask_proposals)).cpu()
-        assert 0 <= float(lo_hi[0]) <= 1
-        assert 0 <= float(lo_hi[1]) <= 1
         size = None if size is None else (int(size[0]), int(size[1]))
+        # the reference's two range asserts (zutis.py:385-386): a flag the statistics kernel raises while it reads the proposals anyway,
+        # fetched with the NMS results (every device -> host copy is a stream synchronisation; the predict used to make four)
+        range_flag = torch.zeros((1,), dtype=torch.int32, device=mask_proposals.device)
         masks_dev, scores, category_ids = eng.instance_candidates(
-            mask_proposals, dict_outputs["patch_tokens"], self.text_embeddings, threshold, temperature, size)
+            mask_proposals, dict_outputs["patch_tokens"], self.text_embeddings, threshold, temperature, size, range_flag=range_flag)
         B, Q, Hm, Wm = masks_dev.shape
-        category_ids_dev = category_ids
         if image_ids is None:
             image_ids = [0 for _ in range(B)]
 
         # The reference pulls all B x Q x H x W boolean masks to the host, then loops (zutis.py:423-469).  Here the masks
         # stay on the GPU: IoU counts come from the popcount kernel, the greedy per-category NMS loop runs in one kernel
-        # launch (zh_mask_nms, one workgroup per image), and only the KEPT masks' run boundaries and boxes are copied back.
+        # launch (zh_mask_nms, one workgroup per image), the runs / boxes / areas of the KEPT masks are extracted from the loop's device
+        # outputs (zh_mask_runs_kept), and only those cross PCIe.
         if nms_type is None:
+            lo_hi = torch.stack(torch.aminmax(mask_proposals)).cpu()
+            assert 0 <= float(lo_hi[0]) <= 1
+            assert 0 <= float(lo_hi[1]) <= 1
             confidence_scores: np.ndarray = scores.cpu().numpy()
-            category_ids: np.ndarray = category_ids.cpu().numpy()
+            category_ids_h: np.ndarray = category_ids.cpu().numpy()
             kept = [(bi, int(c), q, float(s)) for bi in range(B)
-                    for q, (s, c) in enumerate(zip(confidence_scores[bi], category_ids[bi])) if c != 0]
+                    for q, (s, c) in enumerate(zip(confidence_scores[bi], category_ids_h[bi])) if c != 0]
+            sel = np.array([bi * Q + q for bi, _, q, _ in kept], dtype=np.int32)
+            rles, boxes, areas = eng.encode_masks(masks_dev.view(B * Q, Hm, Wm), sel)
         else:
             assert nms_type in ["hard", "linear", "gaussian"]
-            kept = eng.instance_nms(masks_dev, scores, category_ids_dev, nms_type)
-        sel = np.array([bi * Q + q for bi, _, q, _ in kept], dtype=np.int32)
-        rles, boxes, areas = eng.encode_masks(masks_dev.view(B * Q, Hm, Wm), sel)
+            kept, rles, boxes, areas, range_bad = eng.instance_nms_encode(masks_dev, scores, category_ids, nms_type, range_flag=range_flag)
+            assert not range_bad, "mask proposals outside [0, 1]"        # zutis.py:385-386
         predictions: List[dict] = list()
         for (bi, c, q, s), r, box, area in zip(kept, rles, boxes, areas):
             if area == 0:                               # `if m.sum() == 0: continue` (zutis.py:281,439)

@@ -273,9 +273,11 @@ class ZutisEngine(_EngineBase):
 
     # ------------------------------------------------------------------ predict (instance)
     def instance_candidates(self, mask_proposals_last: torch.Tensor, patch_tokens: torch.Tensor, text: torch.Tensor,
-                            threshold: float = 0.5, temperature: float = 5.0, size: Optional[Tuple[int, int]] = None):
+                            threshold: float = 0.5, temperature: float = 5.0, size: Optional[Tuple[int, int]] = None,
+                            range_flag: Optional[torch.Tensor] = None):
         """zutis.py:376-423 on device: binary masks, sizes, confidence, masked-mean tokens, class + score, and the
-        full-resolution thresholded masks.  Returns (masks u8 [B,Q,H,W], scores f32 [B,Q], category int64 [B,Q])."""
+        full-resolution thresholded masks.  Returns (masks u8 [B,Q,H,W], scores f32 [B,Q], category int64 [B,Q]).
+        range_flag (int32 [1], zeroed): bit 0 is set when a proposal lies outside [0, 1] (the asserts of zutis.py:385-386)."""
         self._pack()
         mp = mask_proposals_last.contiguous()
         B, Q, h, w = mp.shape
@@ -285,7 +287,7 @@ class ZutisEngine(_EngineBase):
         sizes = torch.empty((B * Q,), dtype=f32, device=dev)
         conf = torch.empty((B * Q,), dtype=f32, device=dev)
         binary = torch.empty((B, Q, h, w), dtype=torch.uint8, device=dev)
-        ops.instance_mask_stats(mp, Q * M, threshold, B, Q, M, sizes, conf, binary)
+        ops.instance_mask_stats(mp, Q * M, threshold, B, Q, M, sizes, conf, binary, range_flag)
         avg = torch.empty((B * Q, E), dtype=f32, device=dev)
         ops.masked_mean_tokens(pt, binary, sizes, avg, B, Q, M, E)
         cat = torch.empty((B, Q), dtype=torch.int64, device=dev)
@@ -342,6 +344,63 @@ class ZutisEngine(_EngineBase):
             rows.sort(key=lambda r: rank[r[1]])
             out += rows
         return out
+
+    def instance_nms_encode(self, masks_u8: torch.Tensor, scores: torch.Tensor, category_ids: torch.Tensor, nms_type: str = "hard",
+                            nms_threshold: float = 0.3, sigma: float = 0.5, threshold: float = 0.001,
+                            range_flag: Optional[torch.Tensor] = None, max_runs: int = 8192):
+        """instance_nms + encode_masks chained on the device (zutis.py:211-299,423-469): popcount IoU counts, the greedy per-category
+        loop, then the run extraction of the kept masks straight from the loop's device outputs (zh_mask_runs_kept) — the NMS result
+        does not visit the host in between.  ONE device -> host copy brings the kept triples, every query's category, the counts, the
+        range flag, the run counts and the boxes; a second one the run positions actually used.
+        Returns (kept [(batch index, category, query index, score)] in the reference's emission order, rles, boxes, areas, range_bad)."""
+        from . import rle
+        B, Q, H, W = masks_u8.shape
+        dev = masks_u8.device
+        inter = torch.empty((B, Q, Q), dtype=torch.int32, device=dev)
+        uni = torch.empty((B, Q, Q), dtype=torch.int32, device=dev)
+        m = masks_u8.contiguous()
+        for b in range(B):
+            ops.mask_iou_counts(m[b], Q, H * W, inter[b], uni[b])
+        n1, n2, n3 = B * (4 * Q + 2) * 8, B * Q * 2 * 4, B * Q * 5 * 4
+        small = torch.empty((n1 + n2 + n3,), dtype=torch.uint8, device=dev)
+        packed = small[:n1].view(torch.float64).view(B, 4 * Q + 2)
+        nr = small[n1:n1 + n2].view(torch.int32).view(B * Q, 2)
+        ba = small[n1 + n2:].view(torch.int32).view(B * Q, 5)
+        idx, _, _, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma, threshold,
+                                      packed=packed, range_flag=range_flag)
+        pos = torch.empty((B * Q, max_runs), dtype=torch.int32, device=dev)
+        ops.mask_runs_kept(m, idx, cnt, max_runs, pos, nr, ba)
+        host = small.cpu().numpy()                                   # the one synchronisation of the predict
+        pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)
+        nr_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 2)
+        ba_h = host[n1 + n2:].view(np.int32).reshape(B, Q, 5)
+        cnt_h = pk[:, 4 * Q].astype(np.int64)
+        range_bad = bool(pk[:, 4 * Q + 1].any())
+        mc = int(cnt_h.max()) if B else 0
+        kept, rles, boxes, areas = [], [], [], []
+        if mc > 0:
+            ntr = max(int(nr_h[b, :cnt_h[b], 0].max()) for b in range(B) if cnt_h[b] > 0)
+            keep = int(min(max_runs, max(1, ntr)))
+            pos_h = pos.view(B, Q, max_runs)[:, :mc, :keep].contiguous().cpu().numpy() if (B > 1 or mc < Q or keep < max_runs) else pos.view(B, Q, max_runs).cpu().numpy()
+            all_cat = pk[:, 3 * Q:4 * Q].astype(np.int64)
+            for b in range(B):
+                n = int(cnt_h[b])
+                if n == 0:
+                    continue
+                r = rle.rles_from_transitions(np.ascontiguousarray(pos_h[b, :n]), np.ascontiguousarray(nr_h[b, :n]), H, W)
+                # the kernel walks the categories in ascending id; the reference walks `set(category_ids_per_image)` (zutis.py:237-238):
+                # order the per-category groups by that very set (stable inside a category: the kernel's = the reference's selection order)
+                rank = {int(c): i for i, c in enumerate(set(all_cat[b]))}
+                order = sorted(range(n), key=lambda j: rank[int(pk[b, 2 * Q + j])])
+                for j in order:
+                    q = int(pk[b, j])
+                    if r[j] is None:                                 # pathological mask (> max_runs transitions): the host encoder
+                        r[j] = rle.encode(masks_u8[b, q].cpu().numpy())
+                    kept.append((b, int(pk[b, 2 * Q + j]), q, float(pk[b, Q + j])))
+                    rles.append(r[j])
+                    boxes.append([float(v) for v in ba_h[b, j, :4]])
+                    areas.append(int(ba_h[b, j, 4]))
+        return kept, rles, boxes, areas, range_bad
 
     def encode_masks(self, masks_u8: torch.Tensor, sel: np.ndarray, max_runs: int = 8192):
         """COCO RLE dicts, xyxy boxes and areas of the masks `sel` (flat indices into [n,H,W]) without moving the masks

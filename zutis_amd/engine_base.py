@@ -255,17 +255,67 @@ class _EngineBase:
         O = self._abuf("O16", (R, D), self._x3("out"))
         Hh = self._abuf("H16", (R, Fd), self._x3("proj"))
         q_, k_, v_ = QKV, QKV.view(QKV.hi[:, D:]), QKV.view(QKV.hi[:, 2 * D:])
+        # Few-row regime (batch-1 evaluation: configs/*.yaml val batch_size 1, trainer.py:328-345): the two N = D GEMMs of a block
+        # (out_proj, c_proj) are 60 tiles of 128 x 128 for 256 CUs, so their K is split over S workgroups per tile — a batched GEMM
+        # over K slabs writing fp32 partial planes — and the planes are summed by the LayerNorm that follows (zh_sum_layernorm_f32:
+        # bias + residual + ln_2 / the next block's ln_1 in the same pass).  Same launch count, 4x the workgroups, no LN launch of its own.
+        s_out, s_proj = self._splitk(R, D, D), self._splitk(R, D, Fd)
+        sk = self._x3("out") and self._x3("proj") and (s_out > 1 or s_proj > 1)
+        parts = self._buf("sk_parts", (max(s_out, s_proj), R, D), f32) if sk else None
+
+        def gemm_parts(site, A, Wt, S):
+            K = A.hi.shape[-1]
+            return self._gemm(site, A, Wt, parts, M=R, N=D, K=K // S, lda=K, ldw=K, ldc=D, batch=S, strideA=K // S, strideW=K // S, strideC=R * D)
+        # Self-attention with few (image, head, 128-query block) items — one image: 12 heads x 10 blocks on 256 CUs — splits the keys
+        # over workgroups as the decoder's cross-attention does (zh_attention_f16_splitk + merge): a function of B * heads and T only
+        eks, ews = 1, None
+        if not causal:
+            per_image = heads * -(-T // 128)
+            eks = max(1, min(8, 256 // per_image)) if B * per_image <= 128 else 1      # the split itself does not depend on B
+            ktiles = -(-T // (32 if xa else 64))
+            while eks > 1 and (eks - 1) * -(-ktiles // eks) >= ktiles:
+                eks -= 1
+            if eks > 1:
+                ews = self._buf("enc_attn_ws", (ops.attention_splitk_workspace_size(B, heads, T, D // heads, eks),), torch.uint8)
         for i in range(n_layers):
             pp = f"enc.{i}."
-            ops.layernorm(X, W_[pp + "ln1.w"], W_[pp + "ln1.b"], eps, R, D, out_f16=Y)
+            if not (sk and i > 0):                         # split-K regime: ln_1 of block i > 0 came out of block i - 1's last kernel
+                ops.layernorm(X, W_[pp + "ln1.w"], W_[pp + "ln1.b"], eps, R, D, out_f16=Y)
             self._gemm("qkv", Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
             ops.attention(q_, k_, v_, O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=D // heads,
                           ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
-                          strideO=T * D, causal=causal, x3=xa)
-            self._gemm("out", O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
-            ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y)
+                          strideO=T * D, causal=causal, x3=xa, ksplit=eks, workspace=ews)
+            if sk:
+                gemm_parts("out", O, W_[pp + "out_w"], s_out)
+                ops.sum_layernorm(parts, s_out, R, D, bias=W_[pp + "out_b"], residual=X, out_sum=X, gamma=W_[pp + "ln2.w"], beta=W_[pp + "ln2.b"],
+                                  eps=eps, out_f16=Y)
+            else:
+                self._gemm("out", O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
+                ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y)
             self._gemm("fc", Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
-            self._gemm("proj", Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
+            if sk:
+                gemm_parts("proj", Hh, W_[pp + "proj_w"], s_proj)
+                nx = f"enc.{i + 1}." if i + 1 < n_layers else None
+                ops.sum_layernorm(parts, s_proj, R, D, bias=W_[pp + "proj_b"], residual=X, out_sum=X,
+                                  gamma=W_[nx + "ln1.w"] if nx else None, beta=W_[nx + "ln1.b"] if nx else None, eps=eps, out_f16=Y if nx else None)
+            else:
+                self._gemm("proj", Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
+
+    # rows (B * T) up to which the N = D GEMMs of a transformer block run split-K; and the split as a function of the shape only
+    # (never of the data): results are bitwise reproducible for a given (rows, D, K)
+    SPLITK_MAX_ROWS = int(os.environ.get("ZH_SPLITK_MAX_ROWS", "2048"))
+
+    def _splitk(self, R: int, N: int, K: int) -> int:
+        """K split of an [R, N] = [R, K] x [N, K]^T GEMM whose partial planes a zh_sum_layernorm_f32 launch adds up.  A function of
+        K alone inside the few-row regime: image i's result does not depend on how many images share its batch there."""
+        if R > self.SPLITK_MAX_ROWS or K % 64:
+            return 1
+        s = 1
+        while 2 * s <= self.SPLITK_MAX and (K // (2 * s)) % 64 == 0 and K // (2 * s) >= 192:
+            s *= 2
+        return s
+
+    SPLITK_MAX = int(os.environ.get("ZH_SPLITK_MAX", "4"))
 
     def _decoder_kv(self, VIN16, KIN16, B, M, D, L, k_pos=None):
         """Cross-attention K / V of all L layers (transformer.py:281-284) from ONE GEMM each: [B*M, L*D] fp16 (split pairs
@@ -352,12 +402,15 @@ class _EngineBase:
             ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
             self._gemm("dec", tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
             self._gemm("dec", ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
-            ops.layernorm(t1, W_[pp + "norm3.w"], W_[pp + "norm3.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
-            if stack_all:                                                                   # :140-150, stacked [B,L,Q,D]
-                ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16,
-                              out_group_rows=Q, out_group_stride=L * Q, out_offset=l * Q)
+            # norm3 (:291) and, where the layer's output is kept, decoder.norm on top of it (:140-150; stacked [B,L,Q,D]) in ONE pass
+            n3 = dict(gamma=W_[pp + "norm3.w"], beta=W_[pp + "norm3.b"], eps=1e-5, out_f32=tgt, out_f16=tgt16)
+            if stack_all:
+                ops.sum_layernorm(t1, 1, R, D, **n3, gamma2=W_["dec.norm.w"], beta2=W_["dec.norm.b"], eps2=1e-5, out2_f16=inter16,
+                                  out2_group_rows=Q, out2_group_stride=L * Q, out2_offset=l * Q)
             elif l == L - 1:
-                ops.layernorm(tgt, W_["dec.norm.w"], W_["dec.norm.b"], 1e-5, R, D, out_f16=inter16, out_f32=out32)
+                ops.sum_layernorm(t1, 1, R, D, **n3, gamma2=W_["dec.norm.w"], beta2=W_["dec.norm.b"], eps2=1e-5, out2_f16=inter16, out2_f32=out32)
+            else:
+                ops.sum_layernorm(t1, 1, R, D, **n3)
         return inter16
 
     cross_ksplit = int(os.environ.get("ZH_CROSS_KSPLIT", "1"))      # class default (env = developer override); instances may set it

@@ -284,6 +284,24 @@ def layernorm(x, gamma, beta, eps, rows, D, *, out_f32=None, out_f16=None, out_f
                                   rows, D, lo_plane, _stream()), "zh_layernorm_f32")
 
 
+def sum_layernorm(parts, n_parts, rows, D, *, part_stride=None, bias=None, residual=None, out_sum=None, gamma=None, beta=None, eps=1e-5,
+                  out_f32=None, out_f16=None, out_group_rows=None, out_group_stride=None, out_offset=0, skip_first_in_group=False,
+                  gamma2=None, beta2=None, eps2=1e-5, out2_f32=None, out2_f16=None, out2_group_rows=None, out2_group_stride=None, out2_offset=0):
+    """x = sum of the n_parts fp32 planes of `parts` + bias + residual -> out_sum; LN(x) -> out_f32 / out_f16 (row-mapped); LN(LN(x)) with
+    gamma2 / beta2 -> out2_* (zh_sum_layernorm_f32).  n_parts = 1 with no bias / residual is a plain (or chained) LayerNorm."""
+    L = _lib.load()
+    part_stride = rows * D if part_stride is None else part_stride
+    ogr = rows if out_group_rows is None else out_group_rows
+    ogs = ogr if out_group_stride is None else out_group_stride
+    ogr2 = rows if out2_group_rows is None else out2_group_rows
+    ogs2 = ogr2 if out2_group_stride is None else out2_group_stride
+    (out_f16, lo1), (out2_f16, lo2) = _hp(out_f16), _hp(out2_f16)
+    _lib.check(L.zh_sum_layernorm_f32(_p(parts), n_parts, part_stride, _p(bias), _p(residual), _p(out_sum), _p(gamma), _p(beta), float(eps),
+                                      _p(out_f32), _p(out_f16), lo1, ogr, ogs, out_offset, int(skip_first_in_group),
+                                      _p(gamma2), _p(beta2), float(eps2), _p(out2_f32), _p(out2_f16), lo2, ogr2, ogs2, out2_offset,
+                                      rows, D, _stream()), "zh_sum_layernorm_f32")
+
+
 def assemble_tokens_ln(patch_emb, cls, pos, gamma, beta, eps, out, B, T, D):
     L = _lib.load()
     _lib.check(L.zh_assemble_tokens_ln(_p(patch_emb), _p(cls), _p(pos), _p(gamma), _p(beta), float(eps), _p(out),
@@ -383,10 +401,11 @@ def confusion_hist(label_true, label_pred, hist, n_class):
                "zh_confusion_hist")
 
 
-def instance_mask_stats(mask_proposals_last, stride_image, threshold, B, Q, M, sizes, conf, binary):
+def instance_mask_stats(mask_proposals_last, stride_image, threshold, B, Q, M, sizes, conf, binary, range_flag=None):
+    """range_flag: int32 [1] (zeroed by the caller): bit 0 set when a proposal lies outside [0, 1] (zutis.py:385-386)."""
     L = _lib.load()
     _lib.check(L.zh_instance_mask_stats(_p(mask_proposals_last), stride_image, float(threshold), B, Q, M, _p(sizes), _p(conf),
-                                        _p(binary), _stream()), "zh_instance_mask_stats")
+                                        _p(binary), _p(range_flag), _stream()), "zh_instance_mask_stats")
 
 
 def masked_mean_tokens(tokens, binary, sizes, avg, B, Q, M, E):
@@ -412,7 +431,8 @@ def mask_iou_counts(masks_u8, n, pixels, inter, uni):
 NMS_TYPES = {"hard": 0, "linear": 1, "gaussian": 2}
 
 
-def mask_nms(inter, uni, scores, category_ids, nms_type="hard", nms_threshold=0.3, sigma=0.5, score_threshold=0.001):
+def mask_nms(inter, uni, scores, category_ids, nms_type="hard", nms_threshold=0.3, sigma=0.5, score_threshold=0.001, packed=None,
+             range_flag=None):
     """Greedy per-category mask NMS on the device (zutis.py:211-299).  inter / uni int32 [B,Q,Q], scores f32 [B,Q], category_ids
     int64 [B,Q] -> (index int32 [B,Q], score f64 [B,Q], category int64 [B,Q], count int32 [B]); the first count[b] entries of
     row b are the kept queries in the reference's emission order."""
@@ -428,8 +448,19 @@ def mask_nms(inter, uni, scores, category_ids, nms_type="hard", nms_threshold=0.
     cat = torch.empty((B, Q), dtype=torch.int64, device=dev)
     cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     _lib.check(L.zh_mask_nms(_p(inter), _p(uni), _p(scores), _p(category_ids), B, Q, NMS_TYPES[nms_type], float(nms_threshold),
-                             float(sigma), float(score_threshold), _p(idx), _p(sc), _p(cat), _p(cnt), _stream()), "zh_mask_nms")
+                             float(sigma), float(score_threshold), _p(idx), _p(sc), _p(cat), _p(cnt), _p(packed), _p(range_flag), _stream()),
+               "zh_mask_nms")
     return idx, sc, cat, cnt
+
+
+def mask_runs_kept(masks_u8, kept_index, kept_count, max_runs, pos, nr, ba):
+    """masks u8 [B,Q,H,W]; kept_index int32 [B,Q] / kept_count int32 [B] = zh_mask_nms' device outputs -> pos int32 [B*Q,max_runs], nr
+    int32 [B*Q,2], ba int32 [B*Q,5] (row b*Q + j = image b's j-th kept mask; rows past the count are not written)."""
+    L = _lib.load()
+    _chk(masks_u8, torch.uint8, "mask_runs_kept masks"); _chk(kept_index, torch.int32, "kept_index"); _chk(kept_count, torch.int32, "kept_count")
+    B, Q, H, W = masks_u8.shape
+    _lib.check(L.zh_mask_runs_kept(_p(masks_u8), _p(kept_index), _p(kept_count), B, Q, H, W, max_runs, _p(pos), _p(nr), _p(ba), _stream()),
+               "zh_mask_runs_kept")
 
 
 # ---------------------------------------------------------------------------------------- bilateral solver (float64)
