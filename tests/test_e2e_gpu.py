@@ -400,17 +400,18 @@ def test_forward_graphed_shape_a_b_a_and_fork(dev):
     assert not torch.equal(eng.forward_graphed(xa)["patch_tokens"], ref_a["patch_tokens"])
 
 
-def test_batch_invariance_full_size(dev):
+@pytest.mark.parametrize("precision,t_mask,t_tok", [("exact", 2e-5, 2e-6), ("fast", 2e-3, 2e-4)])
+def test_batch_invariance_full_size(dev, precision, t_mask, t_tok):
     """Size-independent property at the BASELINE geometry (ViT-B/16 @336): images are independent, and every reduction runs over K /
     keys / one image in an order fixed by the shape, so image i's outputs are BITWISE the same at any position of a batch and in
     batches of different sizes that select the same kernels (here 3 and 4 images: what makes rank-sharded evaluation with equal
     shards reproduce the single-GPU result exactly).  Kernel selection has three thresholds — split-K of the N = D GEMMs up to 2048
     token rows, the key split of self-attention up to 128 (image, head, query block) items, the few-row GEMM kernel up to 128 rows
     (engine_base._splitk / _vit_blocks, gemm_skinny.h) — and across them (one image alone) the sums are re-associated: fp32-class
-    agreement, checked against the same tolerances as the oracle comparison."""
+    agreement at `exact` (measured 1e-7 tokens / 5e-7 masks), the precision's own rounding level at `fast`."""
     from zutis_amd import detgen
     cfg = detgen.VIT_B16
-    eng = _engine(cfg, dev)
+    eng = _engine(cfg, dev, precision)
     x = torch.from_numpy(detgen.images(4, 336, 336, seed=4)).to(dev)
     text = torch.from_numpy(detgen.text_embeddings(81, cfg.embed_dim)).to(dev)
     full = {k: v.clone() for k, v in eng.forward(x).items()}
@@ -426,12 +427,10 @@ def test_batch_invariance_full_size(dev):
     assert torch.equal(again["mask_proposals"], full["mask_proposals"]) and torch.equal(again["patch_tokens"], full["patch_tokens"])
     for i in (0, 3):                                                   # one image alone: other kernels, the same numbers to fp32 re-association
         one = eng.forward(x[i:i + 1].contiguous())
-        # two fp32-class evaluations of the same function: each is within 2e-4 (masks) / 2e-5 (unit-norm tokens) of the fp32 oracle
-        # (test_engine_matches_reference_golden), so they are within the sum of each other
-        assert float((one["mask_proposals"][0] - full["mask_proposals"][i]).abs().max()) < 4e-4
-        assert float((one["patch_tokens"][0] - full["patch_tokens"][i]).abs().max()) < 1e-5
+        assert float((one["mask_proposals"][0] - full["mask_proposals"][i]).abs().max()) < t_mask
+        assert float((one["patch_tokens"][0] - full["patch_tokens"][i]).abs().max()) < t_tok
         lab = eng.predict_semantic(one["patch_tokens"], text, (336, 336))[0]
-        assert float((lab != lab_full[i]).float().mean()) < 1e-3       # argmax flips only on fp32-level ties between two classes
+        assert float((lab != lab_full[i]).float().mean()) < (1e-4 if precision == "exact" else 2e-3)   # argmax flips only on near-ties between two classes
     pt = full["patch_tokens"]
     assert (pt.norm(dim=-1) - 1).abs().max().item() < 1e-5
     assert 0 <= full["mask_proposals"].min().item() and full["mask_proposals"].max().item() <= 1

@@ -204,7 +204,7 @@ def test_gemm_x3_row_periodic_table_before_rounding(dev, kind):
     assert float((got - ref).abs().max()) < tol, float((got - ref).abs().max())
 
 
-@pytest.mark.parametrize("tile", [64, 96, 192, 256, 512, 448, 3064, 32, 1284, 1288, 965, 9612, 1608])
+@pytest.mark.parametrize("tile", [64, 96, 192, 256, 512, 448, 3064, 32, 1288])
 def test_gemm_x3_every_tile_variant(dev, tile):
     """Every x3 tile (128x64, 192x128, 256x128 on the 3-slot ring; 256x256 on the two-slot ring with the SGPR-base LDS-DMA and
     the in-place A lo fragments), forced through zh_dev_set_gemm_overrides, over K = 64 .. 1024 (every prologue / steady / tail
@@ -499,7 +499,7 @@ def test_split_weight_packs_fp16_valued_weights_as_one_plane(dev):
         ops.gemm_x3(_split_act(_randn((64, 128), 1), dev), ops.Act(W16.to(f16).unsqueeze(0).contiguous()), torch.empty((64, 96), dtype=f32, device=dev))
 
 
-@pytest.mark.parametrize("tile", [0, 64, 96, 192, 256, 512, 448, 3064, 5122, 5124, 4484])
+@pytest.mark.parametrize("tile", [0, 64, 96, 192, 256, 512, 448, 3064, 5122, 5124, 4484, 1288, 32])
 def test_gemm_x2_is_bitwise_the_x3_kernel_on_fp16_valued_weights(dev, tile):
     """Every tile of the two-product kernel (incl. the three-slot big tiles and their two-slot A/B form) over every K phase,
     ragged M / N, bias + residual (f32 out), ReLU / QuickGELU split-pair out, fp16 out: bit-identical to the three-product
@@ -602,7 +602,7 @@ def test_gemm_x3_tail_peel_is_bitwise_one_launch(dev, x2):
     assert float((o_p.double() - ref).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K,batch", [(100, 768, 768, 1), (100, 2304, 768, 1), (100, 768, 2048, 1), (20, 384, 384, 1), (7, 8, 64, 1), (128, 260, 320, 3), (97, 36, 1024, 2)])
+@pytest.mark.parametrize("M,N,K,batch", [(100, 768, 768, 1), (100, 2304, 768, 1), (100, 768, 2048, 1), (20, 384, 384, 1), (7, 8, 64, 1), (128, 260, 320, 3), (97, 36, 1024, 2), (5, 30, 64, 1), (33, 1, 128, 1)])
 def test_gemm_x3_few_row_kernel(dev, M, N, K, batch):
     """The few-row kernel behind zh_gemm_f16x3 (M <= 128: operands straight into fragments, K split over the four waves of a block,
     gemm_skinny.h) on the decoder's batch-1 shapes and ragged ones: fp32-class against float64 for every output kind and epilogue
@@ -624,11 +624,12 @@ def test_gemm_x3_few_row_kernel(dev, M, N, K, batch):
     o2 = torch.empty_like(o32)
     ops.gemm_x3(A if batch > 1 else A.view(A.hi[0]), Wt, o2, bias=bias.to(dev), residual=res.to(dev), res_rows=25, **kw)
     assert torch.equal(o32, o2)
-    osp = Act.empty((batch, M, N), True, dev)
-    ops.gemm_x3(A if batch > 1 else A.view(A.hi[0]), Wt, osp if batch > 1 else osp.view(osp.hi[0]), bias=bias.to(dev), act=ops.ACT_RELU, **kw)
-    got = osp.t[0].float().cpu().double() + osp.t[1].float().cpu().double()
-    wr = torch.relu(ref + bias.double())
-    assert float(((got - wr).abs() / (bound + 1e-3 + wr.abs())).max()) < 2e-6
+    if (M * N) % 4 == 0:                                             # the C ABI wants the lo plane of a split output 8-byte aligned
+        osp = Act.empty((batch, M, N), True, dev)
+        ops.gemm_x3(A if batch > 1 else A.view(A.hi[0]), Wt, osp if batch > 1 else osp.view(osp.hi[0]), bias=bias.to(dev), act=ops.ACT_RELU, **kw)
+        got = osp.t[0].float().cpu().double() + osp.t[1].float().cpu().double()
+        wr = torch.relu(ref + bias.double())
+        assert float(((got - wr).abs() / (bound + 1e-3 + wr.abs())).max()) < 2e-6
     o16 = Act.empty((batch, M, N), False, dev)
     ops.gemm_x3(A if batch > 1 else A.view(A.hi[0]), Wt, o16 if batch > 1 else o16.view(o16.hi[0]), bias=bias.to(dev), act=ops.ACT_QUICKGELU, **kw)
     y = ref + bias.double()
@@ -708,7 +709,8 @@ def test_split_k_planes_plus_sum_layernorm_equals_gemm_plus_layernorm(dev):
     Y2 = Act.empty((R, D), True, dev)
     ops.sum_layernorm(parts, S, R, D, bias=bias.to(dev), residual=X2, out_sum=X2, gamma=g.to(dev), beta=b.to(dev), eps=1e-5, out_f16=Y2)
     ref = A32.double() @ W32.double().t() + bias.double() + X0.double()
-    assert float((X2.cpu().double() - ref).abs().max()) < 3e-6 and float((X1.cpu().double() - ref).abs().max()) < 3e-6
+    bound = float((A32.abs().double() @ W32.abs().double().t()).max())
+    assert float((X2.cpu().double() - ref).abs().max()) < 2e-6 * bound + 1e-6 and float((X1.cpu().double() - ref).abs().max()) < 2e-6 * bound + 1e-6
     yr = F.layer_norm(ref, (D,), g.double(), b.double(), 1e-5)
     for Y in (Y1, Y2):
         assert float(((Y.t[0].float() + Y.t[1].float()).cpu().double() - yr).abs().max()) < 5e-6

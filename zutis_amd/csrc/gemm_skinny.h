@@ -111,20 +111,35 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_x3_kernel(GemmArgs p, int 
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += red[w][t][lane];
     const int m = m0 + mt * 16 + frow, n = n0 + nt * 16 + fk * 4;
-    if (m >= p.M || n >= p.N) continue;                      // N % 4 == 0 (host): a lane's four columns are in or out together
+    if (m >= p.M || n >= p.N) continue;
     v *= p.out_scale;
-    if (p.bias) v += *(const f32x4*)(p.bias + n);
-    if (p.act != ZH_ACT_NONE) { v[0] = zh_act(v[0], p.act); v[1] = zh_act(v[1], p.act); v[2] = zh_act(v[2], p.act); v[3] = zh_act(v[3], p.act); }
-    if (R) v += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
     const long ci = cb + (long)m * p.ldc + n;
-    if (out_kind == 0) *(f32x4*)((float*)p.C + ci) = v;
-    else zh_store_h4((half_t*)p.C + ci, out_kind == 2 ? p.planeC : 0, v);
+    if (p.vec_ok) {                                          // N % 4 == 0 and 16-byte aligned rows: a lane's four columns are in or out together
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (p.act != ZH_ACT_NONE) { v[0] = zh_act(v[0], p.act); v[1] = zh_act(v[1], p.act); v[2] = zh_act(v[2], p.act); v[3] = zh_act(v[3], p.act); }
+      if (R) v += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
+      if (out_kind == 0) *(f32x4*)((float*)p.C + ci) = v;
+      else zh_store_h4((half_t*)p.C + ci, out_kind == 2 ? p.planeC : 0, v);
+    } else {                                                 // ragged N / unaligned rows: element by element
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) break;
+        float x = v[e];
+        if (p.bias) x += p.bias[n + e];
+        x = zh_act(x, p.act);
+        if (R) x += R[(long)(m % p.res_rows) * p.ldr + n + e];
+        if (out_kind == 0) ((float*)p.C)[ci + e] = x;
+        else zh_store_h1((half_t*)p.C + ci + e, out_kind == 2 ? p.planeC : 0, x);
+      }
+    }
   }
 }
 
-// Host side: is this GEMM one for the few-row kernel?  (vec_ok: N % 4 == 0 and 16-byte aligned rows of C / bias / residual.)
+// Host side: is this GEMM one for the few-row kernel?  Shape only (never alignment): the K order of a row's sum — and with it the bits of
+// the result — must not depend on how many columns a caller asks for (sharded retrieval merges shards of any width).
 static inline bool gemm_skinny_ok(const GemmArgs& p, int batch, bool vec_ok, int max_rows) {
-  return vec_ok && !p.pos_y && p.M <= max_rows && (long)zh_cdiv(p.N, 32) * zh_cdiv(p.M, 32) * batch <= 65535L * 8;
+  (void)vec_ok;                                              // the epilogue has an element-wise form: every few-row GEMM takes this kernel
+  return !p.pos_y && p.M <= max_rows && (long)zh_cdiv(p.N, 32) * zh_cdiv(p.M, 32) * batch <= 65535L * 8;
 }
 
 template <int SPW>

@@ -146,7 +146,12 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   if (pick == 64 && (long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch <= 256) pick = 3064;
   const int forced = gemm_dev_overrides().tile;
   if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448 || forced == 3064) pick = forced;
-  if (forced == 1284 || forced == 1288 || forced == 965 || forced == 9612 || forced == 1608) pick = forced;   // round-4 candidates for M ~ 1200 rows
+  // M ~ 1200 rows (one image at native resolution: c_fc 1201 x 3072, the split-K planes of c_proj / out_proj): 128 x 64 tiles are 480
+  // workgroups, two per CU, each staging its own A panel; 128 x 128 tiles (8 waves of 32 x 64, 4 slots) are 240, ONE round with a third
+  // fewer staged bytes: c_fc 29.4 -> 24.6 us, c_proj planes (S = 4) 28.8 -> 24.8, out_proj planes 12.2 -> 11.0 (round 4, same box;
+  // 128 x 96 on 5 slots, 96 x 128, 160 x 128 and 4-wave 128 x 128 were timed with it and dropped: within 3 % or slower)
+  if (pick == 64 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch <= 256 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch > 256) pick = 1288;
+  if (forced == 1288) pick = forced;
   if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
   if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124 || pick == 4484) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
@@ -191,6 +196,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
     else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 4, 2, 2>(p, batch, out_kind, stream);   // 4 slots: the epilogue slabs need 102 KiB
     else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 1288) ok = launch_x3<4, 2, 2, 4, 4, 2, 2>(p, batch, out_kind, stream);
     else ok = launch_x3<2, 2, 4, 2, 3, 2, 2>(p, batch, out_kind, stream);
   } else
   if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
@@ -201,11 +207,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2>(p, batch, out_kind, stream);   // 8 waves of 32 x 48
   else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2>(p, batch, out_kind, stream);   // 64 x 64, deep ring
-  else if (pick == 1284) ok = launch_x3<2, 2, 4, 4, 4, 2>(p, batch, out_kind, stream);   // 128 x 128, 4 waves of 64 x 64, 4 slots
   else if (pick == 1288) ok = launch_x3<4, 2, 2, 4, 4, 2>(p, batch, out_kind, stream);   // 128 x 128, 8 waves of 32 x 64, 4 slots
-  else if (pick == 965) ok = launch_x3<4, 2, 2, 3, 5, 2>(p, batch, out_kind, stream);    // 128 x 96, 5 slots
-  else if (pick == 9612) ok = launch_x3<2, 2, 3, 4, 5, 2>(p, batch, out_kind, stream);   // 96 x 128, 5 slots
-  else if (pick == 1608) ok = launch_x3<2, 4, 5, 2, 4, 2>(p, batch, out_kind, stream);   // 160 x 128 (8 waves of 80 x 32), 4 slots
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16x3");
