@@ -332,6 +332,83 @@ def bench_c5(args):
             "embedding_norm": round(float(emb.norm(dim=1).mean().item()), 6)}), flush=True)
 
 
+def c3_model(dev, precision):
+    """The config-3 fixture as the drop-in module: weights / text rows / threshold of tests/golden/c3_vitb16.npz (generated from the
+    reference: 100 candidates, 9 categories, 17 hard-NMS survivors at 480x640), one 480x640 image.  Returns (net, x, golden, thr, H, W)."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    dp = os.path.join(root, "zutis_amd", "dropin")
+    if dp not in sys.path:
+        sys.path.insert(0, dp)
+    from zutis_amd import detgen
+    from networks.zutis import ZUTIS
+    cfg = detgen.VIT_B16
+    g = np.load(os.path.join(root, "tests", "golden", "c3_vitb16.npz"))
+    H, W, thr = 480, 640, detgen.C3_THRESHOLD
+    with contextlib.redirect_stdout(sys.stderr):      # the constructor prints "clip is loaded." like the reference's (zutis.py:105): keep stdout to the one JSON line
+        net = ZUTIS(categories=[f"c{i}" for i in range(81)], clip_arch="ViT-B/16", device=dev, text_embeddings=torch.from_numpy(g["text"]))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.c3_state_dict(cfg).items()}, strict=True)
+    net = net.to(dev).eval().requires_grad_(False)
+    net.precision = precision
+    x = torch.from_numpy(detgen.images(1, H, W, seed=21)).to(dev)
+    return net, x, g, thr, H, W
+
+
+def c3_parity(preds, g, tag):
+    """The step's predictions against the reference's own for this image (fixture generated by oracle/gen_golden.py from /root/reference)."""
+    from zutis_amd import rle
+    ref_cat, ref_score, ref_area = g[f"{tag}_cat"], g[f"{tag}_score"], g[f"{tag}_area"]
+    cats = [p["category_id"] for p in preds]
+    areas = [int(rle.decode(p["segmentation"]).sum()) for p in preds]
+    same_list = cats == list(ref_cat)
+    return {"predictions": len(preds), "reference_predictions": int(len(ref_cat)), "category_list_identical": bool(same_list),
+            "score_max_abs_err": (float(np.abs(np.array([p["score"] for p in preds]) - ref_score).max()) if same_list else None),
+            "mask_area_max_abs_diff_sorted_per_category": (int(max(abs(a - b) for c in set(cats) for a, b in zip(
+                sorted(a for a, cc in zip(areas, cats) if cc == c), sorted(int(a) for a, cc in zip(ref_area, ref_cat) if cc == c)))) if same_list else None),
+            "against": "tests/golden/c3_vitb16.npz: the reference's ZUTIS.forward + predict(instance, hard NMS) on the same image and weights "
+                       "(tests/test_configs_gpu.py::test_c3_native_resolution_instance_predict holds scores to 5e-4, areas to 8 px)"}
+
+
+def batch1_object(precision, dev, steps=40):
+    """What every unchanged caller of the reference runs — one image per call at its native resolution (configs/*.yaml val batch_size 1;
+    trainer.py:328-345 and coco20k_eval.py:258-267: forward, then predict per image) — through the drop-in module, bounded to a fraction
+    of a second: ms per image of forward + instance predict (hard NMS, RLE dicts), of the forward alone and of the semantic predict,
+    launches per image, parity with the reference's predictions for this image."""
+    from zutis_amd import _lib
+    net, x, g, thr, H, W = c3_model(dev, precision)
+    inst = lambda o: net.predict(o, mask_type="instance", threshold=thr, size=(H, W), image_ids=[7], nms_type="hard")
+
+    def timed(fn, n):
+        for _ in range(3):
+            r = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, r
+    ms_step, preds = timed(lambda: inst(net(x)), steps)
+    ms_fwd, out = timed(lambda: net(x), steps)
+    ms_sem, _ = timed(lambda: net.predict(out, mask_type="semantic", size=(H, W)), steps)
+    graph = bool(net.use_hip_graph)
+    counts = {}
+    net.use_hip_graph = False                      # count the C-ABI launches of one eager forward / predict (a graph replays the same ones)
+    _lib.COUNTER = counts
+    try:
+        o = net(x)
+        n_fwd = sum(counts.values())
+        inst(o)
+        n_all = sum(counts.values())
+    finally:
+        _lib.COUNTER = None
+        net.use_hip_graph = graph
+    return {"what": "ONE 480x640 image per call through the drop-in networks.zutis.ZUTIS (the reference's evaluation regime: val batch_size 1, "
+                    "trainer.py:328-345, coco20k_eval.py:258-267): forward + predict(instance, hard NMS) to COCO RLE dicts",
+            "ms_per_image": round(ms_step, 3), "images_per_s": round(1e3 / ms_step, 1), "forward_ms": round(ms_fwd, 3),
+            "instance_predict_ms": round(ms_step - ms_fwd, 3), "semantic_predict_ms": round(ms_sem, 3), "steps": steps,
+            "hip_graph_replay": graph, "precision": precision, "library_launches_forward": n_fwd, "library_launches_instance_predict": n_all - n_fwd,
+            "parity": c3_parity(preds, g, f"{H}x{W}")}
+
+
 def bench_c3(args):
     """Config 3: COCO-20K-style instance segmentation at its own shape and batch — coco20k_eval.py:241-268 evaluates image
     by image — through the drop-in `networks.zutis.ZUTIS`: a step = ONE 480x640 image, forward + predict(mask_type="instance",
@@ -347,23 +424,10 @@ def bench_c3(args):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-    import numpy as np
-    root = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, os.path.join(root, "zutis_amd", "dropin"))
     from zutis_amd import detgen, ops, rle
-    from networks.zutis import ZUTIS
     cfg = detgen.VIT_B16
-    g = np.load(os.path.join(root, "tests", "golden", "c3_vitb16.npz"))
-    H, W, thr = 480, 640, detgen.C3_THRESHOLD
+    net, x, g, thr, H, W = c3_model(dev, args.precision)
     tag = f"{H}x{W}"
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):      # the constructor prints "clip is loaded." like the reference's (zutis.py:105): keep stdout to the one JSON line
-        net = ZUTIS(categories=[f"c{i}" for i in range(81)], clip_arch="ViT-B/16", device=dev, text_embeddings=torch.from_numpy(g["text"]))
-    sd = {k: torch.from_numpy(v) for k, v in detgen.c3_state_dict(cfg).items()}
-    net.load_state_dict(sd, strict=True)
-    net = net.to(dev).eval().requires_grad_(False)
-    net.precision = args.precision
-    x = torch.from_numpy(detgen.images(1, H, W, seed=21)).to(dev)
 
     def step():
         out = net(x)
@@ -386,18 +450,14 @@ def bench_c3(args):
         elapsed = float(t.item())
     roof = cpu = parity = solver = None
     if rank == 0:
-        roof = gemm_roofline(ops, step, elapsed / args.steps)
-        # parity with the reference's own predictions for this image (fixture generated by oracle/gen_golden.py from /root/reference)
-        ref_cat, ref_score, ref_area = g[f"{tag}_cat"], g[f"{tag}_score"], g[f"{tag}_area"]
-        cats = [p["category_id"] for p in preds]
-        areas = [int(rle.decode(p["segmentation"]).sum()) for p in preds]
-        same_list = cats == list(ref_cat)
-        parity = {"predictions": len(preds), "reference_predictions": int(len(ref_cat)), "category_list_identical": bool(same_list),
-                  "score_max_abs_err": (float(np.abs(np.array([p["score"] for p in preds]) - ref_score).max()) if same_list else None),
-                  "mask_area_max_abs_diff_sorted_per_category": (int(max(abs(a - b) for c in set(cats) for a, b in zip(
-                      sorted(a for a, cc in zip(areas, cats) if cc == c), sorted(int(a) for a, cc in zip(ref_area, ref_cat) if cc == c)))) if same_list else None),
-                  "against": "tests/golden/c3_vitb16.npz: the reference's ZUTIS.forward + predict(instance, hard NMS) on the same image and weights "
-                             "(tests/test_configs_gpu.py::test_c3_native_resolution_instance_predict holds scores to 5e-4, areas to 8 px)"}
+        graph = net.use_hip_graph
+        net.use_hip_graph = False                  # the per-launch events need the eager launches (a graph replay bypasses ops.PROFILER)
+        try:
+            roof = gemm_roofline(ops, step, elapsed / args.steps)
+        finally:
+            net.use_hip_graph = graph
+        roof["measured_on"] += "; the timed steps replay the forward from a hipGraph (drop-in default for batches <= 4)" if graph else ""
+        parity = c3_parity(preds, g, tag)
     if rank == 0 and world == 1:
         # ---- bilateral solver at the pseudo-label size: one image per call and 8 per call (zh_bilateral_solve_batch)
         Hs, Ws = 512, 683
@@ -525,6 +585,7 @@ def main():
     ap.add_argument("--d2h", action="store_true", help="developer: every step ends with its int64 label maps copied to pinned host memory on the "
                     "step's stream (the reference's predict ends in .cpu().numpy(), networks/zutis.py:372)")
     ap.add_argument("--no-io-rates", action="store_true", help="skip the short extra runs that report the PCIe-inclusive rates (N = 1)")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the bounded batch-1 object (one 480x640 image per call through the drop-in module)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--torch-gpu-baseline", action="store_true", default=True,
@@ -775,6 +836,11 @@ def main():
                              "dispatches, explicit softmax attention in the decoder / F.interpolate / einsum) in stock PyTorch-ROCm fp32 eager "
                              "on the same MI355X, batch %d, 5 timed passes after 2 warm-ups per leg" % B}
 
+    batch1 = None
+    if rank == 0 and world == 1 and not args.no_batch1:
+        for e in engines.values():                    # the headline's engines are done: free their buffers first
+            e._bufs.clear()
+        batch1 = batch1_object(args.precision, dev)
     if rank == 0:
         total_images = world * B * args.steps
         line = {
@@ -797,6 +863,7 @@ def main():
             "model_tflops_note": "images/s x the REFERENCE model's 124.5 GFLOP per image (SURVEY 8d; MFU convention) per GPU — not executed flops: "
                                  "the engine executes fewer (roofline.executed_algorithmic_flops_per_step, DESIGN 2a)",
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            **({"batch1": batch1} if batch1 else {}),
             **({"torch_gpu_baseline": torch_gpu} if torch_gpu else {}),
             **({"io_inclusive": io_rates} if io_rates else {}),
         }

@@ -73,18 +73,18 @@ def ops_act(x, act):
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     T = 1201
-    ENC_TILES = (0, 64, 96, 3064, 1288, 192, 256)
+    ENC_TILES = (0, 96, 3064, 1288, 6496)
     if which in ("enc", "all"):
         bench(T, 2304, 768, "qkv", ENC_TILES)
         bench(T, 3072, 768, "fc", ENC_TILES, act=ops.ACT_QUICKGELU)
         bench(T, 768, 768, "out", ENC_TILES, out="f32", resid=True)
         bench(T, 768, 3072, "proj", ENC_TILES, out="f32", resid=True)
-        bench(T, 768, 768, "out/S", (0, 96, 3064, 1288), splits=(2, 3, 4), out="f32")
-        bench(T, 768, 3072, "proj/S", (0, 96, 1288), splits=(2, 3, 4, 6, 8), out="f32")
-        bench(442, 2304, 768, "qkv336", (0, 64, 3064, 1288, 32))
-        bench(442, 3072, 768, "fc336", (0, 64, 3064, 1288, 32), act=ops.ACT_QUICKGELU)
-        bench(442, 768, 3072, "proj336", (0, 3064, 32), out="f32", resid=True)
-        bench(442, 768, 3072, "proj336/S", (0, 3064, 1288), splits=(2, 4, 8), out="f32")
+        bench(T, 768, 768, "out/S", (0, 1288), splits=(2, 4), out="f32")
+        bench(T, 768, 3072, "proj/S", (0, 1288, 6496), splits=(2, 3, 4, 6), out="f32")
+        bench(442, 2304, 768, "qkv336", (0, 3064, 6496))
+        bench(442, 3072, 768, "fc336", (0, 3064, 6496), act=ops.ACT_QUICKGELU)
+        bench(442, 768, 3072, "proj336", (0, 3064), out="f32", resid=True)
+        bench(442, 768, 3072, "proj336/S", (0, 3064), splits=(2, 4, 8), out="f32")
     if which == "abl":        # K-loop ablations (ZUTIS_HIP_LIB = a -DZH_X3_NO* variant library): timing only, results are garbage
         bench(T, 2304, 768, "qkv", (96, 1288, 64, 3064))
         bench(T, 3072, 768, "fc", (64, 1288, 3064), act=ops.ACT_QUICKGELU)

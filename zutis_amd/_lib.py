@@ -84,6 +84,26 @@ _SIGS = {
 }
 
 
+COUNTER = None    # a dict while launches are being counted (bench.py: kernels per image): entry-point name -> calls
+
+
+class _CountingProxy:
+    """Forwards every call and counts the plannable (= launching) entry points."""
+
+    def __init__(self, lib, counts):
+        self._lib, self._counts = lib, counts
+
+    def __getattr__(self, name):
+        from . import plan
+        fn = getattr(self._lib, name)
+        if name in plan.op_table():
+            def _count(*args):
+                self._counts[name] = self._counts.get(name, 0) + 1
+                return fn(*args)
+            return _count
+        return fn
+
+
 class _RecordingProxy:
     """Stands in for the CDLL while a plan is recorded: plannable entry points are logged, everything else passes through."""
 
@@ -114,7 +134,11 @@ def load(raw: bool = False):
     """Load the shared library (building nothing: run `python -m zutis_amd.build` / __graft_entry__.build())."""
     global _lib
     if _lib is not None:
-        return _RecordingProxy(_lib, RECORDER) if (RECORDER is not None and not raw) else _lib
+        if RECORDER is not None and not raw:
+            return _RecordingProxy(_lib, RECORDER)
+        if COUNTER is not None and not raw:
+            return _CountingProxy(_lib, COUNTER)
+        return _lib
     if not os.path.exists(LIB_PATH):
         raise ZutisHipError(
             f"{LIB_PATH} is missing: the HIP extension is REQUIRED (no CPU fallback). "

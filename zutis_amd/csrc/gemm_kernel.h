@@ -106,15 +106,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   constexpr int NPLW = SPLIT == 1 ? 2 : 1;  // planes of W (SPLIT = 2: W is exactly its hi plane)
   constexpr int OUT_F16 = OUT == 1;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int ROWS = NPL * BM + NPLW * BN;   // LDS rows per stage (A planes then W planes), 64 B each
-  constexpr int PIECES = ROWS / 16;         // 1-KiB DMA pieces per stage
+  // K64 (round 4): split-pair tiles below the big ones on TWO slots stage slices of 64 k (128-B row pieces = whole cache lines) instead
+  // of 32: a CU's LDS-DMA stream moves 85 GB/s in 128-B pieces against 52 - 57 in 64-B pieces whatever the ring depth or the number of
+  // issuing waves (tools/micro/dma_stream.hip, the batch-1 QKV pattern), and with one image's ~1200 token rows the K loop IS that
+  // stream (ablations: profiles/NOTES.md round 4).
+  constexpr bool K64 = SPLIT && STAGES == 2 && BM * BN < 192 * 256;
+  constexpr int KB = K64 ? 64 : BK;         // k per staged slice
+  constexpr int RPP = 512 / KB;             // rows per 1-KiB DMA piece (16 at 64-B rows, 8 at 128-B rows)
+  constexpr int LPR = 64 / RPP;             // lanes (16-byte chunks) per row
+  constexpr int ROWS = NPL * BM + NPLW * BN;   // LDS rows per stage (A planes then W planes), 2 * KB bytes each
+  constexpr int PIECES = ROWS / RPP;        // 1-KiB DMA pieces per stage
   constexpr int NP = (PIECES + NW - 1) / NW;  // DMA issues per wave per stage (duplicates pad uneven splits)
   static_assert(NP >= 2 && NP <= 8 && STAGES >= (SPLIT ? 2 : 3) && STAGES <= 8, "unsupported pieces-per-wave count / ring depth");
   // Prefetch distance: slice kt+STAGES-1 goes into the slot whose fragments were consumed before the current barrier.
   constexpr int DIST = STAGES - 1;
   constexpr int AHEAD = SPLIT ? 1 : DIST - 2; // whole stages that may still be in flight at a steady-state barrier
   static_assert(AHEAD >= 1 && AHEAD * NP < 64, "ring too shallow / vmcnt overflow");
-  constexpr int STAGE_HALVES = ROWS * BK;
+  constexpr int STAGE_HALVES = ROWS * KB;
   __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE_HALVES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -155,10 +163,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   for (int i = 0; i < NP; ++i) {
     int pc = wave + i * NW;
     pc = pc < PIECES ? pc : PIECES - 1;
-    lds_piece[i] = pc * 16 * BK;
-    const int R0 = pc * 16;                       // uniform
-    const int rl = lane >> 2;
-    const int c = (lane & 3) ^ ((-(rl >> 2)) & 3);    // (R0 + rl) >> 2 == R0/4 + (rl >> 2), R0/4 % 4 == 0
+    lds_piece[i] = pc * RPP * KB;
+    const int R0 = pc * RPP;                      // uniform
+    const int rl = lane / LPR;
+    // 64-B rows: chunk ^ (-(row >> 2) & 3), (R0 + rl) >> 2 == R0/4 + (rl >> 2), R0/4 % 4 == 0.  128-B rows (K64): chunk ^ ((row >> 1) & 7)
+    // — with it the sixteen lanes ds_read_b128 services together (rows 0-3, 12-15 of one k-chunk and 4-11 of its neighbour) fall into
+    // sixteen different 16-byte bank groups: even rows take 0-7, odd rows 8-15, and (c ^ s) is a bijection over the eight rows of a parity
+    const int c = K64 ? ((lane & 7) ^ (((R0 + rl) >> 1) & 7)) : ((lane & 3) ^ ((-(rl >> 2)) & 3));
     if (R0 < NPL * BM) {
       const int pl = SPLIT ? (R0 >= BM) : 0;
       int row = m0 + (R0 - pl * BM) + rl;
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase[i] + goff[i]), (lds_ptr_t)(sb + lds_piece[i]), 16, 0, 0);
-      gbase[i] += BK;
+      gbase[i] += KB;
     }
   };
 
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;                    // even: K % 64 == 0
+  const int nk = p.K / KB;                    // K % 64 == 0: even at 32-k slices, any count >= 1 at 64
   const int frow = lane & 15, fk = lane >> 4;
   // ---- pos tables: accumulators start from pos_y[y] + pos_x[x] (N % 4 == 0 checked on the host).  SPLIT: the accumulator is
   // scaled by out_scale = 2^-s afterwards — start from the table value times 2^s (exact).
@@ -310,13 +321,53 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       else pos_direct_t(float{});
     }
   };
-  const int foff = frow * BK + ((fk ^ ((-(frow >> 2)) & 3)) * 8);   // per-lane offset inside a 16-row subtile
-  const half_t* rdA = smem + (wr * TM * 16) * BK + foff;
-  const half_t* rdW = smem + (NPL * BM + wc * TN * 16) * BK + foff;
+  const int foff = K64 ? frow * KB : frow * BK + ((fk ^ ((-(frow >> 2)) & 3)) * 8);   // per-lane offset inside a 16-row subtile (K64: + the k-step's chunk)
+  const half_t* rdA = smem + (wr * TM * 16) * KB + foff;
+  const half_t* rdW = smem + (NPL * BM + wc * TN * 16) * KB + foff;
 
   constexpr bool BIGT = SPLIT && BM * BN >= 192 * 256;    // the two-slot (SPLIT = 2: three-slot) big tiles
-  static_assert(!SPLIT || BIGT == (STAGES == 2 || (SPLIT == 2 && STAGES == 3 && BM * BN >= 192 * 256)), "big split-pair tiles: 2 slots (x2: 2 or 3)");
-  if constexpr (BIGT) {
+  static_assert(!SPLIT || K64 || BIGT == (STAGES == 2 || (SPLIT == 2 && STAGES == 3 && BM * BN >= 192 * 256)), "big split-pair tiles: 2 slots (x2: 2 or 3)");
+  if constexpr (K64) {
+    // ---- f16x3 loop on 64-k slices, two slots: barrier (slice kt landed everywhere, every read of the other slot has returned) ->
+    // fragments of both k-steps -> DMA of slice kt + 1 into the other slot -> 2 x three sweeps.  One slice of prefetch: a slice carries
+    // 6 TM TN MFMAs per wave, as long as the DMA stream needs to land the next one at its 128-B-piece rate.
+    pos_before_prologue();
+    issue_stage(0);
+    pos_after_prologue();
+    ZH_PROBE(1);
+    const int sz = (frow >> 1) & 7;
+    half8_t fa[2][2 * TM], fw[2][NPLW * TN];
+    for (int kt = 0; kt < nk; ++kt) {
+      const int slot = kt & 1;
+      const int so = slot * STAGE_HALVES;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ko = (((j << 2) | fk) ^ sz) * 8;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int t = 0; t < TM; ++t) fa[j][pl * TM + t] = *(const half8_t*)(rdA + so + (pl * BM + t * 16) * KB + ko);
+          if (pl < NPLW) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) fw[j][pl * TN + t] = *(const half8_t*)(rdW + so + (pl * BN + t * 16) * KB + ko);
+          }
+        }
+      }
+      if (kt + 1 < nk) issue_stage(slot ^ 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int sw = 0; sw < 3; ++sw) {
+          if (SPLIT == 2 && sw == 1) continue;           // W has no lo plane
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][(sw == 1 ? TN : 0) + nt], fa[j][(sw == 2 ? TM : 0) + mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+  } else if constexpr (BIGT) {
     // ---- f16x3 loop, big tile (256 x 256, 8 waves of 128 x 64), TWO 64-KiB slots.  Ablations of the 3-slot 256 x 128 loop
     // (tools/gemm_x3_probe.sh, round 3; QKV shape, model-shaped operands): all 160 us; MFMAs removed 116 us; operand
     // movement removed (no DMA, no fragment reads) 119 us — the LDS-DMA stream (48 KiB per slice and CU, at its request-rate

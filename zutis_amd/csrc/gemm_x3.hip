@@ -151,7 +151,10 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // fewer staged bytes: c_fc 29.4 -> 24.6 us, c_proj planes (S = 4) 28.8 -> 24.8, out_proj planes 12.2 -> 11.0 (round 4, same box;
   // 128 x 96 on 5 slots, 96 x 128, 160 x 128 and 4-wave 128 x 128 were timed with it and dropped: within 3 % or slower)
   if (pick == 64 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch <= 256 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch > 256) pick = 1288;
-  if (forced == 1288) pick = forced;
+  // the wide few-row GEMM (QKV at one image: 1201 x 2304 = 240 tiles of 128 x 96): the same tile on 64-k slices (128-B row pieces, two
+  // slots; gemm_kernel.h K64) 23.5 -> 21.9 us; 128 x 128 and 64 x 64 on 64-k slices tied with their 32-k forms and were dropped
+  if (pick == 96 && !pos_y && (long)zh_cdiv(M, 128) * (N / 96) * batch <= 256) pick = 6496;
+  if (forced == 1288 || forced == 6496) pick = forced;
   if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
   if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124 || pick == 4484) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
@@ -197,6 +200,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
     else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 1288) ok = launch_x3<4, 2, 2, 4, 4, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 6496) ok = launch_x3<4, 2, 2, 3, 2, 2, 2>(p, batch, out_kind, stream);
     else ok = launch_x3<2, 2, 4, 2, 3, 2, 2>(p, batch, out_kind, stream);
   } else
   if (!p.vec_ok) ok = launch_x3<2, 2, 4, 2, 3, 0>(p, batch, out_kind, stream);
@@ -208,6 +212,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2>(p, batch, out_kind, stream);   // 8 waves of 32 x 48
   else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2>(p, batch, out_kind, stream);   // 64 x 64, deep ring
   else if (pick == 1288) ok = launch_x3<4, 2, 2, 4, 4, 2>(p, batch, out_kind, stream);   // 128 x 128, 8 waves of 32 x 64, 4 slots
+  else if (pick == 6496) ok = launch_x3<4, 2, 2, 3, 2, 2>(p, batch, out_kind, stream);   // K64 (64-k slices, two slots): 128 x 96, 8 waves of 32 x 48
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16x3");

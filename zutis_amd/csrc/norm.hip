@@ -107,29 +107,65 @@ struct SumLnArgs {
   int rows, D;
 };
 
+// NPARTS > 0: the plane count as a template parameter — every plane's loads (and the bias / residual ones) are requested before the first add
+// (a run-time plane loop issues one plane, waits, adds: four dependent latencies for c_proj's four planes, 10.4 us for 1201 rows where the
+// plain LayerNorm takes 5.4); the additions keep plane order.  NPARTS = 0: any count, the loop.
+template <int NPARTS>
 __global__ __launch_bounds__(256) void sum_layernorm_kernel(SumLnArgs p) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= p.rows) return;
   const int nv = p.D >> 2;
   LnRow row;
-  const f32x4* p0 = (const f32x4*)(p.parts + r * p.D);
+  if constexpr (NPARTS > 0) {
+    f32x4 pv[NPARTS][LN_MAXV], bv[LN_MAXV], rv[LN_MAXV];
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j)
-    if (lane + 64 * j < nv) row.v[j] = p0[lane + 64 * j];
-  for (int s = 1; s < p.n_parts; ++s) {
-    const f32x4* ps = (const f32x4*)(p.parts + (long)s * p.part_stride + r * p.D);
+    for (int s = 0; s < NPARTS; ++s) {
+      const f32x4* ps = (const f32x4*)(p.parts + (long)s * p.part_stride + r * p.D);
+#pragma unroll
+      for (int j = 0; j < LN_MAXV; ++j)
+        if (lane + 64 * j < nv) pv[s][j] = ps[lane + 64 * j];
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nv) {
+        bv[j] = p.bias ? ((const f32x4*)p.bias)[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        rv[j] = p.residual ? ((const f32x4*)(p.residual + r * p.D))[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nv) {
+        f32x4 x = pv[0][j];
+#pragma unroll
+        for (int s = 1; s < NPARTS; ++s) x += pv[s][j];
+        if (p.bias) x += bv[j];
+        if (p.residual) x += rv[j];
+        row.v[j] = x;
+        if (p.out_sum) ((f32x4*)(p.out_sum + r * p.D))[c] = x;
+      }
+    }
+  } else {
+    const f32x4* p0 = (const f32x4*)(p.parts + r * p.D);
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j)
-      if (lane + 64 * j < nv) row.v[j] += ps[lane + 64 * j];
-  }
+      if (lane + 64 * j < nv) row.v[j] = p0[lane + 64 * j];
+    for (int s = 1; s < p.n_parts; ++s) {
+      const f32x4* ps = (const f32x4*)(p.parts + (long)s * p.part_stride + r * p.D);
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    const int c = lane + 64 * j;
-    if (c < nv) {
-      if (p.bias) row.v[j] += ((const f32x4*)p.bias)[c];
-      if (p.residual) row.v[j] += ((const f32x4*)(p.residual + r * p.D))[c];
-      if (p.out_sum) ((f32x4*)(p.out_sum + r * p.D))[c] = row.v[j];
+      for (int j = 0; j < LN_MAXV; ++j)
+        if (lane + 64 * j < nv) row.v[j] += ps[lane + 64 * j];
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nv) {
+        if (p.bias) row.v[j] += ((const f32x4*)p.bias)[c];
+        if (p.residual) row.v[j] += ((const f32x4*)(p.residual + r * p.D))[c];
+        if (p.out_sum) ((f32x4*)(p.out_sum + r * p.D))[c] = row.v[j];
+      }
     }
   }
   if (!p.gamma) return;
@@ -181,7 +217,11 @@ extern "C" int zh_sum_layernorm_f32(const float* parts, int n_parts, long part_s
   SumLnArgs p{parts, n_parts, part_stride, bias, residual, out_sum, gamma, beta, eps, out_f32, (half_t*)out_f16, lo_plane,
               out_group_rows, out_group_stride, out_offset, skip_first_in_group, gamma2, beta2, eps2, out2_f32, (half_t*)out2_f16, lo_plane2,
               out2_group_rows, out2_group_stride, out2_offset, rows, D};
-  hipLaunchKernelGGL(sum_layernorm_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, p);
+  const dim3 grid(zh_cdiv(rows, 4));
+  if (n_parts == 1) hipLaunchKernelGGL(sum_layernorm_kernel<1>, grid, dim3(256), 0, stream, p);
+  else if (n_parts == 2) hipLaunchKernelGGL(sum_layernorm_kernel<2>, grid, dim3(256), 0, stream, p);
+  else if (n_parts == 4) hipLaunchKernelGGL(sum_layernorm_kernel<4>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(sum_layernorm_kernel<0>, grid, dim3(256), 0, stream, p);
   ZH_CHECK_LAUNCH("zh_sum_layernorm_f32");
   return ZH_OK;
 }

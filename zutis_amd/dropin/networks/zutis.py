@@ -206,8 +206,11 @@ class ZUTIS(nn.Module):
         self.precision: str = "exact"
         # engine_base._decoder: this module serves batch-1 evaluation loops (coco20k_eval.py:241-268), where the decoder's cross-attention is
         # 8 workgroups per launch unless its keys are split: forward at 480x640 4.25 / 3.56 / 3.21 / 3.04 / 2.97 ms for splits 1 / 2 / 4 / 8 / 16
-        self.cross_attention_key_split: int = 8
-        self.use_hip_graph: bool = False       # opt-in: forward() of batches <= 4 replays a hipGraph captured per input shape
+        self.cross_attention_key_split: int = 12     # round 4, 4800 keys: 36.2 / 31.1 us for splits 8 / 12 (30 ties with 12: the merge grows with it)
+        # forward() of batches <= 4 replays a hipGraph captured per input shape (the eager path costs ~11 us of Python + ctypes per launch,
+        # more than most of a one-image forward's ~165 kernels): the reference's callers evaluate image by image (val batch_size 1,
+        # trainer.py:328-345, coco20k_eval.py:258-267).  False: always launch eagerly.
+        self.use_hip_graph: bool = True
 
     # ------------------------------------------------------------------ plumbing
     def _get_engine(self) -> ZutisEngine:

@@ -279,13 +279,13 @@ class _EngineBase:
                 ews = self._buf("enc_attn_ws", (ops.attention_splitk_workspace_size(B, heads, T, D // heads, eks),), torch.uint8)
         for i in range(n_layers):
             pp = f"enc.{i}."
-            if not (sk and i > 0):                         # split-K regime: ln_1 of block i > 0 came out of block i - 1's last kernel
+            if not (sk and s_proj > 1 and i > 0):          # split-K regime: ln_1 of block i > 0 came out of block i - 1's last kernel
                 ops.layernorm(X, W_[pp + "ln1.w"], W_[pp + "ln1.b"], eps, R, D, out_f16=Y)
             self._gemm("qkv", Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
             ops.attention(q_, k_, v_, O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=D // heads,
                           ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
                           strideO=T * D, causal=causal, x3=xa, ksplit=eks, workspace=ews)
-            if sk:
+            if sk and s_out > 1:
                 gemm_parts("out", O, W_[pp + "out_w"], s_out)
                 ops.sum_layernorm(parts, s_out, R, D, bias=W_[pp + "out_b"], residual=X, out_sum=X, gamma=W_[pp + "ln2.w"], beta=W_[pp + "ln2.b"],
                                   eps=eps, out_f16=Y)
@@ -293,7 +293,7 @@ class _EngineBase:
                 self._gemm("out", O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
                 ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y)
             self._gemm("fc", Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
-            if sk:
+            if sk and s_proj > 1:
                 gemm_parts("proj", Hh, W_[pp + "proj_w"], s_proj)
                 nx = f"enc.{i + 1}." if i + 1 < n_layers else None
                 ops.sum_layernorm(parts, s_proj, R, D, bias=W_[pp + "proj_b"], residual=X, out_sum=X,
@@ -311,11 +311,14 @@ class _EngineBase:
         if R > self.SPLITK_MAX_ROWS or K % 64:
             return 1
         s = 1
-        while 2 * s <= self.SPLITK_MAX and (K // (2 * s)) % 64 == 0 and K // (2 * s) >= 192:
+        while 2 * s <= self.SPLITK_MAX and (K // (2 * s)) % 64 == 0 and K // (2 * s) >= self.SPLITK_MIN_K:
             s *= 2
         return s
 
     SPLITK_MAX = int(os.environ.get("ZH_SPLITK_MAX", "4"))
+    # shortest K slab: c_proj (K = 3072) splits four ways (38.4 -> 25.0 us for the GEMM, + 5 us in the LayerNorm that adds the planes);
+    # out_proj (K = 768) does not — its 228 tiles of 64 x 64 already fill the chip (11.8 us; planes + a longer LayerNorm cost more)
+    SPLITK_MIN_K = int(os.environ.get("ZH_SPLITK_MIN_K", "512"))
 
     def _decoder_kv(self, VIN16, KIN16, B, M, D, L, k_pos=None):
         """Cross-attention K / V of all L layers (transformer.py:281-284) from ONE GEMM each: [B*M, L*D] fp16 (split pairs
@@ -401,16 +404,25 @@ class _EngineBase:
             self._gemm("dec", o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt_in)
             ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
             self._gemm("dec", tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
-            self._gemm("dec", ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
+            # linear2 (:289-290; K = 2048): in the few-row regime its K is split over workgroups (a batched GEMM over K slabs) and the
+            # planes meet in the LayerNorm below, with the bias and the residual (20.9 -> ~10 us for 100 queries)
+            s_l2 = self._splitk(R, D, Ff) if xd else 1
+            if s_l2 > 1:
+                l2p = self._buf("dec_l2_parts", (s_l2, R, D), f32)
+                self._gemm("dec", ff16, W_[pp + "l2_w"], l2p, M=R, N=D, K=Ff // s_l2, lda=Ff, ldw=Ff, ldc=D, batch=s_l2, strideA=Ff // s_l2,
+                           strideW=Ff // s_l2, strideC=R * D)
+                src = dict(parts=l2p, n_parts=s_l2, bias=W_[pp + "l2_b"], residual=tgt)
+            else:
+                self._gemm("dec", ff16, W_[pp + "l2_w"], t1, bias=W_[pp + "l2_b"], residual=tgt)
+                src = dict(parts=t1, n_parts=1)
             # norm3 (:291) and, where the layer's output is kept, decoder.norm on top of it (:140-150; stacked [B,L,Q,D]) in ONE pass
             n3 = dict(gamma=W_[pp + "norm3.w"], beta=W_[pp + "norm3.b"], eps=1e-5, out_f32=tgt, out_f16=tgt16)
             if stack_all:
-                ops.sum_layernorm(t1, 1, R, D, **n3, gamma2=W_["dec.norm.w"], beta2=W_["dec.norm.b"], eps2=1e-5, out2_f16=inter16,
-                                  out2_group_rows=Q, out2_group_stride=L * Q, out2_offset=l * Q)
+                n3.update(gamma2=W_["dec.norm.w"], beta2=W_["dec.norm.b"], eps2=1e-5, out2_f16=inter16, out2_group_rows=Q, out2_group_stride=L * Q,
+                          out2_offset=l * Q)
             elif l == L - 1:
-                ops.sum_layernorm(t1, 1, R, D, **n3, gamma2=W_["dec.norm.w"], beta2=W_["dec.norm.b"], eps2=1e-5, out2_f16=inter16, out2_f32=out32)
-            else:
-                ops.sum_layernorm(t1, 1, R, D, **n3)
+                n3.update(gamma2=W_["dec.norm.w"], beta2=W_["dec.norm.b"], eps2=1e-5, out2_f16=inter16, out2_f32=out32)
+            ops.sum_layernorm(src.pop("parts"), src.pop("n_parts"), R, D, **src, **n3)
         return inter16
 
     cross_ksplit = int(os.environ.get("ZH_CROSS_KSPLIT", "1"))      # class default (env = developer override); instances may set it
