@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 217 /* 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 218 /* 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -131,7 +131,13 @@ int zh_layernorm_f32(const float* x, long in_group_rows, long in_group_stride, l
                      long out_group_rows, long out_group_stride, long out_offset,
                      const float* gamma, const float* beta, float eps,
                      float* out_f32, void* out_f16, void* out_f16_plus, float* out_f32_plus,
-                     const float* add, int add_rows, int rows, int D, long lo_plane, zh_stream_t stream);
+                     const float* add, int add_rows, int rows, int D, long lo_plane, int* status, zh_stream_t stream);
+/* status (here, zh_sum_layernorm_f32, zh_global_ln_l2; may be NULL): a device word into which ZH_STATUS_NONFINITE (2) is OR-ed when a row's
+ * variance is inf / NaN.  The split-pair (f16x3) operands of this library hold |x| < 65504: beyond it hi = inf and every later product is
+ * a NaN that reaches the next LayerNorm of the path — checking there costs one compare per row.  The host reads the word once per
+ * forward (at its next synchronisation) and raises; bit 0 of the same word is zh_instance_mask_stats' range flag. */
+#define ZH_STATUS_RANGE 1
+#define ZH_STATUS_NONFINITE 2
 
 /* Split-K combine + bias + residual + LayerNorm (+ a second, chained LayerNorm) in one pass over each row (round 4):
  *   x = ((parts[0] + ... + parts[n_parts-1]) + bias) + residual      parts f32 [n_parts][rows, D] at part_stride, in plane order
@@ -147,7 +153,7 @@ int zh_sum_layernorm_f32(const float* parts, int n_parts, long part_stride, cons
                          long out_group_rows, long out_group_stride, long out_offset, int skip_first_in_group,
                          const float* gamma2, const float* beta2, float eps2, float* out2_f32, void* out2_f16, long lo_plane2,
                          long out2_group_rows, long out2_group_stride, long out2_offset,
-                         int rows, int D, zh_stream_t stream);
+                         int rows, int D, int* status, zh_stream_t stream);
 
 /* cat(class_embedding, patch_emb) + pos_embed, then ln_pre: clip_arch.py:384-397.  out [B,T,D] f32.
  * gamma = beta = NULL: no LayerNorm (DINO ViT prepare_tokens, selfmask/vision_transformer.py:269-281). */
@@ -156,12 +162,16 @@ int zh_assemble_tokens_ln(const float* patch_emb, const float* class_embedding, 
                           int B, int T, int D, zh_stream_t stream);
 
 /* x / (||x||_2 + eps) per row: queries (eps = 0) zutis.py:515; averaged tokens (eps = 1e-7) zutis.py:413. */
-int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, long lo_plane, zh_stream_t stream);
+int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, long lo_plane, float f16_scale, zh_stream_t stream);
+/* f16_scale (zh_l2norm_rows, zh_global_ln_l2, zh_cast_f32_f16; a power of two, 1 = none): the fp16 / split-pair copy holds y * f16_scale; its
+ * consumer multiplies its accumulator by 1 / f16_scale (zh_gemm_f16x3 out_scale).  Unit-norm rows (|y| ~ 0.04) are stored times 2^10 so that
+ * the lo half of the pair is a normal fp16 number (22 significant bits instead of ~19); fp32 outputs are never scaled. */
 
 /* F.layer_norm over the whole (h,w,c) volume per image (no affine) then x/(||x||_c + l2_eps): zutis.py:320-322. */
 size_t zh_global_ln_l2_workspace_size(int B, int M, int C);
 int zh_global_ln_l2(const float* x, float* out_f32, void* out_f16, float eps, float l2_eps,
-                    int B, int M, int C, void* workspace, size_t workspace_bytes, long lo_plane, zh_stream_t stream);
+                    int B, int M, int C, void* workspace, size_t workspace_bytes, long lo_plane, float f16_scale, int* status,
+                    zh_stream_t stream);
 
 /* im2col of the stride==kernel patch conv (pure re-index): clip_arch.py:340,378; selfmask/vision_transformer.py:182.
  * out f16 [B*gh*gw, Kpad], k = c*p*p + i*p + j, zero padded.  pad_to_patch = 0: gh = floor((H-p)/p)+1 (CLIP, trailing
@@ -191,7 +201,7 @@ int zh_add_rowperiodic_f16(const void* a, const float* add, void* out, long rows
 int zh_fill_f32(float* x, float value, long n, zh_stream_t stream);
 
 /* f32 -> f16 (optionally + add[r % add_rows]). */
-int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, long lo_plane,
+int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, long lo_plane, float f16_scale,
                     zh_stream_t stream);
 
 /* argmax_c(F.interpolate(logits, size=(H,W), bilinear)) fused, bit-identical to ATen incl. ties: zutis.py:366-372.

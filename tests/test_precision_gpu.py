@@ -714,3 +714,131 @@ def test_split_k_planes_plus_sum_layernorm_equals_gemm_plus_layernorm(dev):
     yr = F.layer_norm(ref, (D,), g.double(), b.double(), 1e-5)
     for Y in (Y1, Y2):
         assert float(((Y.t[0].float() + Y.t[1].float()).cpu().double() - yr).abs().max()) < 5e-6
+
+
+# ----------------------------------------------------------------------------------------------- the x3 envelope (round 4)
+@pytest.mark.parametrize("scale", [3e4, 1.0, 1e-4])
+def test_gemm_x3_operand_magnitudes(dev, scale):
+    """The split-pair GEMM at the edges of its envelope: activations of magnitude ~3e4 (just inside the fp16 range of the hi plane) stay
+    fp32-class; uniformly tiny activations (1e-4: the lo halves would be subnormal fp16 numbers, ~12 bits for the pair) stay fp32-class
+    when their producer stores them with a power-of-two scale (Act.out_scale, what the engine does for its unit-norm tensors) — and
+    measurably do not without it."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    M, N, K = 300, 256, 512
+    A32 = _randn((M, K), 1) * scale * 0.3
+    W32 = _randn((N, K), 2, 0.05)
+    ref = A32.double() @ W32.double().t()
+    bound = A32.abs().double() @ W32.abs().double().t()
+    W = ops.split_weight(W32.to(dev))
+
+    def run(pre):                                                       # pre: the power of two the producer stores A with
+        a = A32 * pre
+        A = Act(torch.stack([a.to(f16), (a - a.to(f16).float()).to(f16)]).contiguous().to(dev), out_scale=1.0 / pre)
+        out = torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm_x3(A, W, out)
+        return float(((out.cpu().double() - ref).abs() / bound).max())
+    if scale >= 1.0:
+        assert float(A32.abs().max()) < 65504 and run(1.0) < 2e-6
+    else:
+        plain, scaled = run(1.0), run(2.0 ** 13)
+        assert scaled < 2e-6 and plain > 20 * scaled, (plain, scaled)
+
+
+def test_unit_norm_producers_store_normal_lo_halves(dev):
+    """zh_l2norm_rows / zh_global_ln_l2 / zh_cast_f32_f16 with f16_scale = 2^10 (the engine's q16 / pt16 / text16): hi + lo times 2^-10
+    reproduces the fp32 value to 2^-21 relative per element (unscaled: the lo half of a ~0.04 element is subnormal, ~2^-18), and the
+    class-logit product of two such pairs is fp32-class against float64."""
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    rows, D = 300, 512
+    x = _randn((rows, D), 5)
+    y32 = torch.empty((rows, D), dtype=f32, device=dev)
+    errs = {}
+    for name, sc in (("scaled", ops.UNIT_NORM_SCALE), ("plain", 1.0)):
+        a = Act.empty((rows, D), True, dev)
+        a.out_scale = 1.0 / sc
+        ops.l2norm_rows(x.to(dev), rows, D, out_f32=y32, out_f16=a)
+        back = (a.t[0].float() + a.t[1].float()) * a.out_scale
+        errs[name] = float(((back - y32).abs() / y32.abs().clamp_min(1e-3)).max())
+    assert errs["scaled"] < 2.0 ** -21 and errs["plain"] > 4 * errs["scaled"], errs
+    # cast (text rows) x global-LN + L2 (patch tokens) -> logits
+    t = _randn((81, D), 6); t = t / t.norm(dim=1, keepdim=True)
+    B, Mpix = 1, 400
+    ts = _randn((B, Mpix, D), 7) * 2 + 0.3
+    t16 = Act.empty((81, D), True, dev); t16.out_scale = 1.0 / ops.UNIT_NORM_SCALE
+    ops.cast_f16(t.to(dev), t16, 81, D)
+    pt = torch.empty((B, Mpix, D), dtype=f32, device=dev)
+    pt16 = Act.empty((B * Mpix, D), True, dev); pt16.out_scale = 1.0 / ops.UNIT_NORM_SCALE
+    st = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ops.global_ln_l2(ts.to(dev), B, Mpix, D, out_f32=pt, out_f16=pt16, status=st)
+    assert int(st.item()) == 0
+    lo = torch.empty((81, Mpix), dtype=f32, device=dev)
+    ops.gemm_x3(t16, pt16, lo)
+    ref = t.double() @ pt.cpu()[0].double().t()
+    assert float((lo.cpu().double() - ref).abs().max()) < 2e-7
+
+
+def test_status_word_fires_on_non_finite_rows_only(dev):
+    """The LayerNorm family raises ZH_STATUS_NONFINITE for a row holding an inf / NaN (what an fp16 split pair beyond 65504 turns into one
+    product later) and leaves the word alone for finite rows of any magnitude."""
+    from zutis_amd import ops
+    rows, D = 9, 768
+    g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    for val, fires in ((3e4, False), (7e4, False), (float("inf"), True), (float("nan"), True), (-float("inf"), True)):
+        x = _randn((rows, D), 8)
+        x[4, 100] = val                                                 # fp32 rows: 7e4 is an ordinary number HERE (the residual stream is fp32)
+        st = torch.zeros((1,), dtype=torch.int32, device=dev)
+        o = torch.empty((rows, D), dtype=f32, device=dev)
+        ops.layernorm(x.to(dev), g, b, 1e-5, rows, D, out_f32=o, status=st)
+        assert bool(int(st.item()) & ops.STATUS_NONFINITE) == fires, val
+        st.zero_()
+        ops.sum_layernorm(x.to(dev), 1, rows, D, gamma=g, beta=b, out_f32=o, status=st)
+        assert bool(int(st.item()) & ops.STATUS_NONFINITE) == fires, val
+    # ... and 7e4 in an fp16 PRODUCER is the overflow: the pair stores inf, the next GEMM returns NaN, the next LayerNorm fires
+    from zutis_amd.ops import Act
+    x = _randn((rows, D), 9); x[2, 5] = 7e4
+    a = Act.empty((rows, D), True, dev)
+    ops.cast_f16(x.to(dev), a, rows, D)
+    assert torch.isinf(a.t[0][2, 5])
+    out = torch.empty((rows, D), dtype=f32, device=dev)
+    ops.gemm_x3(a, ops.split_weight(_randn((D, D), 10, 0.03).to(dev)), out)
+    st = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ops.layernorm(out, g, b, 1e-5, rows, D, out_f32=torch.empty_like(out), status=st)
+    assert int(st.item()) & ops.STATUS_NONFINITE
+
+
+def test_engine_refuses_to_answer_outside_the_envelope(dev):
+    """End to end: an MLP weight blown up so that QuickGELU(c_fc) leaves the fp16 range -> the forward's status word is set, check_finite()
+    and the drop-in's predict raise (no silent garbage, no fallback); the same engine answers normally again once the weight is back."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin"))
+    from networks.zutis import ZUTIS
+    from zutis_amd import detgen, _lib
+    cfg = detgen.TINY
+    net = ZUTIS(categories=[f"c{i}" for i in range(5)], clip_arch="ViT-B/16", n_queries=cfg.n_queries, n_decoder_layers=cfg.dec_layers,
+                n_heads=cfg.dec_heads, device=dev, text_embeddings=torch.from_numpy(detgen.text_embeddings(5, cfg.embed_dim)),
+                vision_config=(cfg.width, cfg.layers, cfg.patch, cfg.grid, cfg.embed_dim))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.zutis_state_dict(cfg).items()}, strict=True)
+    net = net.to(dev).eval().requires_grad_(False)
+    x = torch.from_numpy(detgen.images(1, 64, 96)).to(dev)
+    ok = net.predict(net(x), mask_type="semantic", size=(64, 96))
+    w = net.encoder.transformer.resblocks[0].mlp.c_fc.weight
+    w0 = w.detach().clone()
+    with torch.no_grad():
+        w.copy_(w0 * 3e5)
+    for mask_type in ("semantic", "instance"):
+        out = net(x)
+        with pytest.raises(_lib.ZutisHipError, match="non-finite"):
+            net.predict(out, mask_type=mask_type, size=(64, 96))
+    net(x)
+    with pytest.raises(_lib.ZutisHipError, match="non-finite"):
+        net._get_engine().check_finite()
+    net._get_engine().check_finite()                                    # the word was cleared by the raise
+    with torch.no_grad():
+        w.copy_(w0)
+    again = net.predict(net(x), mask_type="semantic", size=(64, 96))
+    assert np.array_equal(ok, again)
+    xn = x.clone(); xn[0, 1, 3, 4] = float("nan")
+    with pytest.raises(_lib.ZutisHipError, match="non-finite"):
+        net.predict(net(xn), mask_type="semantic", size=(64, 96))

@@ -40,12 +40,12 @@ _SIGS = {
     "zh_embed_tokens_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "zh_eot_rows_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "zh_group_mean_l2norm": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "zh_layernorm_f32": (_i, [_vp, _l, _l, _l, _l, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
-    "zh_sum_layernorm_f32": (_i, [_vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _l, _l, _l, _l, _i, _vp, _vp, _f, _vp, _vp, _l, _l, _l, _l, _i, _i, _vp]),
+    "zh_layernorm_f32": (_i, [_vp, _l, _l, _l, _l, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp, _vp]),
+    "zh_sum_layernorm_f32": (_i, [_vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _l, _l, _l, _l, _i, _vp, _vp, _f, _vp, _vp, _l, _l, _l, _l, _i, _i, _vp, _vp]),
     "zh_assemble_tokens_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
-    "zh_l2norm_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _l, _vp]),
+    "zh_l2norm_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _l, _f, _vp]),
     "zh_global_ln_l2_workspace_size": (_sz, [_i, _i, _i]),
-    "zh_global_ln_l2": (_i, [_vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _sz, _l, _vp]),
+    "zh_global_ln_l2": (_i, [_vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _sz, _l, _f, _vp, _vp]),
     "zh_im2col_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _l, _vp]),
     "zh_posembed_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "zh_select_upsample_mask": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
@@ -53,7 +53,7 @@ _SIGS = {
     "zh_sine_pe": (_i, [_vp, _i, _i, _i, _f, _vp]),
     "zh_add_rowperiodic_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _l, _l, _vp]),
     "zh_fill_f32": (_i, [_vp, _f, _l, _vp]),
-    "zh_cast_f32_f16": (_i, [_vp, _vp, _i, _vp, _l, _i, _l, _vp]),
+    "zh_cast_f32_f16": (_i, [_vp, _vp, _i, _vp, _l, _i, _l, _f, _vp]),
     "zh_upsample_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "zh_upsample_bilinear_nchw": (_i, [_vp, _vp, _vp, _f, _l, _i, _i, _i, _i, _f, _f, _vp]),
     "zh_confusion_hist": (_i, [_vp, _vp, _vp, _l, _i, _vp]),

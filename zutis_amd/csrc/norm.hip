@@ -9,8 +9,15 @@ struct LnRow {
   f32x4 v[LN_MAXV];
 };
 
-// y = (x - mean) * rstd, in place in registers. nv = D/4 float4 per row.
-__device__ __forceinline__ void ln_normalize(LnRow& r, int nv, int lane, int D, float eps) {
+// The engine's status word (optional `status` argument of the LayerNorm family): bit 1 is OR-ed in when a row's variance is not a finite
+// number — an inf or a NaN reached the residual stream.  That is how an fp16 split pair leaving its range shows: |activation| >= 65504
+// stores hi = inf, lo = -inf / NaN, the next product is a NaN, and every path of the model (residual adds, attention over an image's
+// tokens) leads into a LayerNorm.  One compare per row here, nothing in the GEMM / attention epilogues; the host reads the word at its
+// next synchronisation and raises (no fallback).
+#define ZH_STATUS_NONFINITE 2
+
+// y = (x - mean) * rstd, in place in registers. nv = D/4 float4 per row.  Returns false when the variance is inf / NaN.
+__device__ __forceinline__ bool ln_normalize(LnRow& r, int nv, int lane, int D, float eps) {
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < LN_MAXV; ++j)
@@ -23,9 +30,14 @@ __device__ __forceinline__ void ln_normalize(LnRow& r, int nv, int lane, int D, 
       r.v[j] -= mean;
       q += (r.v[j][0] * r.v[j][0] + r.v[j][1] * r.v[j][1]) + (r.v[j][2] * r.v[j][2] + r.v[j][3] * r.v[j][3]);
     }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float var = wave_sum(q) / (float)D;
+  const float rstd = rsqrtf(var + eps);
 #pragma unroll
   for (int j = 0; j < LN_MAXV; ++j) r.v[j] *= rstd;
+  return var < INFINITY;                                    // false for inf and for NaN
+}
+__device__ __forceinline__ void zh_raise_nonfinite(int* status, bool ok, int lane) {
+  if (status && !ok && lane == 0) atomicOr(status, ZH_STATUS_NONFINITE);
 }
 
 struct LnArgs {
@@ -37,6 +49,7 @@ struct LnArgs {
   float* out_f32_plus;                                              // optional fp32 copy of y + add
   int rows, D; float eps;
   long lo_plane;                                                    // != 0: fp16 outputs are split pairs (lo half at + lo_plane)
+  int* status;                                                      // optional status word (ZH_STATUS_NONFINITE)
 };
 
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
@@ -50,7 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
 #pragma unroll
   for (int j = 0; j < LN_MAXV; ++j)
     if (lane + 64 * j < nv) row.v[j] = xp[lane + 64 * j];
-  ln_normalize(row, nv, lane, p.D, p.eps);
+  zh_raise_nonfinite(p.status, ln_normalize(row, nv, lane, p.D, p.eps), lane);
   const long ob = ((r / p.out_group_rows) * p.out_group_stride + p.out_offset + (r % p.out_group_rows)) * p.D;
   const long ab = p.add ? (long)(r % p.add_rows) * p.D : 0;
 #pragma unroll
@@ -74,7 +87,7 @@ extern "C" int zh_layernorm_f32(const float* x, long in_group_rows, long in_grou
                                 long out_group_rows, long out_group_stride, long out_offset,
                                 const float* gamma, const float* beta, float eps,
                                 float* out_f32, void* out_f16, void* out_f16_plus, float* out_f32_plus,
-                                const float* add, int add_rows, int rows, int D, long lo_plane, hipStream_t stream) {
+                                const float* add, int add_rows, int rows, int D, long lo_plane, int* status, hipStream_t stream) {
   ZH_CHECK_ARG(x && rows > 0, "zh_layernorm_f32: bad input");
   ZH_CHECK_ARG(lo_plane % 4 == 0, "zh_layernorm_f32: lo_plane must be a multiple of 4 halves");
   ZH_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV && D > 0, "zh_layernorm_f32: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXV);
@@ -82,7 +95,7 @@ extern "C" int zh_layernorm_f32(const float* x, long in_group_rows, long in_grou
   ZH_CHECK_ARG(in_group_rows > 0 && out_group_rows > 0, "zh_layernorm_f32: group_rows must be > 0");
   ZH_CHECK_ARG(!(out_f16_plus || out_f32_plus) || (add && add_rows > 0), "zh_layernorm_f32: *_plus outputs need add/add_rows");
   LnArgs p{x, in_group_rows, in_group_stride, in_offset, out_group_rows, out_group_stride, out_offset, gamma, beta, out_f32, (half_t*)out_f16,
-           (half_t*)out_f16_plus, add, add_rows, out_f32_plus, rows, D, eps, lo_plane};
+           (half_t*)out_f16_plus, add, add_rows, out_f32_plus, rows, D, eps, lo_plane, status};
   hipLaunchKernelGGL(layernorm_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, p);
   ZH_CHECK_LAUNCH("zh_layernorm_f32");
   return ZH_OK;
@@ -105,6 +118,7 @@ struct SumLnArgs {
   float* out2_f32; half_t* out2_f16; long lo_plane2;
   long og2_rows, og2_stride, og2_offset;
   int rows, D;
+  int* status;
 };
 
 // NPARTS > 0: the plane count as a template parameter — every plane's loads (and the bias / residual ones) are requested before the first add
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(256) void sum_layernorm_kernel(SumLnArgs p) {
     }
   }
   if (!p.gamma) return;
-  ln_normalize(row, nv, lane, p.D, p.eps);
+  zh_raise_nonfinite(p.status, ln_normalize(row, nv, lane, p.D, p.eps), lane);
   const long g = r / p.og_rows, w = r % p.og_rows;
   const bool emit = !(p.skip_first && w == 0);
   const long ob = (g * p.og_stride + p.og_offset + w) * p.D;
@@ -204,7 +218,7 @@ extern "C" int zh_sum_layernorm_f32(const float* parts, int n_parts, long part_s
                                     long out_group_rows, long out_group_stride, long out_offset, int skip_first_in_group,
                                     const float* gamma2, const float* beta2, float eps2, float* out2_f32, void* out2_f16, long lo_plane2,
                                     long out2_group_rows, long out2_group_stride, long out2_offset,
-                                    int rows, int D, hipStream_t stream) {
+                                    int rows, int D, int* status, hipStream_t stream) {
   ZH_CHECK_ARG(parts && n_parts >= 1 && rows > 0, "zh_sum_layernorm_f32: bad input");
   ZH_CHECK_ARG(n_parts == 1 || part_stride >= (long)rows * D, "zh_sum_layernorm_f32: part_stride %ld < rows * D", part_stride);
   ZH_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV && D > 0, "zh_sum_layernorm_f32: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXV);
@@ -216,7 +230,7 @@ extern "C" int zh_sum_layernorm_f32(const float* parts, int n_parts, long part_s
   ZH_CHECK_ARG(!gamma2 || (out2_group_rows > 0 && (out2_f32 || out2_f16)), "zh_sum_layernorm_f32: second LayerNorm needs an output and out2_group_rows > 0");
   SumLnArgs p{parts, n_parts, part_stride, bias, residual, out_sum, gamma, beta, eps, out_f32, (half_t*)out_f16, lo_plane,
               out_group_rows, out_group_stride, out_offset, skip_first_in_group, gamma2, beta2, eps2, out2_f32, (half_t*)out2_f16, lo_plane2,
-              out2_group_rows, out2_group_stride, out2_offset, rows, D};
+              out2_group_rows, out2_group_stride, out2_offset, rows, D, status};
   const dim3 grid(zh_cdiv(rows, 4));
   if (n_parts == 1) hipLaunchKernelGGL(sum_layernorm_kernel<1>, grid, dim3(256), 0, stream, p);
   else if (n_parts == 2) hipLaunchKernelGGL(sum_layernorm_kernel<2>, grid, dim3(256), 0, stream, p);
@@ -266,8 +280,12 @@ extern "C" int zh_assemble_tokens_ln(const float* patch_emb, const float* class_
 }
 
 // ---- row L2 normalise: queries / ||queries||  (networks/zutis.py:515, no eps) -> fp16 and/or fp32
+// f16_scale (a power of two; here and in the other producers of unit-norm rows): the fp16 / split-pair copy is stored as y * f16_scale and
+// its consumer multiplies the finished accumulator by 1 / f16_scale (Act.out_scale).  A unit-norm row of 512 - 768 elements has
+// |y| ~ 0.04: its lo half, ~2^-11 of that, is a SUBNORMAL fp16 number (below 6.1e-5: 19 significant bits for the pair instead of 22);
+// times 2^10 both halves are normal numbers and nothing can overflow (|y| <= 1).
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float* out_f32, half_t* out_f16, int rows, int D, float eps,
-                                                          long lo_plane) {
+                                                          long lo_plane, float f16_scale) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -288,17 +306,17 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float*
     if (c < nv) {
       f32x4 y = v[j] * inv;
       if (out_f32) ((f32x4*)(out_f32 + r * D))[c] = y;
-      if (out_f16) zh_store_h4(out_f16 + r * D + 4 * c, lo_plane, y);
+      if (out_f16) zh_store_h4(out_f16 + r * D + 4 * c, lo_plane, y * f16_scale);
     }
   }
 }
 
-extern "C" int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, long lo_plane,
+extern "C" int zh_l2norm_rows(const float* x, float* out_f32, void* out_f16, float eps, int rows, int D, long lo_plane, float f16_scale,
                               hipStream_t stream) {
-  ZH_CHECK_ARG(x && (out_f32 || out_f16) && rows > 0 && lo_plane % 4 == 0, "zh_l2norm_rows: bad arguments");
+  ZH_CHECK_ARG(x && (out_f32 || out_f16) && rows > 0 && lo_plane % 4 == 0 && f16_scale > 0.f, "zh_l2norm_rows: bad arguments");
   ZH_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV && D > 0, "zh_l2norm_rows: D=%d unsupported", D);
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, x, out_f32, (half_t*)out_f16, rows, D, eps,
-                     lo_plane);
+                     lo_plane, f16_scale);
   ZH_CHECK_LAUNCH("zh_l2norm_rows");
   return ZH_OK;
 }
@@ -353,7 +371,7 @@ __global__ __launch_bounds__(256) void gln_partial_kernel(const float* x, float*
 
 __global__ __launch_bounds__(256) void gln_apply_kernel(const float* x, const float* part, float* out_f32, half_t* out_f16,
                                                         long per_image, int nchunks, int M, int C, float eps, float l2_eps,
-                                                        long lo_plane) {
+                                                        long lo_plane, float f16_scale, int* status) {
   const int img = blockIdx.y;
   const int lane = threadIdx.x & 63;
   // combine partials (every wave redundantly; nchunks is a few hundred)
@@ -372,6 +390,7 @@ __global__ __launch_bounds__(256) void gln_apply_kernel(const float* x, const fl
   for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
   const float fmean = (float)mean;
   const float rstd = (float)(1.0 / sqrt(m2 / sn + (double)eps));
+  if (status && blockIdx.x == 0 && threadIdx.x == 0 && !(m2 / sn < (double)INFINITY)) atomicOr(status, ZH_STATUS_NONFINITE);
 
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= M) return;
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(256) void gln_apply_kernel(const float* x, const fl
     if (c < nv) {
       f32x4 y = v[j] * inv;
       if (out_f32) ((f32x4*)(out_f32 + ob))[c] = y;
-      if (out_f16) zh_store_h4(out_f16 + ob + 4 * c, lo_plane, y);
+      if (out_f16) zh_store_h4(out_f16 + ob + 4 * c, lo_plane, y * f16_scale);
     }
   }
 }
@@ -404,8 +423,9 @@ extern "C" size_t zh_global_ln_l2_workspace_size(int B, int M, int C) {
 }
 
 extern "C" int zh_global_ln_l2(const float* x, float* out_f32, void* out_f16, float eps, float l2_eps,
-                               int B, int M, int C, void* workspace, size_t workspace_bytes, long lo_plane, hipStream_t stream) {
-  ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && M > 0 && lo_plane % 4 == 0, "zh_global_ln_l2: bad arguments");
+                               int B, int M, int C, void* workspace, size_t workspace_bytes, long lo_plane, float f16_scale, int* status,
+                               hipStream_t stream) {
+  ZH_CHECK_ARG(x && (out_f32 || out_f16) && B > 0 && M > 0 && lo_plane % 4 == 0 && f16_scale > 0.f, "zh_global_ln_l2: bad arguments");
   ZH_CHECK_ARG(C % 4 == 0 && C <= 256 * LN_MAXV && C > 0, "zh_global_ln_l2: C=%d unsupported", C);
   ZH_CHECK_ARG(B < 65536, "zh_global_ln_l2: batch too large");
   const long per_image = (long)M * C;
@@ -416,7 +436,7 @@ extern "C" int zh_global_ln_l2(const float* x, float* out_f32, void* out_f16, fl
   }
   hipLaunchKernelGGL(gln_partial_kernel, dim3(nchunks, B), dim3(256), 0, stream, x, (float*)workspace, per_image, nchunks);
   hipLaunchKernelGGL(gln_apply_kernel, dim3(zh_cdiv(M, 4), B), dim3(256), 0, stream, x, (const float*)workspace, out_f32,
-                     (half_t*)out_f16, per_image, nchunks, M, C, eps, l2_eps, lo_plane);
+                     (half_t*)out_f16, per_image, nchunks, M, C, eps, l2_eps, lo_plane, f16_scale, status);
   ZH_CHECK_LAUNCH("zh_global_ln_l2");
   return ZH_OK;
 }

@@ -251,7 +251,7 @@ extern "C" int zh_add_rowperiodic_f16(const void* a, const float* add, void* out
 
 // ---- fp32 -> fp16 cast (optionally adding a row-periodic fp32 matrix first)
 __global__ __launch_bounds__(256) void cast_kernel(const float* x, const float* add, half_t* out, long n4, int nv, int add_rows,
-                                                   long lo_plane) {
+                                                   long lo_plane, float f16_scale) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n4) return;
   f32x4 v = ((const f32x4*)x)[idx];
@@ -259,16 +259,16 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* x, const float* 
     const long r = idx / nv;
     v += ((const f32x4*)add)[(r % add_rows) * nv + (idx - r * nv)];
   }
-  zh_store_h4(out + 4 * idx, lo_plane, v);
+  zh_store_h4(out + 4 * idx, lo_plane, v * f16_scale);          // f16_scale: see l2norm_rows_kernel (norm.hip)
 }
 
-extern "C" int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, long lo_plane,
+extern "C" int zh_cast_f32_f16(const float* x, const float* add, int add_rows, void* out, long rows, int D, long lo_plane, float f16_scale,
                                hipStream_t stream) {
-  ZH_CHECK_ARG(x && out && rows > 0 && D > 0 && D % 4 == 0 && lo_plane % 4 == 0, "zh_cast_f32_f16: bad arguments");
+  ZH_CHECK_ARG(x && out && rows > 0 && D > 0 && D % 4 == 0 && lo_plane % 4 == 0 && f16_scale > 0.f, "zh_cast_f32_f16: bad arguments");
   ZH_CHECK_ARG(!add || add_rows > 0, "zh_cast_f32_f16: add needs add_rows");
   const long n4 = rows * (D / 4);
   hipLaunchKernelGGL(cast_kernel, dim3(zh_cdiv(n4, 256)), dim3(256), 0, stream, x, add, (half_t*)out, n4, D / 4, add_rows > 0 ? add_rows : 1,
-                     lo_plane);
+                     lo_plane, f16_scale);
   ZH_CHECK_LAUNCH("zh_cast_f32_f16");
   return ZH_OK;
 }

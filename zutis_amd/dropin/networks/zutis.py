@@ -271,7 +271,11 @@ class ZUTIS(nn.Module):
         if mask_type == "semantic":                                                        # zutis.py:355-372
             size = None if size is None else (int(size[0]), int(size[1]))
             out = eng.predict_semantic(dict_outputs["patch_tokens"], self.text_embeddings, size, return_logits)
-            return out if return_logits else out.cpu().numpy()
+            if return_logits:
+                return out
+            labels = out.cpu().numpy()
+            eng.check_finite()                   # the forward's status word, read behind the synchronisation the label copy just made
+            return labels
 
         # instance prediction                                                              # zutis.py:374-470
         mask_proposals: torch.Tensor = dict_outputs["mask_proposals"]
@@ -280,7 +284,7 @@ class ZUTIS(nn.Module):
         size = None if size is None else (int(size[0]), int(size[1]))
         # the reference's two range asserts (zutis.py:385-386): a flag the statistics kernel raises while it reads the proposals anyway,
         # fetched with the NMS results (every device -> host copy is a stream synchronisation; the predict used to make four)
-        range_flag = torch.zeros((1,), dtype=torch.int32, device=mask_proposals.device)
+        range_flag = eng.status_word()           # the engine's sticky status word: bit 0 range (set below), bit 1 non-finite (set by the forward)
         masks_dev, scores, category_ids = eng.instance_candidates(
             mask_proposals, dict_outputs["patch_tokens"], self.text_embeddings, threshold, temperature, size, range_flag=range_flag)
         B, Q, Hm, Wm = masks_dev.shape
@@ -291,10 +295,13 @@ class ZUTIS(nn.Module):
         # stay on the GPU: IoU counts come from the popcount kernel, the greedy per-category NMS loop runs in one kernel
         # launch (zh_mask_nms, one workgroup per image), the runs / boxes / areas of the KEPT masks are extracted from the loop's device
         # outputs (zh_mask_runs_kept), and only those cross PCIe.
+        def raise_on(status: int):
+            if status:
+                range_flag.zero_()
+                eng.raise_on_status(status)      # a non-finite forward: ZutisHipError, not a range assert
+                assert not (status & _ops.STATUS_RANGE), "mask proposals outside [0, 1]"        # zutis.py:385-386
         if nms_type is None:
-            lo_hi = torch.stack(torch.aminmax(mask_proposals)).cpu()
-            assert 0 <= float(lo_hi[0]) <= 1
-            assert 0 <= float(lo_hi[1]) <= 1
+            raise_on(int(range_flag.item()))
             confidence_scores: np.ndarray = scores.cpu().numpy()
             category_ids_h: np.ndarray = category_ids.cpu().numpy()
             kept = [(bi, int(c), q, float(s)) for bi in range(B)
@@ -303,8 +310,8 @@ class ZUTIS(nn.Module):
             rles, boxes, areas = eng.encode_masks(masks_dev.view(B * Q, Hm, Wm), sel)
         else:
             assert nms_type in ["hard", "linear", "gaussian"]
-            kept, rles, boxes, areas, range_bad = eng.instance_nms_encode(masks_dev, scores, category_ids, nms_type, range_flag=range_flag)
-            assert not range_bad, "mask proposals outside [0, 1]"        # zutis.py:385-386
+            kept, rles, boxes, areas, status = eng.instance_nms_encode(masks_dev, scores, category_ids, nms_type, range_flag=range_flag)
+            raise_on(status)
         predictions: List[dict] = list()
         for (bi, c, q, s), r, box, area in zip(kept, rles, boxes, areas):
             if area == 0:                               # `if m.sum() == 0: continue` (zutis.py:281,439)

@@ -106,7 +106,7 @@ class ZutisEngine(_EngineBase):
         tok = self._buf("tok", (B, h * w, D), f32) if want32 else None
         tok16 = self._abuf("tok16", (B * h * w, D), self._x3("ffn1", "textproj")) if want16 else None
         ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B * h * w, D, out_f32=tok, out_f16=tok16,
-                      in_group_rows=h * w, in_group_stride=T, in_offset=1)                 # :403-404
+                      in_group_rows=h * w, in_group_stride=T, in_offset=1, status=self.status_word())   # :403-404
         return tok, tok16, h, w
 
     # ------------------------------------------------------------------ full forward
@@ -144,7 +144,7 @@ class ZutisEngine(_EngineBase):
         g1 = self._abuf("ffn2_h1", (RQ, Fh), self._x3("ffn2"))
         g2 = self._abuf("ffn2_h2", (RQ, Fh), self._x3("ffn2"))
         q32 = self._buf("q32", (RQ, D), f32)
-        q16 = self._abuf("q16", (RQ, D), self._x3("mask"))
+        q16 = self._abuf("q16", (RQ, D), self._x3("mask"), unit_norm=True)
         self._gemm("ffn2", inter16, W_["ffn2.0.w"], g1, bias=W_["ffn2.0.b"], act=ops.ACT_RELU)        # zutis.py:514
         self._gemm("ffn2", g1, W_["ffn2.1.w"], g2, bias=W_["ffn2.1.b"], act=ops.ACT_RELU)
         self._gemm("ffn2", g2, W_["ffn2.2.w"], q32, bias=W_["ffn2.2.b"])
@@ -160,8 +160,8 @@ class ZutisEngine(_EngineBase):
         ops.upsample2x_cl(tsl, B, h, w, self.E, out_f32=ts)                                 # :491-495
         pt = torch.empty((B, h2, w2, self.E), dtype=f32, device=x.device)
         ws = self._buf("gln_ws", (max(1, ops.global_ln_l2_workspace_size(B, M, self.E)),), torch.uint8)
-        pt16 = self._abuf("pt16", (B * M, self.E), self._x3("logits"))   # the copy predict_semantic's class-logit GEMM consumes
-        ops.global_ln_l2(ts, B, M, self.E, out_f32=pt, out_f16=pt16, eps=1e-5, l2_eps=1e-7, workspace=ws)  # :320-322
+        pt16 = self._abuf("pt16", (B * M, self.E), self._x3("logits"), unit_norm=True)   # the copy predict_semantic's class-logit GEMM consumes
+        ops.global_ln_l2(ts, B, M, self.E, out_f32=pt, out_f16=pt16, eps=1e-5, l2_eps=1e-7, workspace=ws, status=self.status_word())  # :320-322
         self._pt16_of = (weakref.ref(pt), pt._version)           # identity, not address: a freed tensor's address can be reused
         return {"mask_proposals": masks, "patch_tokens": pt}
 
@@ -237,13 +237,13 @@ class ZutisEngine(_EngineBase):
         B, h, w, E = patch_tokens.shape
         n = text.shape[0]
         xl = self._x3("logits")
-        pt16 = self._abuf("pt16", (B * h * w, E), xl)
+        pt16 = self._abuf("pt16", (B * h * w, E), xl, unit_norm=True)
         src = self._pt16_of
         if not (src is not None and src[0]() is patch_tokens and src[1] == patch_tokens._version):
             ops.cast_f16(patch_tokens.contiguous(), pt16, B * h * w, E)     # tokens not produced by the last forward()
             self._pt16_of = None
         t32 = text.detach().to(device=patch_tokens.device, dtype=f32).contiguous()
-        t16 = self._abuf("text16", (n, E), xl)
+        t16 = self._abuf("text16", (n, E), xl, unit_norm=True)
         recording = _lib.RECORDER is not None                              # a launch plan always contains the cast
         src = self._text16_of
         same = src is not None and src[0]() is text and src[1] == text._version and src[2] == self._buf_gen
@@ -352,7 +352,9 @@ class ZutisEngine(_EngineBase):
         loop, then the run extraction of the kept masks straight from the loop's device outputs (zh_mask_runs_kept) — the NMS result
         does not visit the host in between.  ONE device -> host copy brings the kept triples, every query's category, the counts, the
         range flag, the run counts and the boxes; a second one the run positions actually used.
-        Returns (kept [(batch index, category, query index, score)] in the reference's emission order, rles, boxes, areas, range_bad)."""
+        Returns (kept [(batch index, category, query index, score)] in the reference's emission order, rles, boxes, areas, status) — status =
+        the word behind `range_flag` as the NMS kernel read it (bit ops.STATUS_RANGE: a proposal outside [0, 1]; the engine's own
+        status_word() also carries ops.STATUS_NONFINITE from the forward)."""
         from . import rle
         B, Q, H, W = masks_u8.shape
         dev = masks_u8.device
@@ -375,7 +377,7 @@ class ZutisEngine(_EngineBase):
         nr_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 2)
         ba_h = host[n1 + n2:].view(np.int32).reshape(B, Q, 5)
         cnt_h = pk[:, 4 * Q].astype(np.int64)
-        range_bad = bool(pk[:, 4 * Q + 1].any())
+        range_bad = int(pk[:, 4 * Q + 1].max()) if range_flag is not None else 0      # the status word as the NMS kernel read it (ops.STATUS_*)
         mc = int(cnt_h.max()) if B else 0
         kept, rles, boxes, areas = [], [], [], []
         if mc > 0:

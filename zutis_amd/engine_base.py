@@ -98,6 +98,7 @@ class _EngineBase:
         self._buf_gen = 0             # bumped on every (re)allocation: launch plans check it
         self._buf_const: Dict[str, torch.Tensor] = {}   # buffers with constant regions: name -> the tensor that was initialised
         self._pt16_of = self._text16_of = None   # which tensors the cached f16 copies "pt16" / "text16" were made from
+        self._status = None           # device status word (ops.STATUS_*): see status_word() / check_finite()
 
     def fork(self):
         """A second engine over the SAME parameters and packed weights with its own activation buffers: one per HIP stream
@@ -109,7 +110,33 @@ class _EngineBase:
         # input-independent tables are shared; captured graphs are not (they replay into the parent's buffers and stream)
         e._geo = {k: v for k, v in self._geo.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
         e._pt16_of = e._text16_of = None       # provenance of the f16 copies held in the (new, empty) buffer cache
+        e._status = None                       # a status word of its own (it is written on the fork's stream)
         return e
+
+    # ------------------------------------------------------------------ the x3 envelope
+    # A split pair holds |x| < 65504 with 22 significant bits (min(2^-22 |x|, 3e-8) absolute: below 0.125 the lo half is a subnormal
+    # fp16 number).  Inside the envelope the engine is fp32-class; OUTSIDE it must not answer silently: an activation beyond the fp16
+    # range stores hi = inf, every product with it is a NaN, and every path of these networks leads into a LayerNorm, whose kernels OR
+    # STATUS_NONFINITE into this word when a row's variance is inf / NaN (one compare per row).  The word is sticky; the host reads it
+    # where it synchronises anyway (the drop-in's predict) or on request (check_finite) and raises.
+    def status_word(self) -> torch.Tensor:
+        if self._status is None:
+            self._status = torch.zeros((1,), dtype=torch.int32, device=self._device())
+        return self._status
+
+    def check_finite(self):
+        """Synchronises.  Raises when a forward since the last check met a non-finite activation (fp16 split-pair range exceeded, or an
+        inf / NaN in the input or the weights); clears the word."""
+        if self._status is None:
+            return
+        self.raise_on_status(int(self._status.item()))
+
+    def raise_on_status(self, word: int):
+        if word & ops.STATUS_NONFINITE:
+            if self._status is not None:
+                self._status.zero_()
+            raise ZutisHipError("non-finite activations: a value left the fp16 split-pair range (|x| >= 65504) or the input / weights hold "
+                                "an inf / NaN — the f16x3 engine does not answer outside its envelope (DESIGN.md, Precision)")
 
     def _version_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.params.values())
@@ -141,9 +168,11 @@ class _EngineBase:
     def _x3(self, *sites) -> bool:
         return any(s in self.x3_sites for s in sites)
 
-    def _abuf(self, name: str, shape, split: bool) -> Act:
-        """Cached fp16 activation buffer, a split pair when a consumer runs in the x3 mode."""
-        return Act(self._buf(name, ((2 if split else 1),) + tuple(shape), f16))
+    def _abuf(self, name: str, shape, split: bool, unit_norm: bool = False) -> Act:
+        """Cached fp16 activation buffer, a split pair when a consumer runs in the x3 mode.  unit_norm: rows of norm 1 (elements ~0.04):
+        a split pair of them is stored times 2^10 so that its lo half is a normal fp16 number (ops.UNIT_NORM_SCALE; the consumer GEMM
+        multiplies the factor out through Act.out_scale)."""
+        return Act(self._buf(name, ((2 if split else 1),) + tuple(shape), f16), out_scale=(1.0 / ops.UNIT_NORM_SCALE) if (unit_norm and split) else 1.0)
 
     @staticmethod
     def _h(t):
@@ -259,6 +288,7 @@ class _EngineBase:
         # (out_proj, c_proj) are 60 tiles of 128 x 128 for 256 CUs, so their K is split over S workgroups per tile — a batched GEMM
         # over K slabs writing fp32 partial planes — and the planes are summed by the LayerNorm that follows (zh_sum_layernorm_f32:
         # bias + residual + ln_2 / the next block's ln_1 in the same pass).  Same launch count, 4x the workgroups, no LN launch of its own.
+        st = self.status_word()
         s_out, s_proj = self._splitk(R, D, D), self._splitk(R, D, Fd)
         sk = self._x3("out") and self._x3("proj") and (s_out > 1 or s_proj > 1)
         parts = self._buf("sk_parts", (max(s_out, s_proj), R, D), f32) if sk else None
@@ -280,7 +310,7 @@ class _EngineBase:
         for i in range(n_layers):
             pp = f"enc.{i}."
             if not (sk and s_proj > 1 and i > 0):          # split-K regime: ln_1 of block i > 0 came out of block i - 1's last kernel
-                ops.layernorm(X, W_[pp + "ln1.w"], W_[pp + "ln1.b"], eps, R, D, out_f16=Y)
+                ops.layernorm(X, W_[pp + "ln1.w"], W_[pp + "ln1.b"], eps, R, D, out_f16=Y, status=st)
             self._gemm("qkv", Y, W_[pp + "qkv_w"], QKV, bias=W_[pp + "qkv_b"])
             ops.attention(q_, k_, v_, O, batch=B, heads=heads, Tq=T, Tk=T, head_dim=D // heads,
                           ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=T * 3 * D, strideK=T * 3 * D, strideV=T * 3 * D,
@@ -288,16 +318,17 @@ class _EngineBase:
             if sk and s_out > 1:
                 gemm_parts("out", O, W_[pp + "out_w"], s_out)
                 ops.sum_layernorm(parts, s_out, R, D, bias=W_[pp + "out_b"], residual=X, out_sum=X, gamma=W_[pp + "ln2.w"], beta=W_[pp + "ln2.b"],
-                                  eps=eps, out_f16=Y)
+                                  eps=eps, out_f16=Y, status=st)
             else:
                 self._gemm("out", O, W_[pp + "out_w"], X, bias=W_[pp + "out_b"], residual=X)
-                ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y)
+                ops.layernorm(X, W_[pp + "ln2.w"], W_[pp + "ln2.b"], eps, R, D, out_f16=Y, status=st)
             self._gemm("fc", Y, W_[pp + "fc_w"], Hh, bias=W_[pp + "fc_b"], act=act)
             if sk and s_proj > 1:
                 gemm_parts("proj", Hh, W_[pp + "proj_w"], s_proj)
                 nx = f"enc.{i + 1}." if i + 1 < n_layers else None
                 ops.sum_layernorm(parts, s_proj, R, D, bias=W_[pp + "proj_b"], residual=X, out_sum=X,
-                                  gamma=W_[nx + "ln1.w"] if nx else None, beta=W_[nx + "ln1.b"] if nx else None, eps=eps, out_f16=Y if nx else None)
+                                  gamma=W_[nx + "ln1.w"] if nx else None, beta=W_[nx + "ln1.b"] if nx else None, eps=eps, out_f16=Y if nx else None,
+                                  status=st)
             else:
                 self._gemm("proj", Hh, W_[pp + "proj_w"], X, bias=W_[pp + "proj_b"], residual=X)
 
@@ -338,6 +369,7 @@ class _EngineBase:
         of _decoder_kv.  Returns f16 rows with decoder.norm applied: every layer stacked as [B,L,Q,D] (stack_all) or the last
         layer only [B*Q, D]; the fp32 copy of the last layer's normed output is left in buffer "dec_out32"."""
         W_, dh, R = self._w, D // heads, B * Q
+        st = self.status_word()
         xd = self._x3("dec")
         Ff = P_shape0(W_["dec.0.l1_w"])
         xk = bool(KALL.plane)
@@ -377,7 +409,7 @@ class _EngineBase:
                           head_dim=dh, ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, strideQ=Q * 3 * D, strideK=Q * 3 * D, strideV=Q * 3 * D,
                           strideO=Q * D, x3=xd)
             self._gemm("dec", o16, W_[pp + "sa_o_w"], t1, bias=W_[pp + "sa_o_b"], residual=residual)
-            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=norm_out32, out_f16=norm_out16)
+            ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=norm_out32, out_f16=norm_out16, status=st)
         # tgt = zeros (zutis.py:164) and query_pos is a parameter, so layer 0's whole self-attention block — projections of
         # (0 + query_pos, 0), attention over the Q queries, out-projection, norm1 — does not depend on the image: its result
         # (tgt after norm1, fp32 and fp16; [R, D] = the same Q rows for every image) is computed once per (batch rows, parameter
@@ -402,7 +434,7 @@ class _EngineBase:
                           head_dim=dh, ldq=D, ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D,
                           strideO=Q * D, x3=xk, ksplit=ksplit, workspace=attn_ws)
             self._gemm("dec", o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt_in)
-            ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16)
+            ops.layernorm(t1, W_[pp + "norm2.w"], W_[pp + "norm2.b"], 1e-5, R, D, out_f32=tgt, out_f16=tgt16, status=st)
             self._gemm("dec", tgt16, W_[pp + "l1_w"], ff16, bias=W_[pp + "l1_b"], act=ops.ACT_RELU)
             # linear2 (:289-290; K = 2048): in the few-row regime its K is split over workgroups (a batched GEMM over K slabs) and the
             # planes meet in the LayerNorm below, with the bias and the residual (20.9 -> ~10 us for 100 queries)
@@ -422,7 +454,7 @@ class _EngineBase:
                           out2_offset=l * Q)
             elif l == L - 1:
                 n3.update(gamma2=W_["dec.norm.w"], beta2=W_["dec.norm.b"], eps2=1e-5, out2_f16=inter16, out2_f32=out32)
-            ops.sum_layernorm(src.pop("parts"), src.pop("n_parts"), R, D, **src, **n3)
+            ops.sum_layernorm(src.pop("parts"), src.pop("n_parts"), R, D, **src, **n3, status=st)
         return inter16
 
     cross_ksplit = int(os.environ.get("ZH_CROSS_KSPLIT", "1"))      # class default (env = developer override); instances may set it

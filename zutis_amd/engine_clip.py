@@ -51,7 +51,7 @@ class ClipImageEncoder(_EngineBase):
         X = self._clip_trunk(x.contiguous(), W_["encoder.positional_embedding"], h, w)
         cls16 = self._abuf("cls16", (B, D), self._x3("embed"))
         ops.layernorm(X, W_["encoder.ln_post.weight"], W_["encoder.ln_post.bias"], 1e-5, B, D, out_f16=cls16,
-                      in_group_rows=1, in_group_stride=1 + h * w, in_offset=0)              # ln_post(x[:, 0, :])
+                      in_group_rows=1, in_group_stride=1 + h * w, in_offset=0, status=self.status_word())              # ln_post(x[:, 0, :])
         e32 = self._buf("emb32", (B, self.E), f32)
         self._gemm("embed", cls16, W_["projT"], e32)                                        # @ proj
         out = torch.empty((B, self.E), dtype=f32, device=x.device)
@@ -98,7 +98,7 @@ class ClipTextEncoder(_EngineBase):
         eot = self._buf("eot", (n, D), f32)
         ops.eot_rows(tok, X, eot)                                                      # :545 (LN is row-wise: gather first)
         e16 = self._abuf("eot16", (n, D), self._x3("embed"))
-        ops.layernorm(eot, W_["lnf.w"], W_["lnf.b"], 1e-5, n, D, out_f16=e16)          # :541 ln_final
+        ops.layernorm(eot, W_["lnf.w"], W_["lnf.b"], 1e-5, n, D, out_f16=e16, status=self.status_word())          # :541 ln_final
         self._gemm("embed", e16, W_["projT"], out)                                     # @ text_projection
 
     def encode_text(self, tokens: torch.Tensor) -> torch.Tensor:

@@ -101,7 +101,7 @@ class SelfMaskEngine(_EngineBase):
         tok = self._buf("tok", (B, h * w, D), f32)
         tok16 = self._abuf("tok16", (B * h * w, D), self._x3("dec_kv"))
         ops.layernorm(X, W_["norm.w"], W_["norm.b"], 1e-6, B * h * w, D, out_f32=tok, out_f16=tok16,
-                      in_group_rows=h * w, in_group_stride=T, in_offset=1)               # norm(x)[:, 1:]  :298, selfmask.py:94-100
+                      in_group_rows=h * w, in_group_stride=T, in_offset=1, status=self.status_word())               # norm(x)[:, 1:]  :298, selfmask.py:94-100
         KALL, VALL = self._decoder_kv(tok16, tok16, B, h * w, D, L)                          # selfmask.py:110-116 (pos=None)
         q16 = self._decoder(KALL, VALL, B, h * w, D, Q, L, self.heads, stack_all=False)
         FEAT = self._abuf("FEAT16", (B * M, D), self._x3("mask"))

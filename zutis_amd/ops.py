@@ -266,9 +266,13 @@ def group_mean_l2norm(x, out, groups, T, E):
     _lib.check(L.zh_group_mean_l2norm(_p(x), _p(out), groups, T, E, _stream()), "zh_group_mean_l2norm")
 
 
+STATUS_RANGE, STATUS_NONFINITE = 1, 2        # bits of the status word (zutis_hip.h ZH_STATUS_*)
+UNIT_NORM_SCALE = 1024.0                     # f16_scale of the unit-norm producers (2^10): see zutis_hip.h
+
+
 def layernorm(x, gamma, beta, eps, rows, D, *, out_f32=None, out_f16=None, out_f16_plus=None, out_f32_plus=None,
               add=None, add_rows=0, in_group_rows=None, in_group_stride=None, in_offset=0,
-              out_group_rows=None, out_group_stride=None, out_offset=0):
+              out_group_rows=None, out_group_stride=None, out_offset=0, status=None):
     L = _lib.load()
     in_group_rows = rows if in_group_rows is None else in_group_rows
     in_group_stride = in_group_rows if in_group_stride is None else in_group_stride
@@ -281,12 +285,13 @@ def layernorm(x, gamma, beta, eps, rows, D, *, out_f32=None, out_f16=None, out_f
     _lib.check(L.zh_layernorm_f32(_p(x), in_group_rows, in_group_stride, in_offset,
                                   out_group_rows, out_group_stride, out_offset, _p(gamma), _p(beta), float(eps),
                                   _p(out_f32), _p(out_f16), _p(out_f16_plus), _p(out_f32_plus), _p(add), add_rows,
-                                  rows, D, lo_plane, _stream()), "zh_layernorm_f32")
+                                  rows, D, lo_plane, _p(status), _stream()), "zh_layernorm_f32")
 
 
 def sum_layernorm(parts, n_parts, rows, D, *, part_stride=None, bias=None, residual=None, out_sum=None, gamma=None, beta=None, eps=1e-5,
                   out_f32=None, out_f16=None, out_group_rows=None, out_group_stride=None, out_offset=0, skip_first_in_group=False,
-                  gamma2=None, beta2=None, eps2=1e-5, out2_f32=None, out2_f16=None, out2_group_rows=None, out2_group_stride=None, out2_offset=0):
+                  gamma2=None, beta2=None, eps2=1e-5, out2_f32=None, out2_f16=None, out2_group_rows=None, out2_group_stride=None, out2_offset=0,
+                  status=None):
     """x = sum of the n_parts fp32 planes of `parts` + bias + residual -> out_sum; LN(x) -> out_f32 / out_f16 (row-mapped); LN(LN(x)) with
     gamma2 / beta2 -> out2_* (zh_sum_layernorm_f32).  n_parts = 1 with no bias / residual is a plain (or chained) LayerNorm."""
     L = _lib.load()
@@ -299,7 +304,7 @@ def sum_layernorm(parts, n_parts, rows, D, *, part_stride=None, bias=None, resid
     _lib.check(L.zh_sum_layernorm_f32(_p(parts), n_parts, part_stride, _p(bias), _p(residual), _p(out_sum), _p(gamma), _p(beta), float(eps),
                                       _p(out_f32), _p(out_f16), lo1, ogr, ogs, out_offset, int(skip_first_in_group),
                                       _p(gamma2), _p(beta2), float(eps2), _p(out2_f32), _p(out2_f16), lo2, ogr2, ogs2, out2_offset,
-                                      rows, D, _stream()), "zh_sum_layernorm_f32")
+                                      rows, D, _p(status), _stream()), "zh_sum_layernorm_f32")
 
 
 def assemble_tokens_ln(patch_emb, cls, pos, gamma, beta, eps, out, B, T, D):
@@ -308,24 +313,32 @@ def assemble_tokens_ln(patch_emb, cls, pos, gamma, beta, eps, out, B, T, D):
                                        B, T, D, _stream()), "zh_assemble_tokens_ln")
 
 
+def _f16_scale(a) -> float:
+    """The factor a producer stores into Act `a` with: 1 / a.out_scale (a plain tensor or an unscaled Act: 1)."""
+    return 1.0 / a.out_scale if isinstance(a, Act) else 1.0
+
+
 def l2norm_rows(x, rows, D, out_f32=None, out_f16=None, eps=0.0):
+    """out_f16 may be an Act with out_scale = 2^-s: the fp16 / split-pair copy is then stored times 2^s (unit-norm rows: UNIT_NORM_SCALE)."""
     L = _lib.load()
+    sc = _f16_scale(out_f16)
     out_f16, lo = _hp(out_f16)
-    _lib.check(L.zh_l2norm_rows(_p(x), _p(out_f32), _p(out_f16), float(eps), rows, D, lo, _stream()), "zh_l2norm_rows")
+    _lib.check(L.zh_l2norm_rows(_p(x), _p(out_f32), _p(out_f16), float(eps), rows, D, lo, sc, _stream()), "zh_l2norm_rows")
 
 
 def global_ln_l2_workspace_size(B, M, Cc) -> int:
     return int(_lib.load(raw=True).zh_global_ln_l2_workspace_size(B, M, Cc))
 
 
-def global_ln_l2(x, B, M, Cc, out_f32=None, out_f16=None, eps=1e-5, l2_eps=1e-7, workspace=None):
+def global_ln_l2(x, B, M, Cc, out_f32=None, out_f16=None, eps=1e-5, l2_eps=1e-7, workspace=None, status=None):
     L = _lib.load()
     need = global_ln_l2_workspace_size(B, M, Cc)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    sc = _f16_scale(out_f16)
     out_f16, lo = _hp(out_f16)
     _lib.check(L.zh_global_ln_l2(_p(x), _p(out_f32), _p(out_f16), float(eps), float(l2_eps), B, M, Cc, _p(workspace),
-                                 workspace.numel() * workspace.element_size(), lo, _stream()), "zh_global_ln_l2")
+                                 workspace.numel() * workspace.element_size(), lo, sc, _p(status), _stream()), "zh_global_ln_l2")
 
 
 def im2col(x, out, patch, Kpad, pad_to_patch=False):
@@ -368,8 +381,9 @@ def fill_f32(x, value=0.0):
 
 def cast_f16(x, out, rows, D, add=None, add_rows=0):
     L = _lib.load()
+    sc = _f16_scale(out)
     out, lo = _hp(out)
-    _lib.check(L.zh_cast_f32_f16(_p(x), _p(add), add_rows, _p(out), rows, D, lo, _stream()), "zh_cast_f32_f16")
+    _lib.check(L.zh_cast_f32_f16(_p(x), _p(add), add_rows, _p(out), rows, D, lo, sc, _stream()), "zh_cast_f32_f16")
 
 
 def lin_scale(in_size: int, out_size: int) -> float:

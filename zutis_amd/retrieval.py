@@ -24,6 +24,9 @@ def _split_rows(x: torch.Tensor) -> Act:
     """fp32 [rows, E] on the GPU -> split-pair Act (one cast kernel)."""
     rows, E = x.shape
     a = Act.empty((rows, E), True, x.device)
+    # the embeddings are unit-norm rows (extract_image_embeddings.py:73, extract_text_embeddings.py:110-112: elements ~0.04): stored times
+    # 2^6 the lo halves of the pairs are normal fp16 numbers (the similarity GEMM multiplies 2^-12 back in); |x| < 1000 cannot overflow
+    a.out_scale = 1.0 / 64.0
     ops.cast_f16(x.detach().to(f32).contiguous(), a, rows, E)
     return a
 
