@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 218 /* 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 219 /* 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -306,12 +306,13 @@ int zh_mask_nms(const int* inter, const int* uni, const float* scores, const lon
  * [n_sel] mask indices): positions int32 [n_sel, max_runs] = column-major pixel indices where the value changes;
  * nruns int32 [n_sel,2] = {#transitions, value of pixel 0}; box_area int32 [n_sel,5] = {xmin,ymin,xmax,ymax,area}.
  * Replaces the mask D2H in front of pycocotools.mask.encode / masks_to_boxes, zutis.py:288-294,446-452. */
+size_t zh_mask_runs_workspace_size(int n, int W);   /* n = n_sel (zh_mask_runs) or B * Q (zh_mask_runs_kept): per-panel counts / boxes */
 int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, int W, int max_runs,
-                 int* positions, int* nruns, int* box_area, zh_stream_t stream);
+                 int* positions, int* nruns, int* box_area, void* workspace, size_t workspace_bytes, zh_stream_t stream);
 /* The same for the queries zh_mask_nms kept, straight from its device outputs (masks u8 [B,Q,H,W]; kept_index int32 [B,Q], kept_count
  * int32 [B]): row b*Q + j of positions / nruns / box_area describes image b's j-th kept mask; rows j >= kept_count[b] are not written. */
 int zh_mask_runs_kept(const unsigned char* masks, const int* kept_index, const int* kept_count, int B, int Q, int H, int W, int max_runs,
-                      int* positions, int* nruns, int* box_area, zh_stream_t stream);
+                      int* positions, int* nruns, int* box_area, void* workspace, size_t workspace_bytes, zh_stream_t stream);
 
 /* Native launch plans (zutis_amd/plan.py): replay n recorded calls of the entry points above (op id + 24 argument words
  * each; dispatcher generated from this header) in one C loop; zh_plan_run2 alternates two plans on two streams. */

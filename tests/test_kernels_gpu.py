@@ -488,8 +488,9 @@ def test_device_rle_matches_hand_derived_vectors(dev, golden_dir):
         assert areas[0] == int(m.sum())
 
 
+@pytest.mark.parametrize("Q", [100, 150])        # <= 128 candidates: the one-wave kernel; more: the block-wide one
 @pytest.mark.parametrize("nms_type", ["hard", "linear", "gaussian"])
-def test_device_mask_nms_matches_reference_control_flow(dev, nms_type):
+def test_device_mask_nms_matches_reference_control_flow(dev, nms_type, Q):
     """zh_mask_nms (one workgroup per image) against the oracle's restatement of ZUTIS.non_maximum_suppression
     (zutis.py:211-299) on random overlapping masks: same (category, query) emission order; scores equal (hard: exactly —
     only x1 / x0 products; linear / gaussian: float64 arithmetic, 1e-12)."""
@@ -497,7 +498,7 @@ def test_device_mask_nms_matches_reference_control_flow(dev, nms_type):
     from zutis_amd.engine import ZutisEngine
     from oracle import zutis_ref as O
     rng = np.random.default_rng(5)
-    B, Q, H, W = 3, 100, 48, 64
+    B, H, W = 3, 48, 64
     masks = np.zeros((B, Q, H, W), np.uint8)
     for b in range(B):
         for q in range(Q):

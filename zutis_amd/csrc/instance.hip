@@ -7,34 +7,62 @@
 // ---- per (image, query): size = #(p > thr), conf = sum(p * (p > thr)) / (size + 1e-7)   (zutis.py:390-397)
 // range_flag (optional): bit 0 is set when any proposal lies outside [0, 1] (or is a NaN) — the reference's two asserts on the
 // mask proposals (zutis.py:385-386), checked by the host at the predict's one synchronisation instead of with a reduction + copy of its own
+// One workgroup per (image, query) row, 4 pixels per thread and pass (round 4: a wave per row walked its 4800 pixels in 75 dependent
+// passes, 25 workgroups at batch 1: 26 us for 1.9 MB).  The sums are integers (counts) and a float sum whose order is fixed by the
+// shape: per thread ascending pixels, then the fixed tree of block_sum4.
+__device__ __forceinline__ float stats_block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
 __global__ __launch_bounds__(256) void instance_stats_kernel(const float* mp, long stride_b, float thr, long rows, int Q, int M,
                                                              float* sizes, float* conf, unsigned char* binary, int* range_flag) {
-  const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // r = b*Q + q
-  if (r >= rows) return;
+  __shared__ float red[4];
+  const long r = blockIdx.x;                                      // r = b*Q + q
   const int b = (int)(r / Q), q = (int)(r % Q);
   const float* p = mp + (long)b * stride_b + (long)q * M;
+  unsigned char* bo = binary + r * M;
   float cnt = 0.f, s = 0.f;
   bool bad = false;
-  for (int m = lane; m < M; m += 64) {
-    const float v = p[m];
-    bad |= !(v >= 0.f && v <= 1.f);
-    const bool on = v > thr;
-    cnt += on ? 1.f : 0.f;
-    s += on ? v : 0.f;
-    binary[r * M + m] = on ? 1 : 0;
+  const bool vec = (M % 4 == 0) && ((((uintptr_t)p) & 15) == 0) && ((((uintptr_t)bo) & 3) == 0);
+  if (vec) {
+    for (int m = threadIdx.x * 4; m < M; m += 1024) {
+      const f32x4 v = *(const f32x4*)(p + m);
+      unsigned pk = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bad |= !(v[e] >= 0.f && v[e] <= 1.f);
+        const bool on = v[e] > thr;
+        cnt += on ? 1.f : 0.f;
+        s += on ? v[e] : 0.f;
+        pk |= (on ? 1u : 0u) << (8 * e);
+      }
+      *(unsigned*)(bo + m) = pk;
+    }
+  } else {
+    for (int m = threadIdx.x; m < M; m += 256) {
+      const float v = p[m];
+      bad |= !(v >= 0.f && v <= 1.f);
+      const bool on = v > thr;
+      cnt += on ? 1.f : 0.f;
+      s += on ? v : 0.f;
+      bo[m] = on ? 1 : 0;
+    }
   }
-  cnt = wave_sum(cnt);
-  s = wave_sum(s);
-  if (lane == 0) { sizes[r] = cnt; conf[r] = s / (cnt + 1e-7f); }
-  if (range_flag && __ballot(bad) != 0ull && lane == 0) atomicOr(range_flag, 1);
+  cnt = stats_block_sum(cnt, red);
+  s = stats_block_sum(s, red);
+  if (threadIdx.x == 0) { sizes[r] = cnt; conf[r] = s / (cnt + 1e-7f); }
+  if (range_flag && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
 }
 
 extern "C" int zh_instance_mask_stats(const float* mask_proposals, long stride_image, float threshold, int B, int Q, int M,
                                       float* sizes, float* confidence, unsigned char* binary, int* range_flag, hipStream_t stream) {
   ZH_CHECK_ARG(mask_proposals && sizes && confidence && binary && B > 0 && Q > 0 && M > 0, "zh_instance_mask_stats: bad arguments");
   const long rows = (long)B * Q;
-  hipLaunchKernelGGL(instance_stats_kernel, dim3(zh_cdiv(rows, 4)), dim3(256), 0, stream, mask_proposals, stride_image, threshold, rows, Q, M,
+  ZH_CHECK_ARG(rows < (1L << 31), "zh_instance_mask_stats: too many rows");
+  hipLaunchKernelGGL(instance_stats_kernel, dim3((unsigned)rows), dim3(256), 0, stream, mask_proposals, stride_image, threshold, rows, Q, M,
                      sizes, confidence, binary, range_flag);
   ZH_CHECK_LAUNCH("zh_instance_mask_stats");
   return ZH_OK;
@@ -213,26 +241,52 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const unsigned char* mas
   packed[idx] = bits;
 }
 
+// A block = a 4 x 4 tile of mask pairs (i0 .. i0+3) x (j0 .. j0+3), tiles on or above the diagonal: a pass loads eight 64-bit words
+// per thread for sixteen (intersection, union) popcounts (round 4: one block per pair loaded two words per popcount pair, 390 MB of L2
+// reads for 100 masks of 480 x 640: 30 us).  Integer sums: any order gives the same counts.
+#define IOU_T 4
 __global__ __launch_bounds__(256) void mask_iou_counts_kernel(const unsigned long long* packed, int n, long W64, int* inter, int* uni) {
-  const int i = blockIdx.x, j = blockIdx.y;
-  if (j < i) return;
-  const unsigned long long* a = packed + (long)i * W64;
-  const unsigned long long* b = packed + (long)j * W64;
-  int ci = 0, cu = 0;
-  for (long w = threadIdx.x; w < W64; w += 256) {
-    const unsigned long long x = a[w], y = b[w];
-    ci += __popcll(x & y);
-    cu += __popcll(x | y);
-  }
-  __shared__ int ri[4], ru[4];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (tj < ti) return;
+  const int i0 = ti * IOU_T, j0 = tj * IOU_T;
+  int ci[IOU_T][IOU_T], cu[IOU_T][IOU_T];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o, 64); cu += __shfl_xor(cu, o, 64); }
-  if ((threadIdx.x & 63) == 0) { ri[threadIdx.x >> 6] = ci; ru[threadIdx.x >> 6] = cu; }
+  for (int a = 0; a < IOU_T; ++a)
+#pragma unroll
+    for (int b = 0; b < IOU_T; ++b) { ci[a][b] = 0; cu[a][b] = 0; }
+  for (long w = threadIdx.x; w < W64; w += 256) {
+    unsigned long long x[IOU_T], y[IOU_T];
+#pragma unroll
+    for (int a = 0; a < IOU_T; ++a) {
+      x[a] = packed[(long)min(i0 + a, n - 1) * W64 + w];
+      y[a] = packed[(long)min(j0 + a, n - 1) * W64 + w];
+    }
+#pragma unroll
+    for (int a = 0; a < IOU_T; ++a)
+#pragma unroll
+      for (int b = 0; b < IOU_T; ++b) { ci[a][b] += __popcll(x[a] & y[b]); cu[a][b] += __popcll(x[a] | y[b]); }
+  }
+  __shared__ int red[4][2 * IOU_T * IOU_T];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < IOU_T; ++a)
+#pragma unroll
+    for (int b = 0; b < IOU_T; ++b) {
+      int v = ci[a][b], u = cu[a][b];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); u += __shfl_xor(u, o, 64); }
+      if (lane == 0) { red[wave][2 * (a * IOU_T + b)] = v; red[wave][2 * (a * IOU_T + b) + 1] = u; }
+    }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int I = ri[0] + ri[1] + ri[2] + ri[3], U = ru[0] + ru[1] + ru[2] + ru[3];
-    inter[(long)i * n + j] = I; inter[(long)j * n + i] = I;
-    uni[(long)i * n + j] = U; uni[(long)j * n + i] = U;
+  if (threadIdx.x < IOU_T * IOU_T) {
+    const int a = threadIdx.x / IOU_T, b = threadIdx.x % IOU_T;
+    const int i = i0 + a, j = j0 + b;
+    if (i < n && j < n) {
+      const int k = 2 * (a * IOU_T + b);
+      const int I = red[0][k] + red[1][k] + red[2][k] + red[3][k], U = red[0][k + 1] + red[1][k + 1] + red[2][k + 1] + red[3][k + 1];
+      inter[(long)i * n + j] = I; inter[(long)j * n + i] = I;
+      uni[(long)i * n + j] = U; uni[(long)j * n + i] = U;
+    }
   }
 }
 
@@ -247,7 +301,8 @@ extern "C" int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels
     return ZH_ERR_WORKSPACE;
   }
   hipLaunchKernelGGL(mask_pack_kernel, dim3(zh_cdiv((long)n * W64, 256)), dim3(256), 0, stream, masks, (unsigned long long*)workspace, pixels, W64, (long)n * W64);
-  hipLaunchKernelGGL(mask_iou_counts_kernel, dim3(n, n), dim3(256), 0, stream, (const unsigned long long*)workspace, n, W64, inter, uni);
+  const int nt = zh_cdiv(n, IOU_T);
+  hipLaunchKernelGGL(mask_iou_counts_kernel, dim3(nt, nt), dim3(256), 0, stream, (const unsigned long long*)workspace, n, W64, inter, uni);
   ZH_CHECK_LAUNCH("zh_mask_iou_counts");
   return ZH_OK;
 }
@@ -257,15 +312,15 @@ extern "C" int zh_mask_iou_counts(const unsigned char* masks, int n, long pixels
 //      the mask is cut into 64-column panels staged through LDS (coalesced row reads); the value changes per column segment are
 //      counted, prefix-summed, and the column-major pixel positions where the value changes are written.
 //      counts = diff([0, positions..., H*W]) with a leading 0-run inserted when pixel 0 is set (host, tiny).
-// One block per (mask, 64-column panel) — round 3: one block per mask walked its 480 x 640 pixels with one thread per column, twice,
-// 17 blocks on 256 CUs: 194 us, a sixth of the batch-1 instance predict.  A panel's block
-//   1. counts the transitions in the columns LEFT of its panel straight from global memory, row-major and coalesced (a vertical
-//      transition is a difference between a row and the row above it; plus the H-1 -> 0 wrap between neighbouring columns): the
-//      offset of its first run in the mask's position list, no workspace and no second launch;
-//   2. stages its panel [H][64] in LDS, four threads per column (a quarter of the rows each) count their segment's transitions,
-//      a 256-entry scan in (column, segment) order places them, a second walk writes the column-major positions;
-//   3. the block of the LAST panel also knows the total; the block of the FIRST panel (nothing to its left) scans the whole mask once
-//      more (row-major) for the box and the area.
+// One block per (mask, 64-column panel), TWO launches (round 4).  Round 3's single launch had every panel's block count the transitions of
+// ALL columns left of its panel from global memory (the last panel re-read 90 % of the mask) and the first panel's block scan the whole
+// mask once more for the box and the area: 55 us for 17 kept masks of 480 x 640, the critical path being those two long blocks.  Now
+//   launch 1 (count): a block stages its panel [H][64] in LDS (coalesced row reads), four threads per column count the transitions of
+//                     their quarter of the rows (the H-1 -> 0 wrap to the previous column included), and the panel's own pixels give its
+//                     part of the box / area: per-panel results into a small table;
+//   launch 2 (emit):  a block sums the counts of the panels to its left (<= W / 64 integers), stages its panel again, a 256-entry scan
+//                     in (column, segment) order places its transitions and a second walk writes the column-major positions; the
+//                     last panel's block writes the total, the first one folds the per-panel boxes / areas.
 #define RUNS_PANEL 64
 #define RUNS_SEG 4
 __device__ __forceinline__ unsigned zh_nz_bytes(unsigned w) {   // 0x01 in every byte of w that is non-zero
@@ -274,40 +329,18 @@ __device__ __forceinline__ unsigned zh_nz_bytes(unsigned w) {   // 0x01 in every
 }
 // count != NULL (zh_mask_runs_kept): entry mi = b * Q + j is the j-th kept query of image b — sel[mi] is its query index (zh_mask_nms'
 // out_index), entries j >= count[b] do nothing: the NMS result never visits the host before the runs are extracted.
-__global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* masks, const int* sel, const int* count, int Q, int H, int W, int max_runs,
-                                                        int* positions, int* nruns, int* box_area) {
-  extern __shared__ unsigned char sm[];                    // [H][64] panel
-  __shared__ int s_red[256];
-  __shared__ int s_minx, s_maxx, s_miny, s_maxy, s_area;
-  const int tid = threadIdx.x, mi = blockIdx.x, pnl = blockIdx.y;
-  if (count && mi % Q >= count[mi / Q]) return;           // whole workgroup, before any barrier
-  const unsigned char* m = masks + (count ? (long)(mi / Q) * Q + sel[mi] : (long)sel[mi]) * H * W;
-  int* pos = positions + (long)mi * max_runs;
-  const int x0 = pnl * RUNS_PANEL, pw = min(RUNS_PANEL, W - x0);
+struct RunsArgs {
+  const unsigned char* masks; const int* sel; const int* count; int Q, H, W, max_runs, npanel;
+  int* positions; int* nruns; int* box_area;
+  int* pcount;       // [n][npanel] transitions per panel
+  int* pbox;         // [n][npanel][5] xmin, ymin, xmax, ymax, area of the panel's pixels
+};
+// stages the panel (values normalised to {0,1}) and returns, per thread = (column c = tid / 4, row quarter sg = tid % 4), the number of
+// transitions of its segment and the value in front of it
+__device__ __forceinline__ int runs_stage_and_count(const RunsArgs& a, const unsigned char* m, unsigned char* sm, int x0, int pw, int& y0, int& y1,
+                                                    unsigned char& prev0) {
+  const int tid = threadIdx.x, H = a.H, W = a.W;
   const bool vec = (W % 16 == 0) && (((uintptr_t)m & 15) == 0);
-  // ---- 1. transitions in columns [0, x0)
-  int cnt = 0;
-  if (x0 > 0) {
-    if (vec) {                                             // x0 % 64 == 0: whole 16-column chunks
-      const int cpr = x0 / 16;
-#pragma unroll 8
-      for (int i = tid; i < (H - 1) * cpr; i += 256) {              // independent iterations: eight pairs of loads in flight
-        const int y = 1 + i / cpr, c16 = i % cpr;
-        const uint4 a = *(const uint4*)(m + (long)y * W + c16 * 16), b = *(const uint4*)(m + (long)(y - 1) * W + c16 * 16);
-        cnt += __popc(zh_nz_bytes(a.x) ^ zh_nz_bytes(b.x)) + __popc(zh_nz_bytes(a.y) ^ zh_nz_bytes(b.y)) +
-               __popc(zh_nz_bytes(a.z) ^ zh_nz_bytes(b.z)) + __popc(zh_nz_bytes(a.w) ^ zh_nz_bytes(b.w));
-      }
-    } else {
-      for (long i = tid; i < (long)(H - 1) * x0; i += 256) {
-        const int y = 1 + (int)(i / x0), x = (int)(i % x0);
-        cnt += (m[(long)y * W + x] != 0) != (m[(long)(y - 1) * W + x] != 0);
-      }
-    }
-    for (int x = 1 + tid; x < x0; x += 256)                // the wrap from the bottom of column x - 1 to the top of column x
-      cnt += (m[x] != 0) != (m[(long)(H - 1) * W + x - 1] != 0);
-  }
-  s_red[tid] = cnt;
-  // ---- 2. the panel
   if (vec && pw % 16 == 0) {
     constexpr int cpr = RUNS_PANEL / 16;
 #pragma unroll 8
@@ -325,16 +358,10 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
     }
   }
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {                   // block sum of the left-hand count
-    if (tid < st) s_red[tid] += s_red[tid + st];
-    __syncthreads();
-  }
-  const int base = s_red[0];
-  __syncthreads();
-  // thread = (column c, segment sg) in the order the positions are emitted: entry e = c * RUNS_SEG + sg == tid
   const int c = tid / RUNS_SEG, sg = tid % RUNS_SEG;
-  const int hs = (H + RUNS_SEG - 1) / RUNS_SEG, y0 = min(H, sg * hs), y1 = min(H, y0 + hs);
-  unsigned char prev0 = 0;
+  const int hs = (H + RUNS_SEG - 1) / RUNS_SEG;
+  y0 = min(H, sg * hs); y1 = min(H, y0 + hs);
+  prev0 = 0;
   int mine = 0;
   if (c < pw && y0 < y1) {
     if (y0 > 0) prev0 = sm[(y0 - 1) * RUNS_PANEL + c];
@@ -348,9 +375,51 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
       prev = v;
     }
   }
+  return mine;
+}
+__device__ __forceinline__ const unsigned char* runs_mask(const RunsArgs& a, int mi) {
+  return a.masks + (a.count ? (long)(mi / a.Q) * a.Q + a.sel[mi] : (long)a.sel[mi]) * a.H * a.W;
+}
+__global__ __launch_bounds__(256) void mask_runs_count_kernel(RunsArgs a) {
+  extern __shared__ unsigned char sm[];                    // [H][64] panel
+  __shared__ int s_cnt, s_minx, s_maxx, s_miny, s_maxy, s_area;
+  const int tid = threadIdx.x, mi = blockIdx.x, pnl = blockIdx.y;
+  if (a.count && mi % a.Q >= a.count[mi / a.Q]) return;   // whole workgroup, before any barrier
+  const unsigned char* m = runs_mask(a, mi);
+  const int x0 = pnl * RUNS_PANEL, pw = min(RUNS_PANEL, a.W - x0);
+  if (tid == 0) { s_cnt = 0; s_minx = a.W; s_maxx = -1; s_miny = a.H; s_maxy = -1; s_area = 0; }
+  int y0, y1; unsigned char prev0;
+  const int mine = runs_stage_and_count(a, m, sm, x0, pw, y0, y1, prev0);   // (contains the barrier that publishes the initial values)
+  // box / area of the panel's own pixels: thread = (column, row quarter)
+  const int c = tid / RUNS_SEG;
+  int area = 0, miny = a.H, maxy = -1;
+  if (c < pw)
+    for (int y = y0; y < y1; ++y)
+      if (sm[y * RUNS_PANEL + c]) { ++area; miny = min(miny, y); maxy = max(maxy, y); }
+  if (mine) atomicAdd(&s_cnt, mine);
+  if (area) { atomicAdd(&s_area, area); atomicMin(&s_minx, x0 + c); atomicMax(&s_maxx, x0 + c); atomicMin(&s_miny, miny); atomicMax(&s_maxy, maxy); }
+  __syncthreads();
+  if (tid == 0) {
+    a.pcount[(long)mi * a.npanel + pnl] = s_cnt;
+    int* b = a.pbox + ((long)mi * a.npanel + pnl) * 5;
+    b[0] = s_minx; b[1] = s_miny; b[2] = s_maxx; b[3] = s_maxy; b[4] = s_area;
+  }
+}
+__global__ __launch_bounds__(256) void mask_runs_emit_kernel(RunsArgs a) {
+  extern __shared__ unsigned char sm[];
+  __shared__ int s_red[256];
+  const int tid = threadIdx.x, mi = blockIdx.x, pnl = blockIdx.y;
+  if (a.count && mi % a.Q >= a.count[mi / a.Q]) return;
+  const unsigned char* m = runs_mask(a, mi);
+  int* pos = a.positions + (long)mi * a.max_runs;
+  const int x0 = pnl * RUNS_PANEL, pw = min(RUNS_PANEL, a.W - x0);
+  int base = 0;
+  for (int p = 0; p < pnl; ++p) base += a.pcount[(long)mi * a.npanel + p];
+  int y0, y1; unsigned char prev0;
+  const int mine = runs_stage_and_count(a, m, sm, x0, pw, y0, y1, prev0);
   s_red[tid] = mine;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {                      // inclusive scan (Hillis - Steele)
+  for (int d = 1; d < 256; d <<= 1) {                      // inclusive scan (Hillis - Steele), entry e = column * RUNS_SEG + segment == tid
     const int t = tid >= d ? s_red[tid - d] : 0;
     __syncthreads();
     s_red[tid] += t;
@@ -358,87 +427,69 @@ __global__ __launch_bounds__(256) void mask_runs_kernel(const unsigned char* mas
   }
   const int total = base + s_red[255];
   if (mine) {
+    const int c = tid / RUNS_SEG;
     int o = base + s_red[tid] - mine;
     unsigned char prev = prev0;
 #pragma unroll 8
     for (int y = y0; y < y1; ++y) {
       const unsigned char v = sm[y * RUNS_PANEL + c];
-      if (v != prev) { if (o < max_runs) pos[o] = (x0 + c) * H + y; ++o; }
+      if (v != prev) { if (o < a.max_runs) pos[o] = (x0 + c) * a.H + y; ++o; }
       prev = v;
     }
   }
-  // ---- 3. the total (known to the last panel's block); box and area from one more row-major scan of the whole mask — by the
-  //         FIRST panel's block, which had no columns to its left to count (the last one had all of them)
-  if (pnl == (int)gridDim.y - 1 && tid == 0) {
-    nruns[mi * 2] = total;                                 // number of transitions (may exceed max_runs => host fallback)
-    nruns[mi * 2 + 1] = m[0] != 0;                         // value of pixel 0
+  if (pnl == a.npanel - 1 && tid == 0) {
+    a.nruns[mi * 2] = total;                               // number of transitions (may exceed max_runs => host fallback)
+    a.nruns[mi * 2 + 1] = m[0] != 0;                       // value of pixel 0
   }
-  if (pnl != 0) return;
-  if (tid == 0) { s_minx = W; s_maxx = -1; s_miny = H; s_maxy = -1; s_area = 0; }
-  __syncthreads();
-  int area = 0, minx = W, maxx = -1, miny = H, maxy = -1;
-  if (vec) {
-    const int cpr = W / 16;
-#pragma unroll 8
-    for (int i = tid; i < H * cpr; i += 256) {
-      const int y = i / cpr, c16 = i - y * cpr;
-      const uint4 v = *(const uint4*)(m + (long)y * W + c16 * 16);
-      const unsigned w4[4] = {zh_nz_bytes(v.x), zh_nz_bytes(v.y), zh_nz_bytes(v.z), zh_nz_bytes(v.w)};
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (w4[k]) {
-          area += __popc(w4[k]);
-          const int xb = c16 * 16 + k * 4;
-          minx = min(minx, xb + (__ffs(w4[k]) - 1) / 8);
-          maxx = max(maxx, xb + (31 - __clz(w4[k])) / 8);
-          miny = min(miny, y); maxy = max(maxy, y);
-        }
+  if (pnl == 0 && tid == 0) {                              // fold the per-panel boxes / areas
+    int minx = a.W, miny = a.H, maxx = -1, maxy = -1, area = 0;
+    for (int p = 0; p < a.npanel; ++p) {
+      const int* b = a.pbox + ((long)mi * a.npanel + p) * 5;
+      minx = min(minx, b[0]); miny = min(miny, b[1]); maxx = max(maxx, b[2]); maxy = max(maxy, b[3]); area += b[4];
     }
-  } else {
-    for (long i = tid; i < (long)H * W; i += 256) {
-      if (m[i]) {
-        const int y = (int)(i / W), x = (int)(i % W);
-        ++area; minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
-      }
-    }
-  }
-  if (area) {
-    atomicAdd(&s_area, area); atomicMin(&s_minx, minx); atomicMax(&s_maxx, maxx); atomicMin(&s_miny, miny); atomicMax(&s_maxy, maxy);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int* b = box_area + mi * 5;
-    b[0] = s_minx; b[1] = s_miny; b[2] = s_maxx; b[3] = s_maxy; b[4] = s_area;
+    int* o = a.box_area + mi * 5;
+    o[0] = minx; o[1] = miny; o[2] = maxx; o[3] = maxy; o[4] = area;
   }
 }
 
+static int launch_mask_runs(const char* what, RunsArgs a, int n, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const size_t lds = ((size_t)a.H * RUNS_PANEL + 15) & ~(size_t)15;
+  ZH_CHECK_ARG(lds <= 150 * 1024, "%s: H=%d too tall for the LDS panel", what, a.H);
+  a.npanel = zh_cdiv(a.W, RUNS_PANEL);
+  ZH_CHECK_ARG(a.npanel <= 65535, "%s: mask too wide", what);
+  const size_t need = (size_t)n * a.npanel * 6 * sizeof(int);
+  if (!workspace || workspace_bytes < need) {
+    zh_set_error("%s: workspace too small (%zu < %zu)", what, workspace_bytes, need);
+    return ZH_ERR_WORKSPACE;
+  }
+  a.pcount = (int*)workspace;
+  a.pbox = a.pcount + (size_t)n * a.npanel;
+  if (lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)mask_runs_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)mask_runs_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  hipLaunchKernelGGL(mask_runs_count_kernel, dim3(n, a.npanel), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(mask_runs_emit_kernel, dim3(n, a.npanel), dim3(256), lds, stream, a);
+  ZH_CHECK_LAUNCH(what);
+  return ZH_OK;
+}
+extern "C" size_t zh_mask_runs_workspace_size(int n, int W) { return (size_t)n * zh_cdiv(W, RUNS_PANEL) * 6 * sizeof(int); }
+
 extern "C" int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, int W, int max_runs,
-                            int* positions, int* nruns, int* box_area, hipStream_t stream) {
+                            int* positions, int* nruns, int* box_area, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   ZH_CHECK_ARG(masks && sel && positions && nruns && box_area && n_sel > 0 && H > 0 && W > 0 && max_runs > 0, "zh_mask_runs: bad arguments");
   ZH_CHECK_ARG((long)H * W < (1L << 31), "zh_mask_runs: mask too large");
-  const size_t lds = ((size_t)H * RUNS_PANEL + 15) & ~(size_t)15;
-  ZH_CHECK_ARG(lds <= 150 * 1024, "zh_mask_runs: H=%d too tall for the LDS panel", H);
-  const int npanel = zh_cdiv(W, RUNS_PANEL);
-  ZH_CHECK_ARG(npanel <= 65535, "zh_mask_runs: mask too wide");
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(mask_runs_kernel, dim3(n_sel, npanel), dim3(256), lds, stream, masks, sel, (const int*)nullptr, 1, H, W, max_runs, positions, nruns, box_area);
-  ZH_CHECK_LAUNCH("zh_mask_runs");
-  return ZH_OK;
+  RunsArgs a{masks, sel, nullptr, 1, H, W, max_runs, 0, positions, nruns, box_area, nullptr, nullptr};
+  return launch_mask_runs("zh_mask_runs", a, n_sel, workspace, workspace_bytes, stream);
 }
 
 extern "C" int zh_mask_runs_kept(const unsigned char* masks, const int* kept_index, const int* kept_count, int B, int Q, int H, int W, int max_runs,
-                                 int* positions, int* nruns, int* box_area, hipStream_t stream) {
+                                 int* positions, int* nruns, int* box_area, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   ZH_CHECK_ARG(masks && kept_index && kept_count && positions && nruns && box_area && B > 0 && Q > 0 && H > 0 && W > 0 && max_runs > 0,
                "zh_mask_runs_kept: bad arguments");
   ZH_CHECK_ARG((long)H * W < (1L << 31) && (long)B * Q < (1L << 31), "zh_mask_runs_kept: mask / batch too large");
-  const size_t lds = ((size_t)H * RUNS_PANEL + 15) & ~(size_t)15;
-  ZH_CHECK_ARG(lds <= 150 * 1024, "zh_mask_runs_kept: H=%d too tall for the LDS panel", H);
-  const int npanel = zh_cdiv(W, RUNS_PANEL);
-  ZH_CHECK_ARG(npanel <= 65535, "zh_mask_runs_kept: mask too wide");
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(mask_runs_kernel, dim3(B * Q, npanel), dim3(256), lds, stream, masks, kept_index, kept_count, Q, H, W, max_runs, positions, nruns, box_area);
-  ZH_CHECK_LAUNCH("zh_mask_runs_kept");
-  return ZH_OK;
+  RunsArgs a{masks, kept_index, kept_count, Q, H, W, max_runs, 0, positions, nruns, box_area, nullptr, nullptr};
+  return launch_mask_runs("zh_mask_runs_kept", a, B * Q, workspace, workspace_bytes, stream);
 }
 
 // ---- greedy per-category mask NMS on the device (networks/zutis.py:211-299, copy at coco20k_eval.py:54-136).
@@ -549,6 +600,95 @@ __global__ __launch_bounds__(256) void mask_nms_kernel(const int* inter, const i
   }
 }
 
+// The same loop for Q <= NMS_WAVE_MAXQ candidates with ONE wave per image doing the selection (round 4).  The block-wide form above
+// spends its time in __syncthreads: ~11 per selection step (an 8-level argmax tree + 3), ~100 steps for the COCO-20K fixture: 52 us for
+// 100 candidates.  Here the whole workgroup first turns the image's integer counts into the Q x Q float64 IoU table in LDS (one
+// division per pair, done once, in parallel: the table replaces two loads and a float64 division per candidate and step) and notes which
+// masks are empty; then wave 0 alone runs the loop: a lane owns candidates lane, lane + 64, the argmax is six rounds of lane shuffles on
+// (score, index) keys, no barrier.  Same arithmetic (float64 scores, IoU = inter / (union + 1e-7) in float64), same tie rule (largest
+// index among equal maxima), same emission order.
+#define NMS_WAVE_MAXQ 128
+__global__ __launch_bounds__(256) void mask_nms_wave_kernel(const int* inter, const int* uni, const float* scores, const long long* cats,
+                                                            int Q, int nms_type, double thr, double sigma, double score_thr,
+                                                            int* out_idx, double* out_score, long long* out_cat, int* out_count,
+                                                            double* packed, const int* range_flag) {
+  extern __shared__ double s_iou[];                          // [Q][Q] IoU, then [Q] scores of the kept, [Q] (as int) indices / categories
+  __shared__ unsigned char s_empty[NMS_WAVE_MAXQ];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  inter += (long)img * Q * Q; uni += (long)img * Q * Q;
+  scores += (long)img * Q; cats += (long)img * Q;
+  out_idx += (long)img * Q; out_score += (long)img * Q; out_cat += (long)img * Q;
+  for (int i = tid; i < Q * Q; i += 256) s_iou[i] = (double)inter[i] / ((double)uni[i] + 1e-7);
+  for (int q = tid; q < Q; q += 256) s_empty[q] = inter[q * Q + q] <= 0;       // area of the mask = |m & m|: empty masks are not emitted
+  __syncthreads();
+  if (tid >= 64) return;                                      // wave 0 selects
+  constexpr int PL = NMS_WAVE_MAXQ / 64;                     // candidates per lane
+  long long cat[PL];
+  double sc[PL];
+  bool act[PL];
+#pragma unroll
+  for (int e = 0; e < PL; ++e) { const int q = lane + 64 * e; cat[e] = q < Q ? cats[q] : 0; }
+  int n_out = 0;
+  long long cur = 0;                                          // categories <= 0 are never processed (0 = background)
+  for (;;) {
+    long long mine = 0x7FFFFFFFFFFFFFFFll;
+#pragma unroll
+    for (int e = 0; e < PL; ++e)
+      if (cat[e] > cur && cat[e] < mine) mine = cat[e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(mine, o, 64); mine = t < mine ? t : mine; }
+    if (mine == 0x7FFFFFFFFFFFFFFFll) break;
+    cur = mine;
+#pragma unroll
+    for (int e = 0; e < PL; ++e) { const int q = lane + 64 * e; act[e] = q < Q && cat[e] == cur; sc[e] = q < Q ? (double)scores[q] : 0.0; }
+    for (;;) {
+      double bv = -1.0; int bi = -1;                          // key = (score, index): equal maxima resolve to the largest index
+#pragma unroll
+      for (int e = 0; e < PL; ++e) {
+        const int q = lane + 64 * e;
+        if (act[e] && (sc[e] > bv || (sc[e] == bv && q > bi))) { bv = sc[e]; bi = q; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+      }
+      if (bi < 0) break;
+      const int best = bi;
+      if (!s_empty[best]) {
+        if (lane == 0) { out_idx[n_out] = best; out_score[n_out] = bv; out_cat[n_out] = cur; }
+        ++n_out;
+      }
+#pragma unroll
+      for (int e = 0; e < PL; ++e) {
+        const int q = lane + 64 * e;
+        if (q == best) act[e] = false;
+        if (!act[e]) continue;
+        const double iou = s_iou[q * Q + best];
+        double v = sc[e];
+        if (nms_type == 0) { if (iou > thr) v = v * 0.0; }
+        else if (nms_type == 1) { if (iou > thr) v = v * (1.0 - iou); }
+        else v = v * exp(-(iou * iou) / sigma);
+        sc[e] = v;
+        if (!(v > score_thr)) act[e] = false;
+      }
+    }
+  }
+  if (lane == 0) out_count[img] = n_out;
+  if (packed) {
+    __builtin_amdgcn_s_waitcnt(0);                           // lane 0's global stores above, re-read below by the other lanes of this wave
+    __threadfence_block();
+    double* row = packed + (long)img * (4 * Q + 2);
+    for (int q = lane; q < Q; q += 64) {
+      row[q] = q < n_out ? (double)out_idx[q] : -1.0;
+      row[Q + q] = q < n_out ? out_score[q] : 0.0;
+      row[2 * Q + q] = q < n_out ? (double)out_cat[q] : 0.0;
+      row[3 * Q + q] = (double)cats[q];
+    }
+    if (lane == 0) { row[4 * Q] = (double)n_out; row[4 * Q + 1] = range_flag ? (double)*range_flag : 0.0; }
+  }
+}
+
 extern "C" int zh_mask_nms(const int* inter, const int* uni, const float* scores, const long long* category_ids, int B, int Q,
                            int nms_type, double nms_threshold, double sigma, double score_threshold,
                            int* out_index, double* out_score, long long* out_category, int* out_count, double* packed, const int* range_flag,
@@ -557,6 +697,12 @@ extern "C" int zh_mask_nms(const int* inter, const int* uni, const float* scores
                "zh_mask_nms: null pointer");
   ZH_CHECK_ARG(B > 0 && Q > 0 && Q <= NMS_MAXQ, "zh_mask_nms: need 0 < Q <= %d", NMS_MAXQ);
   ZH_CHECK_ARG(nms_type >= 0 && nms_type <= 2, "zh_mask_nms: nms_type %d not in {0 hard, 1 linear, 2 gaussian}", nms_type);
+  if (Q <= NMS_WAVE_MAXQ) {
+    const size_t lds = (size_t)Q * Q * sizeof(double);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_nms_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mask_nms_wave_kernel, dim3(B), dim3(256), lds, stream, inter, uni, scores, category_ids, Q, nms_type, nms_threshold, sigma,
+                       score_threshold, out_index, out_score, out_category, out_count, packed, range_flag);
+  } else
   hipLaunchKernelGGL(mask_nms_kernel, dim3(B), dim3(256), 0, stream, inter, uni, scores, category_ids, Q, nms_type, nms_threshold, sigma,
                      score_threshold, out_index, out_score, out_category, out_count, packed, range_flag);
   ZH_CHECK_LAUNCH("zh_mask_nms");

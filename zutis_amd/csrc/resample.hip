@@ -444,28 +444,38 @@ __global__ __launch_bounds__(256) void bilinear_nchw_kernel(const float* x, floa
   if (out) out[idx] = v;
   if (mask) mask[idx] = v > threshold ? 1 : 0;
 }
-// The thresholded-mask form at W % 4 == 0 (instance masks, zutis.py:422-423: 100 planes of 480 x 640 at batch 1): one block row per
-// output row — the row's weights are computed once, no 64-bit index divisions per pixel (the flat kernel above spent 74 us on
-// them for 31 M pixels) — and 4 pixels per thread leave as one 32-bit store.  Same arithmetic per pixel, bit-identical masks.
+// The thresholded-mask form at W % 4 == 0 (instance masks, zutis.py:422-423: 100 planes of 480 x 640 at batch 1): a block covers
+// MASK_ROWS output rows of a plane — the column weights of a thread's 4 pixels are computed once for all of them, no 64-bit index divisions
+// per pixel (the flat kernel above spent 74 us on them for 31 M pixels), 4 pixels leave as one 32-bit store; round 4: eight rows per block
+// instead of one (48 000 blocks of 160 busy threads were most of the 36 us).  Same arithmetic per pixel, bit-identical masks.
+#define MASK_ROWS 8
 __global__ __launch_bounds__(256) void bilinear_mask_rows_kernel(const float* x, unsigned char* mask, float threshold, int h, int w, int H, int W,
-                                                                 float scale_h, float scale_w) {
-  const unsigned row = blockIdx.x;                          // plane * H + oy
-  const unsigned pl = row / (unsigned)H, oy = row - pl * (unsigned)H;
-  const LinW wy = lin_weights((int)oy, h, H, scale_h);
-  const float* p0 = x + (long)pl * h * w + (long)wy.i0 * w;
-  const float* p1 = x + (long)pl * h * w + (long)wy.i1 * w;
+                                                                 float scale_h, float scale_w, int row_groups) {
+  const unsigned grp = blockIdx.x;                          // plane * row_groups + row group
+  const unsigned pl = grp / (unsigned)row_groups, rg = grp - pl * (unsigned)row_groups;
   const int ox0 = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (ox0 >= W) return;
-  unsigned packed = 0;
+  LinW wx[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const LinW wx = lin_weights(ox0 + k, w, W, scale_w);
-    const float r0 = __fmaf_rn(p0[wx.i0], wx.l0, __fmul_rn(p0[wx.i1], wx.l1));
-    const float r1 = __fmaf_rn(p1[wx.i0], wx.l0, __fmul_rn(p1[wx.i1], wx.l1));
-    const float v = __fmaf_rn(r0, wy.l0, __fmul_rn(r1, wy.l1));
-    packed |= (v > threshold ? 1u : 0u) << (8 * k);
+  for (int k = 0; k < 4; ++k) wx[k] = lin_weights(ox0 + k, w, W, scale_w);
+  const float* px = x + (long)pl * h * w;
+#pragma unroll
+  for (int r = 0; r < MASK_ROWS; ++r) {
+    const int oy = (int)rg * MASK_ROWS + r;
+    if (oy >= H) break;
+    const LinW wy = lin_weights(oy, h, H, scale_h);
+    const float* p0 = px + (long)wy.i0 * w;
+    const float* p1 = px + (long)wy.i1 * w;
+    unsigned packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float r0 = __fmaf_rn(p0[wx[k].i0], wx[k].l0, __fmul_rn(p0[wx[k].i1], wx[k].l1));
+      const float r1 = __fmaf_rn(p1[wx[k].i0], wx[k].l0, __fmul_rn(p1[wx[k].i1], wx[k].l1));
+      const float v = __fmaf_rn(r0, wy.l0, __fmul_rn(r1, wy.l1));
+      packed |= (v > threshold ? 1u : 0u) << (8 * k);
+    }
+    *(unsigned*)(mask + ((long)pl * H + oy) * W + ox0) = packed;
   }
-  *(unsigned*)(mask + (long)row * W + ox0) = packed;
 }
 
 // SelfMask inference tail (networks/selfmask/selfmask.py:207-221) without a host round trip: per image pick the query with
@@ -507,8 +517,9 @@ extern "C" int zh_upsample_bilinear_nchw(const float* x, float* out, unsigned ch
                                          int h, int w, int H, int W, float scale_h, float scale_w, hipStream_t stream) {
   ZH_CHECK_ARG(x && (out || mask_u8) && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "zh_upsample_bilinear_nchw: bad arguments");
   if (!out && W % 4 == 0 && ((uintptr_t)mask_u8 & 3) == 0 && planes * H < (1L << 31) && W <= 1024 * 65535) {
-    hipLaunchKernelGGL(bilinear_mask_rows_kernel, dim3((unsigned)(planes * H), zh_cdiv(W, 1024)), dim3(256), 0, stream, x, mask_u8, threshold,
-                       h, w, H, W, scale_h, scale_w);
+    const int row_groups = zh_cdiv(H, MASK_ROWS);
+    hipLaunchKernelGGL(bilinear_mask_rows_kernel, dim3((unsigned)(planes * row_groups), zh_cdiv(W, 1024)), dim3(256), 0, stream, x, mask_u8, threshold,
+                       h, w, H, W, scale_h, scale_w, row_groups);
     ZH_CHECK_LAUNCH("zh_upsample_bilinear_nchw");
     return ZH_OK;
   }

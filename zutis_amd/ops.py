@@ -473,7 +473,9 @@ def mask_runs_kept(masks_u8, kept_index, kept_count, max_runs, pos, nr, ba):
     L = _lib.load()
     _chk(masks_u8, torch.uint8, "mask_runs_kept masks"); _chk(kept_index, torch.int32, "kept_index"); _chk(kept_count, torch.int32, "kept_count")
     B, Q, H, W = masks_u8.shape
-    _lib.check(L.zh_mask_runs_kept(_p(masks_u8), _p(kept_index), _p(kept_count), B, Q, H, W, max_runs, _p(pos), _p(nr), _p(ba), _stream()),
+    need = int(_lib.load(raw=True).zh_mask_runs_workspace_size(B * Q, W))
+    ws = torch.empty(need, dtype=torch.uint8, device=masks_u8.device)
+    _lib.check(L.zh_mask_runs_kept(_p(masks_u8), _p(kept_index), _p(kept_count), B, Q, H, W, max_runs, _p(pos), _p(nr), _p(ba), _p(ws), need, _stream()),
                "zh_mask_runs_kept")
 
 
@@ -587,5 +589,7 @@ def mask_runs(masks_u8, sel, max_runs=8192):
     pos = torch.empty((m, max_runs), dtype=torch.int32, device=masks_u8.device)
     nr = torch.empty((m, 2), dtype=torch.int32, device=masks_u8.device)
     ba = torch.empty((m, 5), dtype=torch.int32, device=masks_u8.device)
-    _lib.check(L.zh_mask_runs(_p(masks_u8), _p(sel), m, H, W, max_runs, _p(pos), _p(nr), _p(ba), _stream()), "zh_mask_runs")
+    need = int(_lib.load(raw=True).zh_mask_runs_workspace_size(m, W))
+    ws = torch.empty(need, dtype=torch.uint8, device=masks_u8.device)
+    _lib.check(L.zh_mask_runs(_p(masks_u8), _p(sel), m, H, W, max_runs, _p(pos), _p(nr), _p(ba), _p(ws), need, _stream()), "zh_mask_runs")
     return pos, nr, ba
