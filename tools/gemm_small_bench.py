@@ -95,6 +95,11 @@ if __name__ == "__main__":
             bench(T, 768, 3072, f"proj/w{nw}", (1288,), splits=(4,), out="f32", NW=nw)
             bench(100, 768, 768, f"dec/w{nw}", (0,), out="f32", resid=True, NW=nw)
             bench(100, 768, 2048, f"l2/w{nw}", (0,), out="f32", resid=True, NW=nw)
+    if which == "pmc64":      # counters of the 32-k (96) and 64-k (6496) forms of the one-image QKV tile
+        def t(fn, n=12):
+            for i in range(n): fn(i)
+            torch.cuda.synchronize(); return 0.0
+        bench(T, 2304, 768, "qkv", (96, 6496))
     if which == "pmc":        # rocprofv3 --pmc target: a few eager launches of the batch-1 QKV / fc / proj shapes, cold weights
         def t(fn, n=12):
             for i in range(n): fn(i)
