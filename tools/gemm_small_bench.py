@@ -95,6 +95,16 @@ if __name__ == "__main__":
             bench(T, 768, 3072, f"proj/w{nw}", (1288,), splits=(4,), out="f32", NW=nw)
             bench(100, 768, 768, f"dec/w{nw}", (0,), out="f32", resid=True, NW=nw)
             bench(100, 768, 2048, f"l2/w{nw}", (0,), out="f32", resid=True, NW=nw)
+    if which == "dec32":      # the decoder's GEMMs at the headline's batch (32 images x 100 queries = 3200 rows) under the tile candidates
+        DT = (0, 64, 96, 1288, 6496, 192, 256)
+        bench(3200, 768, 768, "dec o", DT, out="f32", resid=True)
+        bench(3200, 2304, 768, "dec qkv", DT)
+        bench(3200, 768, 768, "dec q", DT)
+        bench(3200, 2048, 768, "dec l1", DT, act=ops.ACT_RELU)
+        bench(3200, 768, 2048, "dec l2", DT, out="f32", resid=True)
+        bench(3200, 768, 2048, "dec l2/S", (0, 96, 1288), splits=(2, 4), out="f32")
+        bench(19200, 256, 768, "ffn2.0", (0, 96, 1288, 192, 256), act=ops.ACT_RELU)
+        bench(19200, 768, 256, "ffn2.2", (0, 96, 1288, 192, 256), out="f32")
     if which == "pmc64":      # counters of the 32-k (96) and 64-k (6496) forms of the one-image QKV tile
         def t(fn, n=12):
             for i in range(n): fn(i)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries and bench lines under profiles/ (run on the GPU box from the repo root, e.g.
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
+#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r04'
 # then copy gpurun_out/<round>_* into profiles/).  One rocprofv3 --kernel-trace --stats pass per configuration; the PMC traffic
 # passes are the ones bench.py spawns itself (roofline.traffic of the default line).  The headline precision is `exact` (bench.py's
 # default); `fast` is profiled as the second precision.
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
@@ -22,6 +22,14 @@ prof bench_exact_inflight $Q
 prof bench_fast $Q --inflight 1 --precision fast
 prof c4 $Q --workload c4
 prof c5 $Q --workload c5 --inflight 1
+# batch 1 (config 3's shape through the drop-in module): per-kernel stats and the ordered launch list of ONE hipGraph-replayed forward + predict
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_c3 -- python3 tools/c3_trace_run.py graph 12 > gpurun_out/p_c3.log 2>&1
+f=$(find gpurun_out/p_c3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${R}_c3_graph_kernel_stats.csv
+python3 tools/trace_list.py gpurun_out/p_c3 im2col 1 > gpurun_out/${R}_c3_launch_list.txt 2>&1
+rm -rf gpurun_out/p_c3
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_bs -- python3 tools/bilateral_prof_run.py 1 > gpurun_out/p_bs.log 2>&1
+f=$(find gpurun_out/p_bs -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${R}_bilateral_b1_kernel_stats.csv
+rm -rf gpurun_out/p_bs
 python3 bench.py 2> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench.json
 python3 bench.py --workload c4 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c4.json
 python3 bench.py --workload c5 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c5.json

@@ -151,9 +151,10 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // fewer staged bytes: c_fc 29.4 -> 24.6 us, c_proj planes (S = 4) 28.8 -> 24.8, out_proj planes 12.2 -> 11.0 (round 4, same box;
   // 128 x 96 on 5 slots, 96 x 128, 160 x 128 and 4-wave 128 x 128 were timed with it and dropped: within 3 % or slower)
   if (pick == 64 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 128) * batch <= 256 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch > 256) pick = 1288;
-  // the wide few-row GEMM (QKV at one image: 1201 x 2304 = 240 tiles of 128 x 96): the same tile on 64-k slices (128-B row pieces, two
-  // slots; gemm_kernel.h K64) 23.5 -> 21.9 us; 128 x 128 and 64 x 64 on 64-k slices tied with their 32-k forms and were dropped
-  if (pick == 96 && !pos_y && (long)zh_cdiv(M, 128) * (N / 96) * batch <= 256) pick = 6496;
+  // (developer A/B, code 6496: the 128 x 96 tile on 64-k slices — 128-B row pieces, two slots, gemm_kernel.h K64.  A CU's pure LDS-DMA
+  //  stream runs 85 GB/s in 128-B pieces against 52 - 57 in 64-B pieces (tools/micro/dma_stream.hip), but inside the GEMM the form with
+  //  ONE slice in flight ties with the 3-slot 32-k form: QKV at one image 21.9 - 22.8 us against 22.4 - 23.5 over four runs, K loop
+  //  18.2 against 13.8 us on a cold weight (profiles/NOTES.md round 4): measured, tested, not selected.)
   if (forced == 1288 || forced == 6496) pick = forced;
   if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
