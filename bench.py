@@ -76,7 +76,7 @@ def live_pmc_traffic(extra_args, split: int, timeout_s=240):
         d = tempfile.mkdtemp(prefix="zh_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--inflight", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-second-precision",
-               "--no-live-traffic"] + list(extra_args)
+               "--no-live-traffic", "--no-batch1"] + list(extra_args)
         try:
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=timeout_s, check=True)
@@ -405,7 +405,9 @@ def batch1_object(precision, dev, steps=40):
                     "trainer.py:328-345, coco20k_eval.py:258-267): forward + predict(instance, hard NMS) to COCO RLE dicts",
             "ms_per_image": round(ms_step, 3), "images_per_s": round(1e3 / ms_step, 1), "forward_ms": round(ms_fwd, 3),
             "instance_predict_ms": round(ms_step - ms_fwd, 3), "semantic_predict_ms": round(ms_sem, 3), "steps": steps,
-            "hip_graph_replay": graph, "precision": precision, "library_launches_forward": n_fwd, "library_launches_instance_predict": n_all - n_fwd,
+            "hip_graph_replay": graph, "precision": precision, "library_calls_forward": n_fwd, "library_calls_instance_predict": n_all - n_fwd,
+            "library_calls_note": "C-ABI entry-point calls (zh_*) of one eager forward / predict; a few launch two kernels (split attention + "
+                                  "merge, global LayerNorm, IoU pack + counts, run extraction): profiles/r04_c3_launch_list.txt lists the kernels",
             "parity": c3_parity(preds, g, f"{H}x{W}")}
 
 
@@ -587,6 +589,7 @@ def main():
     ap.add_argument("--no-io-rates", action="store_true", help="skip the short extra runs that report the PCIe-inclusive rates (N = 1)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the bounded batch-1 object (one 480x640 image per call through the drop-in module)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the extra CPU-baseline pass with one thread per physical core")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--torch-gpu-baseline", action="store_true", default=True,
                     help="also time the oracle (= the reference's op sequence) with stock PyTorch-ROCm fp32 eager ops on this GPU "
@@ -744,7 +747,7 @@ def main():
             roof["traffic"], roof["traffic_source"] = live_pmc_traffic(extra, 1 if "SPLIT=1" in roof["kernel"] else (2 if "SPLIT=2" in roof["kernel"] else 0))
         if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 2)
-        roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r03_bench_%s_kernel_stats.csv"
+        roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r04_bench_%s_kernel_stats.csv"
                                 % args.precision)
 
     # ---- CPU baseline: the oracle (CPU port of the reference path) on a bounded sample, rank 0 at N=1 only
@@ -776,6 +779,18 @@ def main():
                          f"({', '.join('%.1f' % t for t in times)} s) after a 1-image warm-up; host has {os.cpu_count()} hardware "
                          f"threads, {torch.get_num_threads()} torch threads was the fastest setting of 8..128 on this host class"}
         lo_ref = O.semantic_logits_lowres(o_ref["patch_tokens"], tc).numpy()
+        # BASELINE.md promised the host's physical cores: one more pass of a smaller sample with one torch thread per physical core, next to
+        # the 16-thread figure above (which is the faster one on this host class and stays `value`)
+        phys = max(1, (os.cpu_count() or 2) // 2)
+        if phys != torch.get_num_threads() and not args.no_cpu_all_cores:
+            torch.set_num_threads(phys)
+            n2 = min(4, ns)
+            cpu_pass(xs[:1])
+            t1 = time.perf_counter()
+            cpu_pass(xs[:n2])
+            cpu["all_physical_cores"] = {"cores": phys, "value": round(n2 / (time.perf_counter() - t1), 3), "unit": "images/s",
+                                         "sample": f"{n2} images, one pass after a 1-image warm-up"}
+            torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
 
         def parity_of(e):
             out = e.forward(x[:ns])
