@@ -41,6 +41,20 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_x3_kernel(GemmArgs p, int 
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the epilogue's operands of the sub-tile this wave will finish (wave w finishes sub-tile w) are requested NOW, in front of the K loop:
+  // behind it they are two more dependent memory latencies of a launch that is little else (~1 us of a 9-us launch)
+  static_assert(MT * NT == NW, "one sub-tile per wave");
+  const long cb = (long)batch * p.sC;
+  const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+  const int own_nt = wave / MT, own_mt = wave - own_nt * MT;
+  const int own_m = m0 + own_mt * 16 + frow, own_n = n0 + own_nt * 16 + fk * 4;
+  const bool own_ok = own_m < p.M && own_n < p.N;
+  f32x4 bias_v = {0.f, 0.f, 0.f, 0.f}, res_v = {0.f, 0.f, 0.f, 0.f};
+  if (p.vec_ok && own_ok) {
+    if (p.bias) bias_v = *(const f32x4*)(p.bias + own_n);
+    if (R) res_v = *(const f32x4*)(R + (long)(own_m % p.res_rows) * p.ldr + own_n);
+  }
+
   const int nk = p.K / BK;                                   // 32-wide steps; this wave: wave, wave + NW, ...
   const int mine = nk > wave ? (nk - wave + NW - 1) / NW : 0;
   const int nchunks = (mine + G - 1) / G;
@@ -103,21 +117,19 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_x3_kernel(GemmArgs p, int 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) red[wave][nt * MT + mt][lane] = acc[nt][mt];
   __syncthreads();
-  const long cb = (long)batch * p.sC;
-  const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
-  for (int t = wave; t < NTILE; t += NW) {
-    const int nt = t / MT, mt = t - nt * MT;
+  {
+    const int t = wave;
     f32x4 v = red[0][t][lane];
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += red[w][t][lane];
-    const int m = m0 + mt * 16 + frow, n = n0 + nt * 16 + fk * 4;
-    if (m >= p.M || n >= p.N) continue;
+    const int m = own_m, n = own_n;
+    if (!own_ok) return;
     v *= p.out_scale;
     const long ci = cb + (long)m * p.ldc + n;
     if (p.vec_ok) {                                          // N % 4 == 0 and 16-byte aligned rows: a lane's four columns are in or out together
-      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (p.bias) v += bias_v;
       if (p.act != ZH_ACT_NONE) { v[0] = zh_act(v[0], p.act); v[1] = zh_act(v[1], p.act); v[2] = zh_act(v[2], p.act); v[3] = zh_act(v[3], p.act); }
-      if (R) v += *(const f32x4*)(R + (long)(m % p.res_rows) * p.ldr + n);
+      if (R) v += res_v;
       if (out_kind == 0) *(f32x4*)((float*)p.C + ci) = v;
       else zh_store_h4((half_t*)p.C + ci, out_kind == 2 ? p.planeC : 0, v);
     } else {                                                 // ragged N / unaligned rows: element by element
