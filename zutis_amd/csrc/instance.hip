@@ -74,7 +74,7 @@ extern "C" int zh_instance_mask_stats(const float* mask_proposals, long stride_i
 // order (deterministic, independent of the batch) and divides.  (Round 3: the first version walked ALL pixels in one block per
 // (query tile, image) — 10 blocks at batch 1, the COCO-20K evaluation's regime, 4800 dependent iterations: 1.8 ms of the
 // 3.5 ms instance predict.)
-#define QT 10
+#define QT 10      // (round 4: 20 queries per block with 16 rows of loads in flight: 31 -> 60 us — 190 blocks, one round, each twice as long)
 #define MCH 128
 template <int CPT>
 __global__ __launch_bounds__(256) void masked_mean_kernel(const float* tokens, const unsigned char* binary, float* partial, int Q, int M, int E,
@@ -168,21 +168,22 @@ __global__ __launch_bounds__(256) void instance_classify_kernel(const float* avg
   const float inv = 1.0f / (sqrtf((red[0] + red[1]) + (red[2] + red[3])) + 1e-7f);
   float bv = -1.f;
   int bi = 0x7fffffff;
-  // three classes per pass (cls, cls + 4, cls + 8): their rows are loaded together — one class at a time was 21 dependent passes of
+  // CPP classes per pass (cls, cls + 4, ...): their rows are loaded together — one class at a time was 21 dependent passes of
   // load -> reduce -> exp per wave, 48 us for 100 queries x 81 classes at batch 1.  Each class's dot product keeps its summation
   // order and the classes are compared in ascending order, as before: bit-identical categories and scores.
-  for (int cls = wave; cls < n; cls += 12) {
-    const float* t[3];
-    float d[3] = {0.f, 0.f, 0.f};
+  constexpr int CPP = 6;                                  // classes per pass and wave (round 4: 3 -> 6, 81 classes in 4 passes instead of 7)
+  for (int cls = wave; cls < n; cls += 4 * CPP) {
+    const float* t[CPP];
+    float d[CPP];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) t[j] = text + (long)(cls + 4 * j < n ? cls + 4 * j : cls) * E;
+    for (int j = 0; j < CPP; ++j) { t[j] = text + (long)(cls + 4 * j < n ? cls + 4 * j : cls) * E; d[j] = 0.f; }
     for (int c = lane; c < E; c += 64) {
       const float x = sv[c] * inv;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) d[j] += t[j][c] * x;
+      for (int j = 0; j < CPP; ++j) d[j] += t[j][c] * x;
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < CPP; ++j) {
       const float dj = wave_sum(d[j]);
       const float pr = 1.0f / (1.0f + expf(-temperature * dj));
       if (cls + 4 * j < n && pr > bv) { bv = pr; bi = cls + 4 * j; }          // classes ascend within a wave -> first max kept
