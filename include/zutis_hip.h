@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 219 /* 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 220 /* 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -78,12 +78,16 @@ int zh_gemm_f16(const void* A, long lda, long strideA, const void* W, long ldw, 
  * planeW = 0: W has NO lo plane — every value of W * 2^s is an fp16 number, as for the released CLIP towers, whose weights the
  * reference's own constructor rounds to fp16 (convert_weights, clip_arch.py:566-587,625) before zutis.py:55 / encode_image use
  * them: the kernel then issues Ah.Wh + Al.Wh only, bit-identical to the three-product form on a zero lo plane, at 2/3 of the
- * MFMA work ("f16x2").  A is always a split pair. */
+ * MFMA work ("f16x2").  A is always a split pair.
+ * flags: ZH_GEMM_FIXED_K_ORDER (1) = the caller compares results of calls with different M / N bit for bit (sharded retrieval): only
+ * the LDS-ring kernels, whose K order is the same for every tile shape, are used; 0 = few-row problems (M <= 128, a small grid) take the
+ * few-row kernel (gemm_skinny.h: K split over the waves of a workgroup — a different, equally fp32-class summation order). */
+#define ZH_GEMM_FIXED_K_ORDER 1
 int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA, const void* W, long ldw, long strideW, long planeW,
                   void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
                   const float* bias, const float* residual, long ldr, long strideR, int res_rows,
                   const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
-                  int act, int M, int N, int K, int batch, zh_stream_t stream);
+                  int act, int M, int N, int K, int batch, int flags, zh_stream_t stream);
 
 /* Flash attention: O = softmax(scale * Q K^T) V per (image, head); Q [Tq, heads*dh] rows with stride ldq, etc.
  * f16 in/out, fp32 softmax/accumulate; head_dim in {64, 96}.

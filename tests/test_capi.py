@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu(lib):
     rc = lib.zh_attention_f16(16, 8, 8, 16, 8, 8, 16, 8, 8, 16, 8, 8, 1, 1, 4, 4, 64, 1.0, 64, 0, 64, 0, None)
     assert rc == -1 and b"all three or none" in lib.zh_last_error()
     # the reference-equivalent GEMM refuses plain fp16 operands (no silent precision downgrade)
-    rc = lib.zh_gemm_f16x3(16, 64, 0, 0, 16, 64, 0, 0, 16, 8, 0, 0, 0, 1.0, None, None, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 8, 8, 64, 1, None)
+    rc = lib.zh_gemm_f16x3(16, 64, 0, 0, 16, 64, 0, 0, 16, 8, 0, 0, 0, 1.0, None, None, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 8, 8, 64, 1, 0, None)
     assert rc == -1 and b"A must be a split pair" in lib.zh_last_error()
     assert lib.zh_global_ln_l2_workspace_size(2, 1764, 512) == 2 * ((1764 * 512 + 4095) // 4096) * 16
 

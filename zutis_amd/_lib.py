@@ -32,7 +32,7 @@ _SIGS = {
     "zh_dev_set_gemm_overrides": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "zh_gemm_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "zh_gemm_f16x3": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _f, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i,
-                           _vp]),
+                           _i, _vp]),
     "zh_attention_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _l, _l, _l, _l, _vp]),
     "zh_attention_splitk_workspace_size": (_sz, [_i, _i, _i, _i, _i]),
     "zh_attention_f16_splitk": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _f, _l, _l, _l, _l, _i, _vp, _sz, _vp]),

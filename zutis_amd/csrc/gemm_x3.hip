@@ -13,6 +13,9 @@
 #ifndef ZH_SKINNY_MAX_ROWS
 #define ZH_SKINNY_MAX_ROWS 128
 #endif
+#ifndef ZH_SKINNY_MAX_BLOCKS
+#define ZH_SKINNY_MAX_BLOCKS 512
+#endif
 #ifdef ZH_GEMM_PROBE
 extern "C" void zh_gemm_x3_set_probe(long long* p) { g_probe = p; }   // developer build (tools/gemm_x3_stamp.py)
 #endif
@@ -45,7 +48,7 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
                              void* C, long ldc, long strideC, long planeC, int out_kind, float out_scale,
                              const float* bias, const float* residual, long ldr, long strideR, int res_rows,
                              const void* pos_y, const void* pos_x, long ld_pos, int pos_h, int pos_w, int pos_f16,
-                             int act, int M, int N, int K, int batch, hipStream_t stream) {
+                             int act, int M, int N, int K, int batch, int flags, hipStream_t stream) {
   ZH_CHECK_ARG(A && W && C, "zh_gemm_f16x3: null operand");
   ZH_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "zh_gemm_f16x3: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   ZH_CHECK_ARG(K % 64 == 0, "zh_gemm_f16x3: K=%d must be a multiple of 64", K);
@@ -110,8 +113,13 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // over the four waves of a block, no ring.  Tile code 32 forces it for any M (tests), any other forced code disables it.
   {
     const int forced_tile = gemm_dev_overrides().tile;
-    const int max_rows = forced_tile == 32 ? (1 << 30) : (forced_tile ? 0 : ZH_SKINNY_MAX_ROWS);
-    if (gemm_skinny_ok(p, batch, p.vec_ok, max_rows)) {
+    // ZH_GEMM_FIXED_K_ORDER: the caller compares results of calls with different M / N bit for bit (sharded retrieval): the LDS-ring
+    // family only, whose K order is the same for every tile.  Otherwise: few rows AND a grid small enough that the kernel's re-reads of
+    // the row block (once per 32 output columns) do not matter — the class-logit GEMM of a 32-image batch (81 x 1764 x 512 x 32 =
+    // 5376 workgroups) took 113 us here against ~20 on the ring.
+    const int max_rows = forced_tile == 32 ? (1 << 30) : ((forced_tile || (flags & 1)) ? 0 : ZH_SKINNY_MAX_ROWS);
+    const long sk_blocks = (long)zh_cdiv(N, 32) * zh_cdiv(M, 32) * batch;
+    if (gemm_skinny_ok(p, batch, p.vec_ok, max_rows) && (forced_tile == 32 || sk_blocks <= ZH_SKINNY_MAX_BLOCKS)) {
       if (x2) launch_skinny<1>(p, batch, out_kind, stream);
       else launch_skinny<2>(p, batch, out_kind, stream);
       ZH_CHECK_LAUNCH("zh_gemm_f16x3");
@@ -175,12 +183,12 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
         const long esz = out_kind == 0 ? 4 : 2;
         int rc = zh_gemm_f16x3(A, lda, strideA, planeA, W, ldw, strideW, planeW, C, ldc, strideC, planeC, out_kind, out_scale, bias,
                                residual, ldr, strideR, residual ? res_rows : 0, pos_y, pos_x, ld_pos, pos_h, pos_w, pos_f16, act,
-                               (int)M1, N, K, 1, stream);
+                               (int)M1, N, K, 1, flags, stream);
         if (rc != ZH_OK) return rc;
         return zh_gemm_f16x3((const char*)A + M1 * lda * 2, lda, strideA, planeA, W, ldw, strideW, planeW,
                              (char*)C + M1 * ldc * esz, ldc, strideC, planeC, out_kind, out_scale, bias,
                              residual ? residual + M1 * ldr : nullptr, ldr, strideR, residual ? (int)(res_rows - M1) : 0,
-                             pos_y, pos_x, ld_pos, pos_h, pos_w, pos_f16, act, (int)(M - M1), N, K, 1, stream);
+                             pos_y, pos_x, ld_pos, pos_h, pos_w, pos_f16, act, (int)(M - M1), N, K, 1, flags, stream);
       }
     }
   }

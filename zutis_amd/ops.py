@@ -133,8 +133,9 @@ def _pos(pos, N):
 
 def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, act: int = ACT_NONE, *, M=None, N=None, K=None,
             lda=None, ldw=None, ldc=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, ldr=None,
-            strideR: int = 0, pos=None):
-    """out = act((A @ W^T) * W.out_scale + bias + pos) + residual[m % res_rows] at the reference's fp32-class precision: A and W
+            strideR: int = 0, pos=None, fixed_k_order: bool = False):
+    """fixed_k_order: results of calls with different M / N are compared bit for bit (sharded retrieval): ring kernels only.
+    out = act((A @ W^T) * W.out_scale + bias + pos) + residual[m % res_rows] at the reference's fp32-class precision: A and W
     are split pairs (Act with plane != 0); out is an f32 tensor, an fp16 tensor / plain Act, or a split Act (then the residual is
     added in fp32 before the one rounding, act must be none).  pos: see _pos()."""
     L = _lib.load()
@@ -157,7 +158,7 @@ def gemm_x3(A: Act, W: Act, out, bias=None, residual=None, res_rows: int = 0, ac
         assert bias.dtype == f32 and bias.numel() >= N
     args = (_p(a), lda, strideA, A.plane, _p(w), ldw, strideW, W.plane, _p(o), ldc, strideC, planeC, kind,
             float(A.out_scale * W.out_scale), _p(bias), _p(residual), ldr or 0, strideR, res_rows, *_pos(pos, N),
-            act, M, N, K, batch, _stream())
+            act, M, N, K, batch, int(bool(fixed_k_order)), _stream())
     nbytes = _gemm_bytes(M, N, K, batch, strideA, strideW, 4, 4 if kind == 0 else (4 if kind == 2 else 2), residual is not None)
     if not W.plane:                                  # one-plane weight: 2 bytes per element instead of 4
         nbytes -= N * K * 2.0 * (batch if (strideW or batch == 1) else 1)

@@ -58,7 +58,7 @@ def retrieve_topk(text_embeddings: torch.Tensor, image_embeddings: torch.Tensor,
         n = min(chunk, N - lo)
         img = _split_rows(image_embeddings[lo:lo + n])
         scores = torch.empty((C, (n + 7) // 8 * 8), dtype=f32, device=dev)
-        ops.gemm_x3(t, img, scores, N=n)                               # text @ image.T   (index_dataset.py:163)
+        ops.gemm_x3(t, img, scores, N=n, fixed_k_order=True)           # text @ image.T   (index_dataset.py:163); shards of any size: same bits
         ops.topk_rows(scores, kc[j], N=n, with_values=True, idx_add=lo + index_offset,
                       out_idx=cand_idx[:, col:col + kc[j]], out_val=cand_val[:, col:col + kc[j]])
         col += kc[j]
