@@ -576,11 +576,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 #ifndef ZH_X3_NOBAR
       wait_vmcnt_barrier<AHEADX * NP>();
 #endif
+#ifdef ZH_X3_DMA_FIRST                   // developer A/B (round 4): the next slice's DMA in front of this slice's fragment reads
+      issue_stage(wslot);
+      read_frags();
+#else
 #ifndef ZH_X3_NOFRAG
       read_frags();
 #endif
 #ifndef ZH_X3_NODMA
       issue_stage(wslot);
+#endif
 #endif
 #ifndef ZH_X3_NOMFMA
       sweeps();
