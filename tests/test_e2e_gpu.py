@@ -110,6 +110,31 @@ def _dropin_zutis(cfg, dev, n_cat):
     return net.to(dev).eval()
 
 
+def test_dropin_replays_a_graph_from_the_second_occurrence_of_a_shape(dev):
+    """The drop-in's forward of a batch <= 4: the first call of a shape runs eagerly (a shape seen once must not pay a capture), the
+    second captures a hipGraph, later ones replay it — all bitwise equal; use_hip_graph = False never captures."""
+    from zutis_amd import detgen
+    cfg = detgen.TINY
+    net = _dropin_zutis(cfg, dev, 7)
+    xa = torch.from_numpy(detgen.images(1, 64, 96, seed=1)).to(dev)
+    xb = torch.from_numpy(detgen.images(1, 64, 96, seed=2)).to(dev)
+    graphs = lambda: [k for k in net._get_engine()._geo if isinstance(k, tuple) and k and k[0] == "graph"]
+    with torch.no_grad():
+        o1 = {k: v.clone() for k, v in net(xa).items()}
+        assert graphs() == []
+        o2 = {k: v.clone() for k, v in net(xa).items()}
+        assert len(graphs()) == 1
+        o3 = net(xa)
+        ob = net(xb)
+        assert len(graphs()) == 1
+        for k in o1:
+            assert torch.equal(o1[k], o2[k]) and torch.equal(o1[k], o3[k]) and not torch.equal(o1[k], ob[k])
+        net.use_hip_graph = False
+        net._engine = None
+        net(xa); net(xa); net(xa)
+        assert graphs() == []
+
+
 @pytest.mark.parametrize("precision,t_score,t_pix", [("fast", 2e-2, 1e-2), ("exact", 2e-3, 5e-4)])
 def test_dropin_module_matches_reference_golden(dev, golden_dir, precision, t_score, t_pix):
     """The reference's call surface (ZUTIS.forward / .predict semantic + instance, all NMS types) on the HIP path,

@@ -211,6 +211,7 @@ class ZUTIS(nn.Module):
         # more than most of a one-image forward's ~165 kernels): the reference's callers evaluate image by image (val batch_size 1,
         # trainer.py:328-345, coco20k_eval.py:258-267).  False: always launch eagerly.
         self.use_hip_graph: bool = True
+        self._shapes_seen: Dict[Tuple[int, ...], int] = {}
 
     # ------------------------------------------------------------------ plumbing
     def _get_engine(self) -> ZutisEngine:
@@ -248,7 +249,16 @@ class ZUTIS(nn.Module):
                 "torch.no_grad() or call .requires_grad_(False) as trainer.evaluate / coco20k_eval.py do")
         eng = self._get_engine()
         if self.use_hip_graph and x.shape[0] <= 4:       # host-bound regime: replay a captured hipGraph per input shape
-            return eng.forward_graphed(x.float().contiguous())
+            # ... from the SECOND time a shape is seen: capturing costs three eager forwards, and a native-resolution evaluation set holds
+            # shapes that occur once (they run eagerly, as before round 4) next to the few that most images share (480x640, 640x480, ...)
+            key = tuple(x.shape)
+            seen = self._shapes_seen.get(key, 0)
+            if seen < 2:
+                if len(self._shapes_seen) > 4096:
+                    self._shapes_seen.clear()
+                self._shapes_seen[key] = seen + 1
+            if seen >= 1:
+                return eng.forward_graphed(x.float().contiguous())
         return eng.forward(x.float())
 
     # ------------------------------------------------------------------ predict
