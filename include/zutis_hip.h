@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 220 /* 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 221 /* 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list); 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -314,9 +314,14 @@ size_t zh_mask_runs_workspace_size(int n, int W);   /* n = n_sel (zh_mask_runs) 
 int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, int W, int max_runs,
                  int* positions, int* nruns, int* box_area, void* workspace, size_t workspace_bytes, zh_stream_t stream);
 /* The same for the queries zh_mask_nms kept, straight from its device outputs (masks u8 [B,Q,H,W]; kept_index int32 [B,Q], kept_count
- * int32 [B]): row b*Q + j of positions / nruns / box_area describes image b's j-th kept mask; rows j >= kept_count[b] are not written. */
+ * int32 [B]): row b*Q + j of positions / nruns / box_area describes image b's j-th kept mask; rows j >= kept_count[b] are not written.
+ * packed_capacity = 0: positions int32 [B*Q, max_runs] as above.  packed_capacity > 0: positions is ONE list of packed_capacity ints —
+ * the kept masks' transitions back to back (image-major, kept order; a mask contributes min(#transitions, max_runs) entries, so the
+ * host finds every list from nruns alone); entries that would fall past the capacity are not written (the host sees that from the
+ * same counts and asks again).  A short head of such a list travels in the same device -> host copy as the small tables. */
 int zh_mask_runs_kept(const unsigned char* masks, const int* kept_index, const int* kept_count, int B, int Q, int H, int W, int max_runs,
-                      int* positions, int* nruns, int* box_area, void* workspace, size_t workspace_bytes, zh_stream_t stream);
+                      int* positions, long packed_capacity, int* nruns, int* box_area, void* workspace, size_t workspace_bytes,
+                      zh_stream_t stream);
 
 /* Native launch plans (zutis_amd/plan.py): replay n recorded calls of the entry points above (op id + 24 argument words
  * each; dispatcher generated from this header) in one C loop; zh_plan_run2 alternates two plans on two streams. */
@@ -330,11 +335,12 @@ const char* zh_plan_op_name(int op);
 
 /* HOST helper: RLE string from run lengths (pycocotools rleToString). */
 long zh_rle_counts_to_string_host(const long long* counts, long n, char* out, long cap);
-/* HOST.  The RLE strings of n masks from zh_mask_runs' output in one call: positions int32 [n, stride], nruns int32 [n, 2]
- * (transitions, value of pixel 0), HW pixels per mask; strings back to back in `out` (cap bytes), offsets int64 [n + 1]; a mask
- * with more transitions than `stride` gets an empty string (the caller re-encodes it from the mask).  Returns the total length,
+/* HOST.  The RLE strings of n masks from zh_mask_runs' output in one call: positions int32 [n, stride] (packed = 0) or the packed
+ * list of zh_mask_runs_kept (packed = 1, stride = its max_runs: row i follows row i - 1, min(transitions, stride) entries each), nruns
+ * int32 [n, 2] (transitions, value of pixel 0), HW pixels per mask; strings back to back in `out` (cap bytes), offsets int64 [n + 1]; a
+ * mask with more transitions than `stride` gets an empty string (the caller re-encodes it from the mask).  Returns the total length,
  * -1 when cap is too small.  Replaces pycocotools.mask.encode per kept mask (networks/zutis.py:290,448). */
-long zh_rle_from_transitions_host(const int* positions, long stride, const int* nruns, long n, long HW, char* out, long cap,
+long zh_rle_from_transitions_host(const int* positions, long stride, int packed, const int* nruns, long n, long HW, char* out, long cap,
                                   long long* offsets);
 
 /* HOST helper (no GPU): COCO RLE string of one u8 [H,W] mask = pycocotools.mask.encode(np.asfortranarray(m))["counts"]

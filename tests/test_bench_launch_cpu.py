@@ -39,7 +39,9 @@ def test_launch_command_starts_n_ranks(tmp_path):
         "import os, torch, torch.distributed as dist\n"
         "dist.init_process_group('gloo')\n"
         "t = torch.tensor([float(os.environ['RANK']) + 1]); dist.all_reduce(t)\n"
-        "print('RANK', os.environ['RANK'], 'WORLD', os.environ['WORLD_SIZE'], 'LOCAL', os.environ['LOCAL_RANK'], 'SUM', int(t.item()), flush=True)\n"
+        "import sys\n"
+        "sys.stdout.write('RANK %s WORLD %s LOCAL %s SUM %d\\n' % (os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'], int(t.item())))\n"
+        "sys.stdout.flush()\n"           # ONE write per rank: print() writes its arguments piecewise and the two ranks share the pipe
         "dist.destroy_process_group()\n")
     import socket
     with socket.socket() as s:

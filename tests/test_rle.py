@@ -110,3 +110,9 @@ def test_batched_rle_from_transitions_host_entry():
         assert (rle.decode(out[i]) == m).all()
     short = rle.rles_from_transitions(P[:, :3], NR, H, W)
     assert short[0] is None and short[1] == rle.encode(masks[1])
+    # the packed list of zh_mask_runs_kept: every mask's min(transitions, max_runs) entries back to back
+    for max_runs in (keep, 3):
+        flat = np.concatenate([t[:max_runs] for t in pos]).astype(np.int32)
+        got = rle.rles_from_transitions(flat, NR, H, W, packed_max_runs=max_runs)
+        for i, m in enumerate(masks):
+            assert got[i] == (rle.encode(m) if len(pos[i]) <= max_runs else None), (max_runs, i)

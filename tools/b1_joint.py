@@ -1,0 +1,53 @@
+"""Developer: the batch-1 evaluation loop as its callers run it (forward, then instance predict, image after image) with the host
+side of the predict broken into segments (perf_counter around the engine calls of one predict).
+   gpurun -- python tools/b1_joint.py"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+dev = torch.device("cuda:0")
+net, x, g, thr, H, W = bench.c3_model(dev, "exact")
+eng = net._get_engine()
+inst = lambda o: net.predict(o, mask_type="instance", threshold=thr, size=(H, W), image_ids=[7], nms_type="hard")
+
+
+def joint(n=60):
+    for _ in range(5):
+        inst(net(x))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        inst(net(x))
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for rep in range(3):
+    print(f"{joint():.3f} ms per image (forward + instance predict, joint loop)", flush=True)
+
+# host segments of one joint iteration
+seg = {}
+def wrap(obj, name):
+    f = getattr(obj, name)
+    def w(*a, **k):
+        t0 = time.perf_counter()
+        r = f(*a, **k)
+        seg[name] = seg.get(name, 0.0) + time.perf_counter() - t0
+        return r
+    setattr(obj, name, w)
+from zutis_amd import rle
+wrap(eng, "instance_candidates"); wrap(eng, "instance_nms_encode"); wrap(rle, "rles_from_transitions"); wrap(eng, "forward_graphed")
+n = 60
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    o = net(x)
+    t1 = time.perf_counter()
+    inst(o)
+    seg["predict (whole)"] = seg.get("predict (whole)", 0.0) + time.perf_counter() - t1
+torch.cuda.synchronize()
+tot = (time.perf_counter() - t0) / n * 1e3
+print(f"joint {tot:.3f} ms per image; host time per image inside:")
+for k, v in seg.items():
+    print(f"   {k:28s} {v / n * 1e3:.3f} ms")

@@ -100,14 +100,16 @@ extern "C" long zh_rle_counts_to_string_host(const long long* counts, long n, ch
 // pixel 0}; counts = diff([0, positions..., HW]) with a leading empty zero-run when pixel 0 is set (pycocotools starts with zeros).
 // Strings are written back to back into `out`; offsets int64 [n + 1].  Masks with more than `stride` transitions get an empty
 // string (offsets equal): the caller falls back to the mask encoder.  Returns the total length or -1 when `cap` is too small.
-extern "C" long zh_rle_from_transitions_host(const int* positions, long stride, const int* nruns, long n, long HW, char* out, long cap,
-                                             long long* offsets) {
-  long len = 0;
+// packed != 0: `positions` is zh_mask_runs_kept's packed list — row i starts where row i - 1 ended, min(transitions, stride) entries each.
+extern "C" long zh_rle_from_transitions_host(const int* positions, long stride, int packed, const int* nruns, long n, long HW, char* out,
+                                             long cap, long long* offsets) {
+  long len = 0, at = 0;
   for (long i = 0; i < n; ++i) {
     offsets[i] = len;
     const long nt = nruns[2 * i];
+    const int* p = packed ? positions + at : positions + i * stride;
+    at += nt < stride ? nt : stride;
     if (nt > stride) continue;
-    const int* p = positions + i * stride;
     const bool lead = nruns[2 * i + 1] != 0;
     const long nc = nt + 1 + (lead ? 1 : 0);              // number of runs
     long c1 = 0, c2 = 0;                                   // counts[k - 1], counts[k - 2]

@@ -335,6 +335,7 @@ struct RunsArgs {
   int* positions; int* nruns; int* box_area;
   int* pcount;       // [n][npanel] transitions per panel
   int* pbox;         // [n][npanel][5] xmin, ymin, xmax, ymax, area of the panel's pixels
+  long packed_cap;   // > 0 (kept form only): `positions` is ONE list of that many ints, the kept masks' transitions back to back
 };
 // stages the panel (values normalised to {0,1}) and returns, per thread = (column c = tid / 4, row quarter sg = tid % 4), the number of
 // transitions of its segment and the value in front of it
@@ -413,6 +414,28 @@ __global__ __launch_bounds__(256) void mask_runs_emit_kernel(RunsArgs a) {
   if (a.count && mi % a.Q >= a.count[mi / a.Q]) return;
   const unsigned char* m = runs_mask(a, mi);
   int* pos = a.positions + (long)mi * a.max_runs;
+  long room = a.max_runs;                                  // entries this mask may write
+  if (a.packed_cap > 0) {
+    // packed form: mask mi's list starts where the lists of the kept masks in front of it (image-major, kept order) end; each of those
+    // is min(its transitions, max_runs) long — summed here from the count kernel's per-panel counts (<= B*Q*npanel ints, L2-resident)
+    long part = 0;
+    for (int mp = tid; mp < mi; mp += 256) {
+      if (mp % a.Q >= a.count[mp / a.Q]) continue;
+      int t = 0;
+      for (int p = 0; p < a.npanel; ++p) t += a.pcount[(long)mp * a.npanel + p];
+      part += min(t, a.max_runs);
+    }
+    s_red[tid] = (int)part;                                // < 2^31: B*Q*max_runs is checked by the host entry
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st) s_red[tid] += s_red[tid + st];
+      __syncthreads();
+    }
+    const long off = s_red[0];
+    __syncthreads();
+    pos = a.positions + off;
+    room = min((long)a.max_runs, a.packed_cap - off);      // <= 0: the list does not fit any more (the host sees it from the counts)
+  }
   const int x0 = pnl * RUNS_PANEL, pw = min(RUNS_PANEL, a.W - x0);
   int base = 0;
   for (int p = 0; p < pnl; ++p) base += a.pcount[(long)mi * a.npanel + p];
@@ -434,7 +457,7 @@ __global__ __launch_bounds__(256) void mask_runs_emit_kernel(RunsArgs a) {
 #pragma unroll 8
     for (int y = y0; y < y1; ++y) {
       const unsigned char v = sm[y * RUNS_PANEL + c];
-      if (v != prev) { if (o < a.max_runs) pos[o] = (x0 + c) * a.H + y; ++o; }
+      if (v != prev) { if (o < room) pos[o] = (x0 + c) * a.H + y; ++o; }
       prev = v;
     }
   }
@@ -480,16 +503,19 @@ extern "C" int zh_mask_runs(const unsigned char* masks, const int* sel, int n_se
                             int* positions, int* nruns, int* box_area, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   ZH_CHECK_ARG(masks && sel && positions && nruns && box_area && n_sel > 0 && H > 0 && W > 0 && max_runs > 0, "zh_mask_runs: bad arguments");
   ZH_CHECK_ARG((long)H * W < (1L << 31), "zh_mask_runs: mask too large");
-  RunsArgs a{masks, sel, nullptr, 1, H, W, max_runs, 0, positions, nruns, box_area, nullptr, nullptr};
+  RunsArgs a{masks, sel, nullptr, 1, H, W, max_runs, 0, positions, nruns, box_area, nullptr, nullptr, 0};
   return launch_mask_runs("zh_mask_runs", a, n_sel, workspace, workspace_bytes, stream);
 }
 
 extern "C" int zh_mask_runs_kept(const unsigned char* masks, const int* kept_index, const int* kept_count, int B, int Q, int H, int W, int max_runs,
-                                 int* positions, int* nruns, int* box_area, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                                 int* positions, long packed_capacity, int* nruns, int* box_area, void* workspace, size_t workspace_bytes,
+                                 hipStream_t stream) {
   ZH_CHECK_ARG(masks && kept_index && kept_count && positions && nruns && box_area && B > 0 && Q > 0 && H > 0 && W > 0 && max_runs > 0,
                "zh_mask_runs_kept: bad arguments");
   ZH_CHECK_ARG((long)H * W < (1L << 31) && (long)B * Q < (1L << 31), "zh_mask_runs_kept: mask / batch too large");
-  RunsArgs a{masks, kept_index, kept_count, Q, H, W, max_runs, 0, positions, nruns, box_area, nullptr, nullptr};
+  ZH_CHECK_ARG(packed_capacity >= 0 && (packed_capacity == 0 || (long)B * Q * max_runs < (1L << 31)),
+               "zh_mask_runs_kept: packed_capacity=%ld (needs B*Q*max_runs < 2^31)", packed_capacity);
+  RunsArgs a{masks, kept_index, kept_count, Q, H, W, max_runs, 0, positions, nruns, box_area, nullptr, nullptr, packed_capacity};
   return launch_mask_runs("zh_mask_runs_kept", a, B * Q, workspace, workspace_bytes, stream);
 }
 
@@ -627,8 +653,9 @@ __global__ __launch_bounds__(256) void mask_nms_wave_kernel(const int* inter, co
   long long cat[PL];
   double sc[PL];
   bool act[PL];
+  double sc0[PL];       // the candidates' own scores, read once (they were a dependent global load in front of every category's loop: ~1.5 us x 9)
 #pragma unroll
-  for (int e = 0; e < PL; ++e) { const int q = lane + 64 * e; cat[e] = q < Q ? cats[q] : 0; }
+  for (int e = 0; e < PL; ++e) { const int q = lane + 64 * e; cat[e] = q < Q ? cats[q] : 0; sc0[e] = q < Q ? (double)scores[q] : 0.0; }
   int n_out = 0;
   long long cur = 0;                                          // categories <= 0 are never processed (0 = background)
   for (;;) {
@@ -641,7 +668,7 @@ __global__ __launch_bounds__(256) void mask_nms_wave_kernel(const int* inter, co
     if (mine == 0x7FFFFFFFFFFFFFFFll) break;
     cur = mine;
 #pragma unroll
-    for (int e = 0; e < PL; ++e) { const int q = lane + 64 * e; act[e] = q < Q && cat[e] == cur; sc[e] = q < Q ? (double)scores[q] : 0.0; }
+    for (int e = 0; e < PL; ++e) { const int q = lane + 64 * e; act[e] = q < Q && cat[e] == cur; sc[e] = sc0[e]; }
     for (;;) {
       double bv = -1.0; int bi = -1;                          // key = (score, index): equal maxima resolve to the largest index
 #pragma unroll

@@ -18,6 +18,24 @@ from .engine_base import (ALL_SITES, DECODER_SITES, ENCODER_SITES, HEAD_SITES, P
 from .ops import Act
 
 
+_PINNED: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _to_host(t: torch.Tensor) -> np.ndarray:
+    """A 1-D uint8 device tensor on the host: one asynchronous copy into a cached PINNED buffer + one stream synchronisation (`.cpu()`
+    goes through pageable memory: an allocation, a staged copy and its own synchronisation).  The array is a view of the cached buffer:
+    valid until the next call with the same size (callers take what they need out of it before they return)."""
+    key = (t.device.index or 0, t.numel())
+    buf = _PINNED.get(key)
+    if buf is None:
+        if len(_PINNED) >= 16:
+            _PINNED.clear()
+        buf = _PINNED[key] = torch.empty((t.numel(),), dtype=torch.uint8, pin_memory=True)
+    buf.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return buf.numpy()
+
+
 class ZutisEngine(_EngineBase):
     """Inference engine for one ZUTIS network.  `params` maps reference state_dict keys to fp32 CUDA tensors
     (typically the nn.Parameters of the drop-in module, so load_state_dict() is picked up via version counters)."""
@@ -347,11 +365,12 @@ class ZutisEngine(_EngineBase):
 
     def instance_nms_encode(self, masks_u8: torch.Tensor, scores: torch.Tensor, category_ids: torch.Tensor, nms_type: str = "hard",
                             nms_threshold: float = 0.3, sigma: float = 0.5, threshold: float = 0.001,
-                            range_flag: Optional[torch.Tensor] = None, max_runs: int = 8192):
+                            range_flag: Optional[torch.Tensor] = None, max_runs: int = 8192, pack_head: Optional[int] = None):
         """instance_nms + encode_masks chained on the device (zutis.py:211-299,423-469): popcount IoU counts, the greedy per-category
         loop, then the run extraction of the kept masks straight from the loop's device outputs (zh_mask_runs_kept) — the NMS result
         does not visit the host in between.  ONE device -> host copy brings the kept triples, every query's category, the counts, the
-        range flag, the run counts and the boxes; a second one the run positions actually used.
+        range flag, the run counts, the boxes AND the kept masks' run positions as one packed list (a second copy only when the list outgrows
+        the PACK_HEAD ints per image that ride along).
         Returns (kept [(batch index, category, query index, score)] in the reference's emission order, rles, boxes, areas, status) — status =
         the word behind `range_flag` as the NMS kernel read it (bit ops.STATUS_RANGE: a proposal outside [0, 1]; the engine's own
         status_word() also carries ops.STATUS_NONFINITE from the forward)."""
@@ -363,33 +382,43 @@ class ZutisEngine(_EngineBase):
         m = masks_u8.contiguous()
         for b in range(B):
             ops.mask_iou_counts(m[b], Q, H * W, inter[b], uni[b])
+        # ONE buffer for everything the host needs: [kept triples + categories + count + status (f64) | run counts | boxes + areas | the
+        # head of the packed transition list (PACK_HEAD ints per image)]
         n1, n2, n3 = B * (4 * Q + 2) * 8, B * Q * 2 * 4, B * Q * 5 * 4
-        small = torch.empty((n1 + n2 + n3,), dtype=torch.uint8, device=dev)
+        head = int(min(B * Q * max_runs, B * ((ZutisEngine.PACK_HEAD if B <= 4 else ZutisEngine.PACK_HEAD // 4) if pack_head is None else pack_head)))
+        small = torch.empty((n1 + n2 + n3 + 4 * head,), dtype=torch.uint8, device=dev)
         packed = small[:n1].view(torch.float64).view(B, 4 * Q + 2)
         nr = small[n1:n1 + n2].view(torch.int32).view(B * Q, 2)
-        ba = small[n1 + n2:].view(torch.int32).view(B * Q, 5)
+        ba = small[n1 + n2:n1 + n2 + n3].view(torch.int32).view(B * Q, 5)
+        pos_head = small[n1 + n2 + n3:].view(torch.int32)
         idx, _, _, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma, threshold,
                                       packed=packed, range_flag=range_flag)
-        pos = torch.empty((B * Q, max_runs), dtype=torch.int32, device=dev)
-        ops.mask_runs_kept(m, idx, cnt, max_runs, pos, nr, ba)
-        host = small.cpu().numpy()                                   # the one synchronisation of the predict
+        ops.mask_runs_kept(m, idx, cnt, max_runs, pos_head, nr, ba, packed=True)
+        host = _to_host(small)                                       # the one synchronisation of the predict
         pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)
         nr_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 2)
-        ba_h = host[n1 + n2:].view(np.int32).reshape(B, Q, 5)
+        ba_h = host[n1 + n2:n1 + n2 + n3].view(np.int32).reshape(B, Q, 5)
         cnt_h = pk[:, 4 * Q].astype(np.int64)
         range_bad = int(pk[:, 4 * Q + 1].max()) if range_flag is not None else 0      # the status word as the NMS kernel read it (ops.STATUS_*)
         mc = int(cnt_h.max()) if B else 0
         kept, rles, boxes, areas = [], [], [], []
         if mc > 0:
-            ntr = max(int(nr_h[b, :cnt_h[b], 0].max()) for b in range(B) if cnt_h[b] > 0)
-            keep = int(min(max_runs, max(1, ntr)))
-            pos_h = pos.view(B, Q, max_runs)[:, :mc, :keep].contiguous().cpu().numpy() if (B > 1 or mc < Q or keep < max_runs) else pos.view(B, Q, max_runs).cpu().numpy()
+            lens = [np.minimum(nr_h[b, :int(cnt_h[b]), 0], max_runs).astype(np.int64) for b in range(B)]     # list length of every kept mask
+            total = int(sum(int(l.sum()) for l in lens))
+            if total <= head:
+                flat = host[n1 + n2 + n3:].view(np.int32)
+            else:                                                    # the lists outgrew the head: the whole packed list in a second copy
+                big = torch.empty((total,), dtype=torch.int32, device=dev)
+                ops.mask_runs_kept(m, idx, cnt, max_runs, big, nr, ba, packed=True)
+                flat = big.cpu().numpy()
             all_cat = pk[:, 3 * Q:4 * Q].astype(np.int64)
+            at = 0
             for b in range(B):
                 n = int(cnt_h[b])
                 if n == 0:
                     continue
-                r = rle.rles_from_transitions(np.ascontiguousarray(pos_h[b, :n]), np.ascontiguousarray(nr_h[b, :n]), H, W)
+                r = rle.rles_from_transitions(flat[at:], nr_h[b, :n], H, W, packed_max_runs=max_runs)     # image b's lists start at `at`
+                at += int(lens[b].sum())
                 # the kernel walks the categories in ascending id; the reference walks `set(category_ids_per_image)` (zutis.py:237-238):
                 # order the per-category groups by that very set (stable inside a category: the kernel's = the reference's selection order)
                 rank = {int(c): i for i, c in enumerate(set(all_cat[b]))}
@@ -403,6 +432,10 @@ class ZutisEngine(_EngineBase):
                     boxes.append([float(v) for v in ba_h[b, j, :4]])
                     areas.append(int(ba_h[b, j, 4]))
         return kept, rles, boxes, areas, range_bad
+
+    # ints of the packed transition list that ride along with the small tables, per image (256 KB; a quarter of it per image in batches
+    # above 4): the 17 kept masks of the config-3 fixture (480x640, noisy: ~1750 transitions each) are 29.8 k
+    PACK_HEAD = 65536
 
     def encode_masks(self, masks_u8: torch.Tensor, sel: np.ndarray, max_runs: int = 8192):
         """COCO RLE dicts, xyxy boxes and areas of the masks `sel` (flat indices into [n,H,W]) without moving the masks

@@ -412,25 +412,27 @@ class _EngineBase:
             ops.layernorm(t1, W_[pp + "norm1.w"], W_[pp + "norm1.b"], 1e-5, R, D, out_f32=norm_out32, out_f16=norm_out16, status=st)
         # tgt = zeros (zutis.py:164) and query_pos is a parameter, so layer 0's whole self-attention block — projections of
         # (0 + query_pos, 0), attention over the Q queries, out-projection, norm1 — does not depend on the image: its result
-        # (tgt after norm1, fp32 and fp16; [R, D] = the same Q rows for every image) is computed once per (batch rows, parameter
-        # version) with the same kernels and cached; layer 0 then starts at the cross-attention.
+        # (tgt after norm1, fp32 and fp16; [R, D] = the same Q rows for every image) and the cross-attention's query projection of
+        # it (:281-282) are computed once per (batch rows, parameter version) with the same kernels and cached; layer 0 then
+        # starts at the cross-attention itself.
         ikey = ("dec_init", R, self._packed_key)
         init = self._geo.get(ikey)
         if init is None:
             dev = self._device()
             z16 = Act(torch.zeros((2 if xd else 1, R, D), dtype=f16, device=dev))
-            init = {"tgt0": torch.empty((R, D), dtype=f32, device=dev), "tgt0_16": Act.empty((R, D), xd, dev)}
+            init = {"tgt0": torch.empty((R, D), dtype=f32, device=dev), "tgt0_16": Act.empty((R, D), xd, dev), "qc0_16": Act.empty((R, D), xd, dev)}
             self_attention_block("dec.0.", z16, None, init["tgt0"], init["tgt0_16"])      # q = k = query_pos, v = 0, + tgt (= 0)
+            self._gemm("dec", init["tgt0_16"], W_["dec.0.ca_q_w"], init["qc0_16"], residual=W_["dec.0.ca_q_tab"], res_rows=Q)
             self._geo_put(ikey, init)
         for l in range(L):
             pp = f"dec.{l}."
             if l == 0:
-                tgt_in, tgt_in16 = init["tgt0"], init["tgt0_16"]
+                tgt_in, qc = init["tgt0"], init["qc0_16"]
             else:
                 self_attention_block(pp, tgt16, tgt, tgt, tgt16)                            # transformer.py:272-278
-                tgt_in, tgt_in16 = tgt, tgt16
-            self._gemm("dec", tgt_in16, W_[pp + "ca_q_w"], qc16, residual=W_[pp + "ca_q_tab"], res_rows=Q)   # :281-282 query projection
-            ops.attention(qc16, KALL.view(KALL.hi[:, l * D:]), VALL.view(VALL.hi[:, l * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=M,
+                tgt_in, qc = tgt, qc16
+                self._gemm("dec", tgt16, W_[pp + "ca_q_w"], qc16, residual=W_[pp + "ca_q_tab"], res_rows=Q)   # :281-282 query projection
+            ops.attention(qc, KALL.view(KALL.hi[:, l * D:]), VALL.view(VALL.hi[:, l * D:]), o16, batch=B, heads=heads, Tq=Q, Tk=M,
                           head_dim=dh, ldq=D, ldk=L * D, ldv=L * D, ldo=D, strideQ=Q * D, strideK=M * L * D, strideV=M * L * D,
                           strideO=Q * D, x3=xk, ksplit=ksplit, workspace=attn_ws)
             self._gemm("dec", o16, W_[pp + "ca_o_w"], t1, bias=W_[pp + "ca_o_b"], residual=tgt_in)

@@ -468,16 +468,20 @@ def mask_nms(inter, uni, scores, category_ids, nms_type="hard", nms_threshold=0.
     return idx, sc, cat, cnt
 
 
-def mask_runs_kept(masks_u8, kept_index, kept_count, max_runs, pos, nr, ba):
+def mask_runs_kept(masks_u8, kept_index, kept_count, max_runs, pos, nr, ba, packed=False):
     """masks u8 [B,Q,H,W]; kept_index int32 [B,Q] / kept_count int32 [B] = zh_mask_nms' device outputs -> pos int32 [B*Q,max_runs], nr
-    int32 [B*Q,2], ba int32 [B*Q,5] (row b*Q + j = image b's j-th kept mask; rows past the count are not written)."""
+    int32 [B*Q,2], ba int32 [B*Q,5] (row b*Q + j = image b's j-th kept mask; rows past the count are not written).  packed: pos is ONE
+    int32 list (any length) that takes the kept masks' transitions back to back, min(#transitions, max_runs) each, as far as it reaches."""
     L = _lib.load()
     _chk(masks_u8, torch.uint8, "mask_runs_kept masks"); _chk(kept_index, torch.int32, "kept_index"); _chk(kept_count, torch.int32, "kept_count")
+    _chk(pos, torch.int32, "mask_runs_kept pos")
     B, Q, H, W = masks_u8.shape
+    if not packed and pos.numel() < B * Q * max_runs:
+        raise ZutisHipError(f"mask_runs_kept: pos holds {pos.numel()} ints, the row form needs {B * Q * max_runs}")
     need = int(_lib.load(raw=True).zh_mask_runs_workspace_size(B * Q, W))
     ws = torch.empty(need, dtype=torch.uint8, device=masks_u8.device)
-    _lib.check(L.zh_mask_runs_kept(_p(masks_u8), _p(kept_index), _p(kept_count), B, Q, H, W, max_runs, _p(pos), _p(nr), _p(ba), _p(ws), need, _stream()),
-               "zh_mask_runs_kept")
+    _lib.check(L.zh_mask_runs_kept(_p(masks_u8), _p(kept_index), _p(kept_count), B, Q, H, W, max_runs, _p(pos), pos.numel() if packed else 0,
+                                   _p(nr), _p(ba), _p(ws), need, _stream()), "zh_mask_runs_kept")
 
 
 # ---------------------------------------------------------------------------------------- bilateral solver (float64)

@@ -124,21 +124,25 @@ def rle_from_transitions(positions: np.ndarray, first_value: int, h: int, w: int
     return {"size": [int(h), int(w)], "counts": buf.raw[:n]}
 
 
-def rles_from_transitions(positions: np.ndarray, nruns: np.ndarray, h: int, w: int):
+def rles_from_transitions(positions: np.ndarray, nruns: np.ndarray, h: int, w: int, packed_max_runs: int = 0):
     """The COCO RLE dicts of all n masks from zh_mask_runs' host copies in ONE C call (zh_rle_from_transitions_host): positions int32
     [n, keep], nruns int32 [n, 2] = (transitions, value of pixel 0).  Entry i is None when mask i has more transitions than `keep`
-    (the caller re-encodes it from the mask itself)."""
+    (the caller re-encodes it from the mask itself).  packed_max_runs > 0: positions is zh_mask_runs_kept's packed list (1-D: mask i's
+    min(transitions, packed_max_runs) entries follow mask i - 1's)."""
     import ctypes as C
     from . import _lib
-    pos = np.ascontiguousarray(positions, dtype=np.int32)
-    nr = np.ascontiguousarray(nruns, dtype=np.int32)
-    n, keep = pos.shape
-    cap = int(8 * (np.minimum(nr[:, 0], keep).astype(np.int64) + 3).sum() + 16)
+    pos = positions if (positions.dtype == np.int32 and positions.flags.c_contiguous) else np.ascontiguousarray(positions, dtype=np.int32)
+    nr = nruns if (nruns.dtype == np.int32 and nruns.flags.c_contiguous) else np.ascontiguousarray(nruns, dtype=np.int32)
+    n = nr.shape[0]
+    keep = int(packed_max_runs) if packed_max_runs else pos.shape[1]
+    nt = nr[:, 0].tolist()
+    cap = 8 * (sum(min(t, keep) for t in nt) + 3 * n) + 16
     buf = C.create_string_buffer(cap)
     off = np.empty(n + 1, dtype=np.int64)
-    total = _lib.load().zh_rle_from_transitions_host(pos.ctypes.data, keep, nr.ctypes.data, n, h * w, C.addressof(buf), cap, off.ctypes.data)
+    total = _lib.load(raw=True).zh_rle_from_transitions_host(pos.ctypes.data, keep, 1 if packed_max_runs else 0, nr.ctypes.data, n, h * w,
+                                                             C.addressof(buf), cap, off.ctypes.data)
     assert total >= 0
     raw = buf.raw
     size = [int(h), int(w)]
-    return [({"size": size, "counts": raw[off[i]:off[i + 1]]} if nr[i, 0] <= keep else None) for i in range(n)]
-
+    o = off.tolist()
+    return [({"size": size, "counts": raw[o[i]:o[i + 1]]} if nt[i] <= keep else None) for i in range(n)]
