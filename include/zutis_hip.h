@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 221 /* 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list); 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 222 /* 222: zh_mask_rle_kept; 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list), packed form of zh_rle_from_transitions_host; 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -322,6 +322,14 @@ int zh_mask_runs(const unsigned char* masks, const int* sel, int n_sel, int H, i
 int zh_mask_runs_kept(const unsigned char* masks, const int* kept_index, const int* kept_count, int B, int Q, int H, int W, int max_runs,
                       int* positions, long packed_capacity, int* nruns, int* box_area, void* workspace, size_t workspace_bytes,
                       zh_stream_t stream);
+
+/* COCO RLE strings of the kept masks on the device (= pycocotools.mask.encode(...)["counts"], zutis.py:290,448) from zh_mask_runs_kept's
+ * PACKED list and nruns table: mask b*Q + j (j < kept_count[b]) gets its string at out + 5 * off + 16 * rank, off = start of its list in
+ * `positions` (sum of min(transitions, max_runs) over the kept masks in front of it), rank = number of kept masks in front of it;
+ * out_len int32 [B*Q] = the string's length, -1 when the mask has more than max_runs transitions or its list / string does not fit the
+ * capacities (the caller encodes that mask from its pixels).  HW = pixels per mask. */
+int zh_mask_rle_kept(const int* positions, long packed_capacity, const int* nruns, const int* kept_count, int B, int Q, int max_runs, long HW,
+                     unsigned char* out, long out_capacity, int* out_len, zh_stream_t stream);
 
 /* Native launch plans (zutis_amd/plan.py): replay n recorded calls of the entry points above (op id + 24 argument words
  * each; dispatcher generated from this header) in one C loop; zh_plan_run2 alternates two plans on two streams. */

@@ -546,6 +546,57 @@ def test_device_mask_nms_matches_reference_control_flow(dev, nms_type, Q):
         assert kept3 == eng_kept and rles3 == rles1 and boxes3 == boxes1 and areas3 == areas1, kw
 
 
+def test_device_rle_strings_equal_the_host_encoder(dev):
+    """zh_mask_rle_kept: the COCO RLE strings the device writes from the packed run list are byte for byte the host encoder's
+    (= pycocotools.mask.encode, tests/test_rle.py pins that one): noisy masks (long strings, several 256-run chunks), blobs, an empty and
+    a full mask, pixel 0 set, a single pixel at the very end; a mask over max_runs and lists past the capacity report -1."""
+    from zutis_amd import ops, rle
+    rng = np.random.default_rng(11)
+    B, Q, H, W = 2, 9, 61, 83
+    masks = np.zeros((B, Q, H, W), np.uint8)
+    for b in range(B):
+        masks[b, 0] = rng.random((H, W)) > 0.5                      # ~2500 transitions
+        masks[b, 1, 10:40, 5:70] = 1
+        masks[b, 3] = 1                                             # full (2: empty)
+        masks[b, 4, 0, 0] = 1
+        masks[b, 5, H - 1, W - 1] = 1
+        masks[b, 6] = rng.random((H, W)) > 0.97
+        masks[b, 7, :, ::2] = 1                                     # runs of exactly H pixels: every delta against run k - 2 is 0
+        masks[b, 8, ::2, :] = 1                                     # runs of one pixel
+    md = torch.from_numpy(masks).to(dev)
+    order = [np.array([3, 0, 8, 2, 5, 1, 7], np.int32), np.array([4, 6, 0], np.int32)]
+    idx = torch.zeros((B, Q), dtype=torch.int32)
+    for b in range(B):
+        idx[b, :len(order[b])] = torch.from_numpy(order[b])
+    cnt = torch.tensor([len(o) for o in order], dtype=torch.int32)
+    idx, cnt = idx.to(dev), cnt.to(dev)
+    for max_runs, cap in ((8192, 1 << 16), (3000, 1 << 16), (8192, 6000)):
+        pos = torch.empty((cap,), dtype=torch.int32, device=dev)
+        nr = torch.empty((B * Q, 2), dtype=torch.int32, device=dev)
+        ba = torch.empty((B * Q, 5), dtype=torch.int32, device=dev)
+        ops.mask_runs_kept(md, idx, cnt, max_runs, pos, nr, ba, packed=True)
+        out = torch.zeros((5 * cap + 16 * B * Q,), dtype=torch.uint8, device=dev)
+        ln = torch.full((B * Q,), -7, dtype=torch.int32, device=dev)
+        ops.mask_rle_kept(pos, nr, cnt, B, Q, max_runs, H * W, out, ln)
+        out_h, ln_h, nr_h = out.cpu().numpy(), ln.cpu().numpy().reshape(B, Q), nr.cpu().numpy().reshape(B, Q, 2)
+        off = rank = n_bad = 0
+        for b in range(B):
+            for j, q in enumerate(order[b]):
+                want = rle.encode(masks[b, q])["counts"]
+                nt = int(nr_h[b, j, 0])
+                fits = nt <= max_runs and off + nt <= cap
+                if fits:
+                    c0 = 5 * off + 16 * rank
+                    assert ln_h[b, j] == len(want) and out_h[c0:c0 + len(want)].tobytes() == want, (max_runs, cap, b, j)
+                else:
+                    assert ln_h[b, j] == -1, (max_runs, cap, b, j)
+                    n_bad += 1
+                off += min(nt, max_runs)
+                rank += 1
+            assert (ln_h[b, len(order[b]):] == -7).all()            # slots past the count are not touched
+        assert (n_bad > 0) == ((max_runs, cap) != (8192, 1 << 16))
+
+
 def test_range_flag_of_the_instance_statistics(dev):
     """The reference asserts 0 <= mask_proposals <= 1 (zutis.py:385-386): zh_instance_mask_stats raises a device flag for a value
     outside the range or a NaN, and leaves it alone otherwise."""

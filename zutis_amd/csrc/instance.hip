@@ -519,6 +519,98 @@ extern "C" int zh_mask_runs_kept(const unsigned char* masks, const int* kept_ind
   return launch_mask_runs("zh_mask_runs_kept", a, B * Q, workspace, workspace_bytes, stream);
 }
 
+// ---- COCO RLE strings of the kept masks, on the device (pycocotools rleEncode + rleToString, the strings of zutis.py:290,448).
+// Input: zh_mask_runs_kept's packed list (column-major pixel indices where the value changes) and its nruns table.  One workgroup per
+// kept mask: run k = edge(k + 1) - edge(k) with edge(0) = 0, edge(i) = positions[i - 1], edge(nt + 1) = H*W (plus a leading empty run of
+// zeros when pixel 0 is set: the format starts with zeros); x_k = run_k - run_{k-2} for k > 2, else run_k; x is written as little-endian
+// 5-bit groups, bit 5 = "more", + 48 — the number of groups is a function of x alone, so a block scan of the group counts places every
+// run's characters.  Mask mi's string starts at 5 * off(mi) + 16 * rank(mi) in `out` (off = the start of its list in the packed
+// positions, rank = kept masks in front of it: both follow from nruns and the counts, on the host too), out_len[mi] = its length, or
+// -1 when the mask has more than max_runs transitions or its list / string lies past a capacity (the host encodes that mask itself).
+struct RleArgs {
+  const int* positions; long packed_cap; const int* nruns; const int* count; int Q, max_runs; long HW;
+  unsigned char* out; long out_cap; int* out_len;
+};
+__device__ __forceinline__ int rle_groups(long x) {
+  int n = 0;
+  bool more = true;
+  while (more) {
+    const long ch = x & 0x1f;
+    x >>= 5;
+    more = (ch & 0x10) ? x != -1 : x != 0;
+    ++n;
+  }
+  return n;
+}
+__global__ __launch_bounds__(256) void mask_rle_kernel(RleArgs a) {
+  __shared__ int s_a[256], s_b[256];
+  __shared__ int s_w[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mi = blockIdx.x;
+  if (mi % a.Q >= a.count[mi / a.Q]) return;               // whole workgroup, before any barrier
+  int part = 0, rank = 0;
+  for (int mp = tid; mp < mi; mp += 256)
+    if (mp % a.Q < a.count[mp / a.Q]) { part += min(a.nruns[2 * mp], a.max_runs); ++rank; }
+  s_a[tid] = part; s_b[tid] = rank;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) { s_a[tid] += s_a[tid + st]; s_b[tid] += s_b[tid + st]; }
+    __syncthreads();
+  }
+  const long off = s_a[0], cstart = 5L * s_a[0] + 16L * s_b[0];
+  const int nt = a.nruns[2 * mi], lead = a.nruns[2 * mi + 1] != 0 ? 1 : 0;
+  const int nc = nt + 1 + lead;
+  if (nt > a.max_runs || off + nt > a.packed_cap || cstart + 5L * nc > a.out_cap) {
+    if (tid == 0) a.out_len[mi] = -1;
+    return;
+  }
+  const int* p = a.positions + off;
+  unsigned char* o = a.out + cstart;
+  auto run = [&](int k) -> long {                           // k in [0, nc)
+    if (lead) { if (k == 0) return 0; --k; }
+    const long lo = k == 0 ? 0 : p[k - 1], hi = k == nt ? a.HW : p[k];
+    return hi - lo;
+  };
+  int base = 0;
+  for (int k0 = 0; k0 < nc; k0 += 256) {
+    const int k = k0 + tid;
+    long x = 0;
+    int n = 0;
+    if (k < nc) { x = run(k); if (k > 2) x -= run(k - 2); n = rle_groups(x); }
+    int inc = n;                                            // inclusive scan: within the wave by shuffles, across the four waves through LDS
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    __syncthreads();                                        // (the previous chunk's s_w reads are done)
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += s_w[w];
+    const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (k < nc) {
+      unsigned char* q = o + base + wbase + inc - n;
+      bool more = true;
+      while (more) {
+        long ch = x & 0x1f;
+        x >>= 5;
+        more = (ch & 0x10) ? x != -1 : x != 0;
+        if (more) ch |= 0x20;
+        *q++ = (unsigned char)(ch + 48);
+      }
+    }
+    base += total;
+  }
+  if (tid == 0) a.out_len[mi] = base;
+}
+extern "C" int zh_mask_rle_kept(const int* positions, long packed_capacity, const int* nruns, const int* kept_count, int B, int Q, int max_runs,
+                                long HW, unsigned char* out, long out_capacity, int* out_len, hipStream_t stream) {
+  ZH_CHECK_ARG(positions && nruns && kept_count && out && out_len && B > 0 && Q > 0 && max_runs > 0 && HW > 0 && packed_capacity > 0 &&
+               out_capacity > 0, "zh_mask_rle_kept: bad arguments");
+  ZH_CHECK_ARG((long)B * Q * max_runs < (1L << 31) / 5 && HW < (1L << 31), "zh_mask_rle_kept: B*Q*max_runs or H*W too large");
+  RleArgs a{positions, packed_capacity, nruns, kept_count, Q, max_runs, HW, out, out_capacity, out_len};
+  hipLaunchKernelGGL(mask_rle_kernel, dim3(B * Q), dim3(256), 0, stream, a);
+  ZH_CHECK_LAUNCH("zh_mask_rle_kept");
+  return ZH_OK;
+}
+
 // ---- greedy per-category mask NMS on the device (networks/zutis.py:211-299, copy at coco20k_eval.py:54-136).
 // One workgroup per image; inputs are the exact integer intersection / union counts of zh_mask_iou_counts, so every IoU is
 // inter / (union + 1e-7) in float64 exactly as utils/iou.py:30-32 computes it on boolean masks.  Control flow of the

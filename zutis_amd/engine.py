@@ -369,8 +369,8 @@ class ZutisEngine(_EngineBase):
         """instance_nms + encode_masks chained on the device (zutis.py:211-299,423-469): popcount IoU counts, the greedy per-category
         loop, then the run extraction of the kept masks straight from the loop's device outputs (zh_mask_runs_kept) — the NMS result
         does not visit the host in between.  ONE device -> host copy brings the kept triples, every query's category, the counts, the
-        range flag, the run counts, the boxes AND the kept masks' run positions as one packed list (a second copy only when the list outgrows
-        the PACK_HEAD ints per image that ride along).
+        range flag, the run counts, the boxes AND the kept masks' COCO RLE strings, encoded on the device (zh_mask_rle_kept) from the packed
+        run list; the host encodes only when that list outgrows its PACK_HEAD ints per image (a second copy) or a mask its max_runs.
         Returns (kept [(batch index, category, query index, score)] in the reference's emission order, rles, boxes, areas, status) — status =
         the word behind `range_flag` as the NMS kernel read it (bit ops.STATUS_RANGE: a proposal outside [0, 1]; the engine's own
         status_word() also carries ops.STATUS_NONFINITE from the forward)."""
@@ -382,55 +382,69 @@ class ZutisEngine(_EngineBase):
         m = masks_u8.contiguous()
         for b in range(B):
             ops.mask_iou_counts(m[b], Q, H * W, inter[b], uni[b])
-        # ONE buffer for everything the host needs: [kept triples + categories + count + status (f64) | run counts | boxes + areas | the
-        # head of the packed transition list (PACK_HEAD ints per image)]
-        n1, n2, n3 = B * (4 * Q + 2) * 8, B * Q * 2 * 4, B * Q * 5 * 4
+        # ONE buffer for everything the host needs: [kept triples + categories + count + status (f64) | run counts | boxes + areas | string
+        # lengths | the RLE strings of the kept masks, written by the device (zh_mask_rle_kept) from the packed transition list].  The list
+        # itself (PACK_HEAD ints per image) stays on the device.
+        n1, n2, n3, n4 = B * (4 * Q + 2) * 8, B * Q * 2 * 4, B * Q * 5 * 4, B * Q * 4
         head = int(min(B * Q * max_runs, B * ((ZutisEngine.PACK_HEAD if B <= 4 else ZutisEngine.PACK_HEAD // 4) if pack_head is None else pack_head)))
-        small = torch.empty((n1 + n2 + n3 + 4 * head,), dtype=torch.uint8, device=dev)
+        small = torch.empty((n1 + n2 + n3 + n4 + 5 * head + 16 * B * Q,), dtype=torch.uint8, device=dev)
         packed = small[:n1].view(torch.float64).view(B, 4 * Q + 2)
         nr = small[n1:n1 + n2].view(torch.int32).view(B * Q, 2)
         ba = small[n1 + n2:n1 + n2 + n3].view(torch.int32).view(B * Q, 5)
-        pos_head = small[n1 + n2 + n3:].view(torch.int32)
+        slen = small[n1 + n2 + n3:n1 + n2 + n3 + n4].view(torch.int32)
+        chars = small[n1 + n2 + n3 + n4:]
+        pos_head = torch.empty((head,), dtype=torch.int32, device=dev)
         idx, _, _, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma, threshold,
                                       packed=packed, range_flag=range_flag)
         ops.mask_runs_kept(m, idx, cnt, max_runs, pos_head, nr, ba, packed=True)
+        ops.mask_rle_kept(pos_head, nr, cnt, B, Q, max_runs, H * W, chars, slen)
         host = _to_host(small)                                       # the one synchronisation of the predict
         pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)
         nr_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 2)
         ba_h = host[n1 + n2:n1 + n2 + n3].view(np.int32).reshape(B, Q, 5)
-        cnt_h = pk[:, 4 * Q].astype(np.int64)
+        slen_h = host[n1 + n2 + n3:n1 + n2 + n3 + n4].view(np.int32).reshape(B, Q)
+        chars_h = host[n1 + n2 + n3 + n4:]
+        cnt_l = pk[:, 4 * Q].astype(np.int64).tolist()
         range_bad = int(pk[:, 4 * Q + 1].max()) if range_flag is not None else 0      # the status word as the NMS kernel read it (ops.STATUS_*)
-        mc = int(cnt_h.max()) if B else 0
         kept, rles, boxes, areas = [], [], [], []
-        if mc > 0:
-            lens = [np.minimum(nr_h[b, :int(cnt_h[b]), 0], max_runs).astype(np.int64) for b in range(B)]     # list length of every kept mask
-            total = int(sum(int(l.sum()) for l in lens))
-            if total <= head:
-                flat = host[n1 + n2 + n3:].view(np.int32)
-            else:                                                    # the lists outgrew the head: the whole packed list in a second copy
-                big = torch.empty((total,), dtype=torch.int32, device=dev)
+        if B and max(cnt_l) > 0:
+            lens = [np.minimum(nr_h[b, :cnt_l[b], 0], max_runs).tolist() for b in range(B)]          # list length of every kept mask
+            total = sum(sum(l) for l in lens)
+            flat = None
+            if total > head:                                         # the lists outgrew the head: the whole packed list in a second copy,
+                big = torch.empty((total,), dtype=torch.int32, device=dev)                          # strings built on the host
                 ops.mask_runs_kept(m, idx, cnt, max_runs, big, nr, ba, packed=True)
                 flat = big.cpu().numpy()
-            all_cat = pk[:, 3 * Q:4 * Q].astype(np.int64)
-            at = 0
+            size = [int(H), int(W)]
+            at = rank_all = 0
             for b in range(B):
-                n = int(cnt_h[b])
+                n = cnt_l[b]
                 if n == 0:
                     continue
-                r = rle.rles_from_transitions(flat[at:], nr_h[b, :n], H, W, packed_max_runs=max_runs)     # image b's lists start at `at`
-                at += int(lens[b].sum())
+                if flat is not None:
+                    r = rle.rles_from_transitions(flat[at:], nr_h[b, :n], H, W, packed_max_runs=max_runs)     # image b's lists start at `at`
+                    at += sum(lens[b])
+                else:
+                    r, sl = [], slen_h[b, :n].tolist()
+                    for j in range(n):                               # mask j's string: 5 * (start of its list) + 16 * (kept masks before it)
+                        c0 = 5 * at + 16 * rank_all
+                        r.append({"size": size, "counts": chars_h[c0:c0 + sl[j]].tobytes()} if sl[j] >= 0 else None)
+                        at += lens[b][j]
+                        rank_all += 1
                 # the kernel walks the categories in ascending id; the reference walks `set(category_ids_per_image)` (zutis.py:237-238):
                 # order the per-category groups by that very set (stable inside a category: the kernel's = the reference's selection order)
-                rank = {int(c): i for i, c in enumerate(set(all_cat[b]))}
-                order = sorted(range(n), key=lambda j: rank[int(pk[b, 2 * Q + j])])
+                row = pk[b].tolist()
+                rank = {int(c): i for i, c in enumerate(set(pk[b, 3 * Q:4 * Q].astype(np.int64)))}
+                order = sorted(range(n), key=lambda j: rank[int(row[2 * Q + j])])
+                ba_l = ba_h[b, :n].tolist()
                 for j in order:
-                    q = int(pk[b, j])
+                    q = int(row[j])
                     if r[j] is None:                                 # pathological mask (> max_runs transitions): the host encoder
                         r[j] = rle.encode(masks_u8[b, q].cpu().numpy())
-                    kept.append((b, int(pk[b, 2 * Q + j]), q, float(pk[b, Q + j])))
+                    kept.append((b, int(row[2 * Q + j]), q, float(row[Q + j])))
                     rles.append(r[j])
-                    boxes.append([float(v) for v in ba_h[b, j, :4]])
-                    areas.append(int(ba_h[b, j, 4]))
+                    boxes.append([float(v) for v in ba_l[j][:4]])
+                    areas.append(int(ba_l[j][4]))
         return kept, rles, boxes, areas, range_bad
 
     # ints of the packed transition list that ride along with the small tables, per image (256 KB; a quarter of it per image in batches

@@ -484,6 +484,16 @@ def mask_runs_kept(masks_u8, kept_index, kept_count, max_runs, pos, nr, ba, pack
                                    _p(nr), _p(ba), _p(ws), need, _stream()), "zh_mask_runs_kept")
 
 
+def mask_rle_kept(pos_packed, nr, kept_count, B, Q, max_runs, HW, out, out_len):
+    """COCO RLE strings of the kept masks on the device from mask_runs_kept(packed=True)'s list: out u8 (any length) takes mask b*Q + j's
+    string at 5 * off + 16 * rank (see include/zutis_hip.h), out_len int32 [B*Q] its length (-1: the caller encodes that mask itself)."""
+    L = _lib.load()
+    _chk(pos_packed, torch.int32, "mask_rle_kept positions"); _chk(nr, torch.int32, "mask_rle_kept nruns"); _chk(kept_count, torch.int32, "kept_count")
+    _chk(out, torch.uint8, "mask_rle_kept out"); _chk(out_len, torch.int32, "mask_rle_kept out_len")
+    _lib.check(L.zh_mask_rle_kept(_p(pos_packed), pos_packed.numel(), _p(nr), _p(kept_count), B, Q, max_runs, HW, _p(out), out.numel(), _p(out_len),
+                                  _stream()), "zh_mask_rle_kept")
+
+
 # ---------------------------------------------------------------------------------------- bilateral solver (float64)
 def denormalize_u8(x, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
     """utils/utils.py:261-273 on device: x f32 [3,H,W] -> rgb u8 [H,W,3]."""
