@@ -38,14 +38,30 @@ def wrap(obj, name):
     setattr(obj, name, w)
 from zutis_amd import rle
 wrap(eng, "instance_candidates"); wrap(eng, "instance_nms_encode"); wrap(rle, "rles_from_transitions"); wrap(eng, "forward_graphed")
+# the serial host stretch between the predict's synchronisation and the next forward's graph launch (the GPU idles through it)
+import zutis_amd.engine as E
+marks = {}
+_th = E._to_host
+def to_host(t):
+    r = _th(t); marks["sync"] = time.perf_counter(); return r
+E._to_host = to_host
+_rp = torch.cuda.CUDAGraph.replay
+def replay(self):
+    marks["replay"] = time.perf_counter(); return _rp(self)
+torch.cuda.CUDAGraph.replay = replay
 n = 60
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(n):
+    t_in = time.perf_counter()
     o = net(x)
+    if "ret" in marks:
+        seg["host: predict returned -> graph launch"] = seg.get("host: predict returned -> graph launch", 0.0) + marks["replay"] - marks["ret"]
     t1 = time.perf_counter()
     inst(o)
-    seg["predict (whole)"] = seg.get("predict (whole)", 0.0) + time.perf_counter() - t1
+    marks["ret"] = time.perf_counter()
+    seg["host: synchronised -> predict returns"] = seg.get("host: synchronised -> predict returns", 0.0) + marks["ret"] - marks["sync"]
+    seg["predict (whole)"] = seg.get("predict (whole)", 0.0) + marks["ret"] - t1
 torch.cuda.synchronize()
 tot = (time.perf_counter() - t0) / n * 1e3
 print(f"joint {tot:.3f} ms per image; host time per image inside:")

@@ -26,4 +26,6 @@ for r in sel:
         nblk = -1
     print("%8.2f us  gap %7.2f  blocks %6d x %4s  lds %6s  %s" % ((e - s) / 1e3, gap, nblk, wg, r.get("LDS_Block_Size", "?"), r["Kernel_Name"][:110]))
 span = int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])
+if occ > 1 and i1 < len(rows) and i1 == i0 + len(sel):
+    print("idle until the next %s: %.2f us" % (first, (int(rows[i1]["Start_Timestamp"]) - prev) / 1e3))
 print("launches %d  busy %.3f ms  span %.3f ms" % (len(sel), busy / 1e6, span / 1e6))

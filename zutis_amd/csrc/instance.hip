@@ -531,6 +531,7 @@ struct RleArgs {
   const int* positions; long packed_cap; const int* nruns; const int* count; int Q, max_runs; long HW;
   unsigned char* out; long out_cap; int* out_len;
 };
+#define RLE_LDS_RUNS 8192
 __device__ __forceinline__ int rle_groups(long x) {
   int n = 0;
   bool more = true;
@@ -563,7 +564,15 @@ __global__ __launch_bounds__(256) void mask_rle_kernel(RleArgs a) {
     if (tid == 0) a.out_len[mi] = -1;
     return;
   }
+  // the mask's list goes to LDS in one sweep of wide loads (every run is read four times below: 25 -> ~10 us for the fixture's
+  // 1750-transition masks); lists longer than the LDS copy are read where they lie
+  __shared__ int s_p[RLE_LDS_RUNS];
   const int* p = a.positions + off;
+  if (nt <= RLE_LDS_RUNS) {
+    for (int i = tid; i < nt; i += 256) s_p[i] = p[i];
+    __syncthreads();
+    p = s_p;
+  }
   unsigned char* o = a.out + cstart;
   auto run = [&](int k) -> long {                           // k in [0, nc)
     if (lead) { if (k == 0) return 0; --k; }

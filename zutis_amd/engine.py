@@ -188,11 +188,23 @@ class ZutisEngine(_EngineBase):
         """Same result as forward(), replayed from a hipGraph captured once per input shape.  At batch 1-4 the eager path is
         host-bound (~230 launches x ~11 us of Python/ctypes = 2.7 ms per forward regardless of B); COCO-20K evaluation
         (coco20k_eval.py:241-268) runs batch 1.  Outputs are fresh tensors (copied out of the graph's static buffers)."""
-        self._pack()
         key = ("graph", tuple(x.shape))
         g = self._geo.get(key)
-        if g is not None and g["weights"] != self._packed_key:
-            g = None                                 # parameters changed since capture: the graph holds the old packed weights
+        if g is not None and g["weights"] is self._packed_key:
+            # Launch first, check the parameters' versions behind the launch: walking the 275 parameters (_version_key) is 55 - 150 us of
+            # Python, and in a batch-1 evaluation loop the GPU idles through everything the host does between one image's predict and the
+            # next image's launch.  A parameter that changed since the capture (rare: load_state_dict after the first forward) makes
+            # this replay a wasted one: its outputs are dropped and the forward runs again on re-packed weights.
+            g["x"].copy_(x)
+            g["graph"].replay()
+            out = {k: v.clone() for k, v in g["out"].items()}
+            if self._version_key() == self._packed_key:
+                return out
+            self.status_word().zero_()               # whatever the stale weights raised
+        self._pack()                                 # (drops every graph when the parameters changed)
+        g = self._geo.get(key)
+        if g is not None and g["weights"] is not self._packed_key:
+            g = None
         if g is None:
             static_x = x.clone()
             s = torch.cuda.Stream()
