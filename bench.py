@@ -389,6 +389,20 @@ def batch1_object(precision, dev, steps=40):
     ms_step, preds = timed(lambda: inst(net(x)), steps)
     ms_fwd, out = timed(lambda: net(x), steps)
     ms_sem, _ = timed(lambda: net.predict(out, mask_type="semantic", size=(H, W)), steps)
+    # the body of trainer.evaluate's loop for coco2017 / voc2012 (trainer.py:327-348): forward, semantic predict, instance predict, the metric
+    # meter's update with the ground truth (a host int64 array, as the loader hands it over) and get_scores(), every image
+    from utils.running_score import RunningScore
+    meter = RunningScore(81, device=dev)
+    gt = np.random.default_rng(3).integers(0, 81, (1, H, W)).astype(np.int64)
+
+    def trainer_body():
+        o = net(x)
+        sem = net.predict(o, mask_type="semantic", size=(H, W))
+        r = inst(o)
+        meter.update(gt, sem)
+        meter.get_scores()
+        return r
+    ms_loop, _ = timed(trainer_body, steps)
     graph = bool(net.use_hip_graph)
     counts = {}
     net.use_hip_graph = False                      # count the C-ABI launches of one eager forward / predict (a graph replays the same ones)
@@ -404,7 +418,11 @@ def batch1_object(precision, dev, steps=40):
     return {"what": "ONE 480x640 image per call through the drop-in networks.zutis.ZUTIS (the reference's evaluation regime: val batch_size 1, "
                     "trainer.py:328-345, coco20k_eval.py:258-267): forward + predict(instance, hard NMS) to COCO RLE dicts",
             "ms_per_image": round(ms_step, 3), "images_per_s": round(1e3 / ms_step, 1), "forward_ms": round(ms_fwd, 3),
-            "instance_predict_ms": round(ms_step - ms_fwd, 3), "semantic_predict_ms": round(ms_sem, 3), "steps": steps,
+            "instance_predict_ms": round(ms_step - ms_fwd, 3), "semantic_predict_ms": round(ms_sem, 3),
+            "trainer_evaluate_body_ms": round(ms_loop, 3),
+            "trainer_evaluate_body_what": "trainer.py:327-348 per image: forward + predict(semantic) + predict(instance, hard NMS) + RunningScore.update(host "
+                                          "ground truth, predictions) + get_scores()",
+            "steps": steps,
             "hip_graph_replay": graph, "precision": precision, "library_calls_forward": n_fwd, "library_calls_instance_predict": n_all - n_fwd,
             "library_calls_note": "C-ABI entry-point calls (zh_*) of one eager forward / predict; a few launch two kernels (split attention + "
                                   "merge, global LayerNorm, IoU pack + counts, run extraction): profiles/r04_c3_launch_list.txt lists the kernels",

@@ -67,3 +67,24 @@ tot = (time.perf_counter() - t0) / n * 1e3
 print(f"joint {tot:.3f} ms per image; host time per image inside:")
 for k, v in seg.items():
     print(f"   {k:28s} {v / n * 1e3:.3f} ms")
+
+# the body of trainer.evaluate's loop (trainer.py:327-348): + semantic predict, the metric meter's update and get_scores()
+import numpy as np
+from utils.running_score import RunningScore
+meter = RunningScore(81, device=dev)
+gt = np.random.default_rng(3).integers(0, 81, (1, H, W)).astype(np.int64)
+seg2 = {}
+def timed(name, fn):
+    t = time.perf_counter(); r = fn(); seg2[name] = seg2.get(name, 0.0) + time.perf_counter() - t; return r
+for it in range(n + 5):
+    if it == 5:
+        seg2.clear(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    o = timed("forward", lambda: net(x))
+    sem = timed("predict semantic", lambda: net.predict(o, mask_type="semantic", size=(H, W)))
+    timed("predict instance", lambda: inst(o))
+    timed("meter.update", lambda: meter.update(gt, sem))
+    timed("meter.get_scores", lambda: meter.get_scores())
+torch.cuda.synchronize()
+print(f"trainer.evaluate body {(time.perf_counter() - t0) / n * 1e3:.3f} ms per image; host time per image inside:")
+for k, v in seg2.items():
+    print(f"   {k:28s} {v / n * 1e3:.3f} ms")

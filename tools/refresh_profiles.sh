@@ -25,8 +25,9 @@ prof c5 $Q --workload c5 --inflight 1
 # batch 1 (config 3's shape through the drop-in module): per-kernel stats and the ordered launch list of ONE hipGraph-replayed forward + predict
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_c3 -- python3 tools/c3_trace_run.py graph 12 > gpurun_out/p_c3.log 2>&1
 f=$(find gpurun_out/p_c3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${R}_c3_graph_kernel_stats.csv
-python3 tools/trace_list.py gpurun_out/p_c3 im2col 1 > gpurun_out/${R}_c3_launch_list.txt 2>&1
+python3 tools/trace_list.py gpurun_out/p_c3 im2col 3 > gpurun_out/${R}_c3_launch_list.txt 2>&1
 rm -rf gpurun_out/p_c3
+python3 tools/b1_joint.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_b1_joint.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_bs -- python3 tools/bilateral_prof_run.py 1 > gpurun_out/p_bs.log 2>&1
 f=$(find gpurun_out/p_bs -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${R}_bilateral_b1_kernel_stats.csv
 rm -rf gpurun_out/p_bs
