@@ -75,7 +75,7 @@ extern "C" int zh_instance_mask_stats(const float* mask_proposals, long stride_i
 // (query tile, image) — 10 blocks at batch 1, the COCO-20K evaluation's regime, 4800 dependent iterations: 1.8 ms of the
 // 3.5 ms instance predict.)
 #define QT 10      // (round 4: 20 queries per block with 16 rows of loads in flight: 31 -> 60 us — 190 blocks, one round, each twice as long)
-#define MCH 128
+#define MCH 64     // pixels per block (round 4: 128 -> 64: twice the workgroups, half the dependent load rounds per workgroup)
 template <int CPT>
 __global__ __launch_bounds__(256) void masked_mean_kernel(const float* tokens, const unsigned char* binary, float* partial, int Q, int M, int E,
                                                           long rows) {
@@ -732,10 +732,43 @@ __global__ __launch_bounds__(256) void mask_nms_kernel(const int* inter, const i
 // spends its time in __syncthreads: ~11 per selection step (an 8-level argmax tree + 3), ~100 steps for the COCO-20K fixture: 52 us for
 // 100 candidates.  Here the whole workgroup first turns the image's integer counts into the Q x Q float64 IoU table in LDS (one
 // division per pair, done once, in parallel: the table replaces two loads and a float64 division per candidate and step) and notes which
-// masks are empty; then wave 0 alone runs the loop: a lane owns candidates lane, lane + 64, the argmax is six rounds of lane shuffles on
-// (score, index) keys, no barrier.  Same arithmetic (float64 scores, IoU = inter / (union + 1e-7) in float64), same tie rule (largest
+// masks are empty; then wave 0 alone runs the loop: a lane owns candidates lane, lane + 64, the argmax is a wave reduction of
+// (score, index) keys (nms_wave_argmax below), no barrier.  Same arithmetic (float64 scores, IoU = inter / (union + 1e-7) in float64), same tie rule (largest
 // index among equal maxima), same emission order.
 #define NMS_WAVE_MAXQ 128
+// argmax of (score, index) keys over a wave: four DPP steps inside each row of 16 lanes (quad xor 1, quad xor 2, half-row mirror, row
+// mirror: both lanes of a pair take the same winner, so after them every lane holds its row's), then the four rows' winners by
+// v_readlane — ~40 VALU instructions instead of six rounds of three ds_bpermute (each a trip through the LDS crossbar).
+__device__ __forceinline__ void nms_take(double& bv, int& bi, double ov, int oi) {
+  if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+}
+template <int CTRL>
+__device__ __forceinline__ void nms_dpp_step(double& bv, int& bi) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, bv);
+  const int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+  const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, 0xf, 0xf, false);
+  nms_take(bv, bi, __builtin_bit_cast(double, ((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo), oi);
+}
+__device__ __forceinline__ void nms_wave_argmax(double& bv, int& bi) {
+  nms_dpp_step<0xB1>(bv, bi);                                 // quad_perm [1,0,3,2]
+  nms_dpp_step<0x4E>(bv, bi);                                 // quad_perm [2,3,0,1]
+  nms_dpp_step<0x141>(bv, bi);                                // row_half_mirror
+  nms_dpp_step<0x140>(bv, bi);                                // row_mirror
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, bv);
+  const int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+  double rv[4]; int ri[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, 16 * r), h = (unsigned)__builtin_amdgcn_readlane(hi, 16 * r);
+    rv[r] = __builtin_bit_cast(double, ((unsigned long long)h << 32) | l);
+    ri[r] = __builtin_amdgcn_readlane(bi, 16 * r);
+  }
+  bv = rv[0]; bi = ri[0];
+#pragma unroll
+  for (int r = 1; r < 4; ++r) nms_take(bv, bi, rv[r], ri[r]);
+}
 __global__ __launch_bounds__(256) void mask_nms_wave_kernel(const int* inter, const int* uni, const float* scores, const long long* cats,
                                                             int Q, int nms_type, double thr, double sigma, double score_thr,
                                                             int* out_idx, double* out_score, long long* out_cat, int* out_count,
@@ -777,11 +810,7 @@ __global__ __launch_bounds__(256) void mask_nms_wave_kernel(const int* inter, co
         const int q = lane + 64 * e;
         if (act[e] && (sc[e] > bv || (sc[e] == bv && q > bi))) { bv = sc[e]; bi = q; }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
-      }
+      nms_wave_argmax(bv, bi);
       if (bi < 0) break;
       const int best = bi;
       if (!s_empty[best]) {
