@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 222 /* 222: zh_mask_rle_kept; 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list), packed form of zh_rle_from_transitions_host; 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 223 /* 223: zh_mask_rle_fused_kept; 222: zh_mask_rle_kept; 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list), packed form of zh_rle_from_transitions_host; 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -330,6 +330,17 @@ int zh_mask_runs_kept(const unsigned char* masks, const int* kept_index, const i
  * capacities (the caller encodes that mask from its pixels).  HW = pixels per mask. */
 int zh_mask_rle_kept(const int* positions, long packed_capacity, const int* nruns, const int* kept_count, int B, int Q, int max_runs, long HW,
                      unsigned char* out, long out_capacity, int* out_len, zh_stream_t stream);
+
+/* Runs + box + area + RLE string of the kept masks in ONE launch (one workgroup per kept mask, the mask held as bits in LDS): what
+ * zh_mask_runs_kept + zh_mask_rle_kept produce, for masks with W <= 1024 whose bits (H*W/8 bytes), count table and run list
+ * (4 * max_runs bytes) fit 150 KB of LDS (zh_mask_rle_fused_supported).  bits (may be NULL: the bytes of `masks` are packed instead) =
+ * the masks bit-packed as zh_mask_iou_counts leaves them in its workspace: u64 [B*Q][(H*W + 63) / 64], bit i of word w = pixel 64 w + i
+ * (row-major) is non-zero.  info int32 [B*Q, 8] = {offset of the string in `out`, its length (-1: not encoded — more than max_runs
+ * transitions, or `out` is full: the caller uses zh_mask_runs for that mask), xmin, ymin, xmax, ymax, area, transitions}; rows of slots
+ * j >= kept_count[b] are not written.  cursor: ONE int32 the caller has zeroed; strings are placed in order of arrival. */
+int zh_mask_rle_fused_supported(int H, int W, int max_runs);
+int zh_mask_rle_fused_kept(const unsigned char* masks, const unsigned long long* bits, const int* kept_index, const int* kept_count, int B, int Q,
+                           int H, int W, int max_runs, unsigned char* out, long out_capacity, int* cursor, int* info, zh_stream_t stream);
 
 /* Native launch plans (zutis_amd/plan.py): replay n recorded calls of the entry points above (op id + 24 argument words
  * each; dispatcher generated from this header) in one C loop; zh_plan_run2 alternates two plans on two streams. */

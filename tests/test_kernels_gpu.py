@@ -597,6 +597,69 @@ def test_device_rle_strings_equal_the_host_encoder(dev):
         assert (n_bad > 0) == ((max_runs, cap) != (8192, 1 << 16))
 
 
+@pytest.mark.parametrize("H,W", [(61, 83), (48, 64), (37, 200), (120, 1024)])
+def test_fused_run_box_string_kernel(dev, H, W):
+    """zh_mask_rle_fused_kept (one workgroup per kept mask: bits in LDS, word-parallel transitions, string placed by an atomic cursor):
+    strings byte for byte the host encoder's, boxes / areas = numpy's, for widths that are / are not multiples of 64 and pixel counts
+    that are / are not multiples of 16; a mask over max_runs and strings past the capacity report length -1 with box and area intact."""
+    from zutis_amd import ops, rle
+    assert ops.mask_rle_fused_supported(H, W, 8192) and not ops.mask_rle_fused_supported(64, 1025, 8192)
+    rng = np.random.default_rng(H * 1000 + W)
+    B, Q = 2, 10
+    masks = np.zeros((B, Q, H, W), np.uint8)
+    for b in range(B):
+        masks[b, 0] = rng.random((H, W)) > 0.5
+        masks[b, 1, H // 5:H // 2, W // 7:W - 3] = 1
+        masks[b, 3] = 1                                             # full (2: empty)
+        masks[b, 4, 0, 0] = 1
+        masks[b, 5, H - 1, W - 1] = 1
+        masks[b, 6] = (rng.random((H, W)) > 0.97) * 255             # any non-zero byte counts as set
+        masks[b, 7, :, ::2] = 1
+        masks[b, 8, ::2, :] = 1
+        masks[b, 9, :, W - 1] = 1                                   # last column only: the row-0 rule across the column boundary
+        masks[b, 9, H - 1, W - 2] = 1
+    md = torch.from_numpy(masks).to(dev)
+    order = [np.array([3, 0, 8, 2, 5, 1, 7, 9], np.int32), np.array([4, 6, 0, 9], np.int32)]
+    idx = torch.zeros((B, Q), dtype=torch.int32)
+    for b in range(B):
+        idx[b, :len(order[b])] = torch.from_numpy(order[b])
+    cnt = torch.tensor([len(o) for o in order], dtype=torch.int32)
+    idx, cnt = idx.to(dev), cnt.to(dev)
+    want = {(b, j): rle.encode((masks[b, q] != 0).astype(np.uint8))["counts"] for b in range(B) for j, q in enumerate(order[b])}
+    bits = torch.empty((B, Q, (H * W + 63) // 64), dtype=torch.int64, device=dev)       # the IoU step's bit-packed masks: the second source
+    for b in range(B):
+        ops.mask_iou_counts(md[b], Q, H * W, torch.empty((Q, Q), dtype=torch.int32, device=dev), torch.empty((Q, Q), dtype=torch.int32, device=dev),
+                            workspace=bits[b])
+    for max_runs, cap, src in ((8192, 1 << 20, None), (8192, 1 << 20, bits), (40, 1 << 20, bits), (8192, max(len(v) for v in want.values()) + 5, None)):
+        out = torch.zeros((cap,), dtype=torch.uint8, device=dev)
+        cursor = torch.zeros((1,), dtype=torch.int32, device=dev)
+        info = torch.full((B * Q, 8), -7, dtype=torch.int32, device=dev)
+        ops.mask_rle_fused_kept(md, idx, cnt, max_runs, out, cursor, info, bits=src)
+        out_h, info_h = out.cpu().numpy(), info.cpu().numpy().reshape(B, Q, 8)
+        n_bad, spans = 0, []
+        for b in range(B):
+            for j, q in enumerate(order[b]):
+                mk = masks[b, q] != 0
+                c0, ln, x0, y0, x1, y1, ar, nt = info_h[b, j].tolist()
+                f = mk.reshape(-1, order="F")
+                assert nt == int((f[1:] != f[:-1]).sum()) and ar == int(mk.sum()), (H, W, max_runs, cap, b, j)
+                if ar:
+                    ys, xs = np.nonzero(mk)
+                    assert (x0, y0, x1, y1) == (xs.min(), ys.min(), xs.max(), ys.max())
+                else:
+                    assert (x0, y0, x1, y1) == (W, H, -1, -1)
+                if ln >= 0:
+                    assert nt <= max_runs and out_h[c0:c0 + ln].tobytes() == want[b, j], (H, W, max_runs, cap, b, j)
+                    spans.append((c0, c0 + ln))
+                else:
+                    assert nt > max_runs or cap < (1 << 20), (H, W, max_runs, cap, b, j)     # with room for every string only the run limit refuses
+                    n_bad += 1
+            assert (info_h[b, len(order[b]):] == -7).all()          # slots past the count are not touched
+        spans.sort()
+        assert all(a1 <= b0 for (_, a1), (b0, _) in zip(spans, spans[1:]))      # the cursor hands out disjoint places
+        assert len(spans) > 0 and (n_bad > 0 or (max_runs, cap) == (8192, 1 << 20))
+
+
 def test_range_flag_of_the_instance_statistics(dev):
     """The reference asserts 0 <= mask_proposals <= 1 (zutis.py:385-386): zh_instance_mask_stats raises a device flag for a value
     outside the range or a NaN, and leaves it alone otherwise."""

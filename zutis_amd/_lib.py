@@ -60,6 +60,8 @@ _SIGS = {
     "zh_topk_rows": (_i, [_vp, _l, _i, _l, _i, _vp, C.c_longlong, _vp, _vp, _l, _vp]),
     "zh_mask_runs_workspace_size": (_sz, [_i, _i]),
     "zh_mask_runs": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "zh_mask_rle_fused_supported": (_i, [_i, _i, _i]),
+    "zh_mask_rle_fused_kept": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "zh_mask_rle_kept": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _l, _vp, _l, _vp, _vp]),
     "zh_mask_runs_kept": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _sz, _vp]),
     "zh_rle_counts_to_string_host": (C.c_long, [_vp, C.c_long, _vp, C.c_long]),

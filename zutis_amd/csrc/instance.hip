@@ -620,6 +620,294 @@ extern "C" int zh_mask_rle_kept(const int* positions, long packed_capacity, cons
   return ZH_OK;
 }
 
+// ---- the same three steps (runs, box / area, RLE string) of a kept mask in ONE workgroup and ONE launch (round 4; the batch-1 predict's tail was
+// count 27 + emit 18 + string 21 us, each a chain of a dozen dependent ~1-us steps on 17 busy workgroups).  With one workgroup per mask the
+// per-pixel walk of the panel kernels would be 17 CUs doing what 170 did, so everything here is word-parallel on the mask's BITS (row-major,
+// H*W/8 bytes in LDS: 38 KB for 480x640; copied from the IoU step's bit-packed workspace when the caller has it, else packed from the bytes
+// with 16-byte loads).  A transition of the column-major order is a bit of T = B xor (B moved down one row) (row 0 against the last row of
+// the column to the left).  A thread owns (32-column panel p, 16-row chunk s):
+//   pass 1: its 16 words of T go through a bit-sliced vertical counter (5 planes, registers): per-column counts of the chunk -> part[s][c];
+//   then a per-column prefix over the chunks (in place) and a block scan over the columns give every (column, chunk)'s place in the list;
+//   pass 2: the 16 words again (registers); per column that has a transition in the chunk, its rows in ascending order -> list[place++];
+//   string: mask_rle_kernel's steps from the LDS list into an LDS buffer (one pass: the length falls out of the scan), an atomic cursor
+//           places it in `out` (order of arrival: the host reads every string's offset from `info`), a coalesced copy writes it.
+// No LDS read-modify-write anywhere.  info int32 [B*Q][8] = {string offset, string length (-1: not encoded — more than max_runs
+// transitions or `out` full), xmin, ymin, xmax, ymax, area, transitions}; rows of slots past an image's count are not written.
+struct FusedRleArgs {
+  const unsigned char* masks; const unsigned long long* bits; const int* sel; const int* count; int Q, H, W, max_runs;
+  unsigned char* out; long out_cap; int* cursor; int* info;
+};
+#define FRLE_ROWS 16                                         // rows per chunk (= counts per (chunk, column) fit the 5-plane counter)
+#ifdef ZH_FRLE_STAMP   // developer build (tools/rle_fused_stamp.py): thread 0's 100-MHz clock at the phase boundaries, in the LAST 64 B x slot of `out`
+#define FRLE_STAMP(i) do { if (tid == 0) ((long long*)(a.out + a.out_cap - 64L * (mi + 1)))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FRLE_STAMP(i) do { } while (0)
+#endif
+__device__ __forceinline__ unsigned rle_bits4(unsigned w) {  // bit k = byte k of w is non-zero
+  const unsigned nz = zh_nz_bytes(w);
+  return (nz & 1u) | ((nz >> 7) & 2u) | ((nz >> 14) & 4u) | ((nz >> 21) & 8u);
+}
+struct FrleLayout { long n64; int P, S, Wp; size_t o_part, o_coloff, o_list, total; };
+__host__ __device__ static inline FrleLayout frle_layout(int H, int W, int max_runs) {
+  FrleLayout L;
+  L.n64 = ((long)H * W + 63) >> 6;
+  L.P = (W + 31) >> 5;                                       // 32-column panels
+  L.Wp = ((W + 63) >> 6) * 64; L.S = (H + FRLE_ROWS - 1) / FRLE_ROWS;
+  L.o_part = (size_t)(L.n64 + 2) * 8;                        // u64 bits[n64 + 2] (two zero words behind the last: funnel reads)
+  size_t r0 = L.o_part + (size_t)L.S * L.Wp * 2;             // u16 part[S][Wp]
+  const size_t cb = ((size_t)5 * (max_runs + 2) + 15) & ~(size_t)15;
+  if (r0 < cb) r0 = cb;                                      // the string is built over bits + part once they are dead
+  L.o_coloff = r0;
+  L.o_list = L.o_coloff + (size_t)L.Wp * 4;                  // int coloff[Wp]
+  L.total = L.o_list + (size_t)max_runs * 4;                 // int list[max_runs]
+  return L;
+}
+__global__ __launch_bounds__(1024) void mask_rle_fused_kernel(FusedRleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  __shared__ int s_w[16], s_red[5][16];
+  __shared__ int s_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nw = nthr >> 6, mi = blockIdx.x;
+  if (mi % a.Q >= a.count[mi / a.Q]) return;                // whole workgroup, before any barrier
+  const int H = a.H, W = a.W;
+  const long HW = (long)H * W;
+  FRLE_STAMP(0);
+  const long mask_index = (long)(mi / a.Q) * a.Q + a.sel[mi];
+  const FrleLayout L = frle_layout(H, W, a.max_runs);
+  unsigned long long* Bw = (unsigned long long*)dyn;
+  unsigned* B32 = (unsigned*)dyn;                            // bit (f & 31) of B32[f >> 5] = pixel f (row-major) is set
+  unsigned short* part = (unsigned short*)(dyn + L.o_part);
+  int* coloff = (int*)(dyn + L.o_coloff);
+  int* list = (int*)(dyn + L.o_list);
+  if (a.bits) {
+    const unsigned long long* src = a.bits + mask_index * L.n64;
+    for (long i = tid; i < L.n64; i += nthr) Bw[i] = src[i];
+    for (long i = L.n64 + tid; i < L.n64 + 2; i += nthr) Bw[i] = 0;
+  } else {
+    const unsigned char* m = a.masks + mask_index * HW;
+    unsigned short* B16 = (unsigned short*)dyn;
+    const long n16 = (HW + 15) >> 4;
+    if (HW % 16 == 0 && ((uintptr_t)m & 15) == 0) {
+#pragma unroll 8
+      for (long i = tid; i < n16; i += nthr) {
+        const uint4 v = ((const uint4*)m)[i];
+        B16[i] = (unsigned short)(rle_bits4(v.x) | (rle_bits4(v.y) << 4) | (rle_bits4(v.z) << 8) | (rle_bits4(v.w) << 12));
+      }
+    } else {
+      for (long i = tid; i < n16; i += nthr) {
+        unsigned b = 0;
+        for (int k = 0; k < 16; ++k)
+          if (16 * i + k < HW && m[16 * i + k]) b |= 1u << k;
+        B16[i] = (unsigned short)b;
+      }
+    }
+    for (long i = n16 + tid; i < (L.n64 + 2) * 4; i += nthr) B16[i] = 0;
+  }
+  for (int i = tid; i < L.S * L.Wp / 2; i += nthr) ((unsigned*)part)[i] = 0;
+  __syncthreads();
+  FRLE_STAMP(1);
+  // 32 columns of row y, from column 32 p on (bits past the row's end are 0)
+  auto rowword = [&](int y, int p) -> unsigned {
+    const long f0 = (long)y * W + 32L * p;
+    const int sh = (int)(f0 & 31);
+    const unsigned lo = B32[f0 >> 5], hi = B32[(f0 >> 5) + 1];
+    unsigned w = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    const int nb = W - 32 * p;
+    if (nb < 32) w &= (1u << nb) - 1u;
+    return w;
+  };
+  // the 16 words of T of item (p, chunk sc) (rows past H: 0); row 0 is compared with the LAST row one column to the left (column 0 of the
+  // mask: pixel 0 itself, no transition)
+  auto item_words = [&](int p, int sc, unsigned (&t)[FRLE_ROWS], int& area, int& miny, int& maxy, unsigned& ored) {
+    const int y0 = sc * FRLE_ROWS;
+    unsigned prev;
+    if (y0 == 0) {
+      const unsigned last = rowword(H - 1, p);
+      prev = (last << 1) | (p ? rowword(H - 1, p - 1) >> 31 : (rowword(0, 0) & 1u));
+    } else prev = rowword(y0 - 1, p);
+    const int nb = min(32, W - 32 * p);
+    const unsigned cmask = nb < 32 ? (1u << nb) - 1u : ~0u;
+#pragma unroll
+    for (int i = 0; i < FRLE_ROWS; ++i) {
+      const int y = y0 + i;
+      unsigned cur = 0;
+      t[i] = 0;
+      if (y < H) {
+        cur = rowword(y, p);
+        t[i] = (cur ^ prev) & cmask;
+        prev = cur;
+        if (cur) { area += __popc(cur); miny = min(miny, y); maxy = y; ored |= cur; }
+      }
+    }
+  };
+  // ---- pass 1: per-column transition counts of every (chunk, panel); area, box
+  const int nitems = L.P * L.S;
+  int area = 0, miny = H, maxy = -1, minx = W, maxx = -1;
+  unsigned t_first[FRLE_ROWS];                               // the thread's first item's words, kept for pass 2 (most shapes: its only item)
+  for (int it = tid; it < nitems; it += nthr) {
+    const int p = it % L.P, sc = it / L.P;
+    unsigned t[FRLE_ROWS], ored = 0;
+    item_words(p, sc, t, area, miny, maxy, ored);
+    if (it == tid) {
+#pragma unroll
+      for (int i = 0; i < FRLE_ROWS; ++i) t_first[i] = t[i];
+    }
+    if (ored) { minx = min(minx, 32 * p + __ffs((int)ored) - 1); maxx = max(maxx, 32 * p + 31 - __clz((int)ored)); }
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;         // bit j of (c4 c3 c2 c1 c0) = transitions of column j so far (<= 16)
+#pragma unroll
+    for (int i = 0; i < FRLE_ROWS; ++i) {
+      unsigned carry = t[i], x;
+      x = c0 & carry; c0 ^= carry; carry = x;
+      x = c1 & carry; c1 ^= carry; carry = x;
+      x = c2 & carry; c2 ^= carry; carry = x;
+      x = c3 & carry; c3 ^= carry; carry = x;
+      c4 ^= carry;
+    }
+    unsigned any = c0 | c1 | c2 | c3 | c4;
+    unsigned short* pc = part + (long)sc * L.Wp + 32 * p;
+    while (any) {
+      const int j = __ffs((int)any) - 1;
+      any &= any - 1;
+      pc[j] = (unsigned short)(((c0 >> j) & 1u) | (((c1 >> j) & 1u) << 1) | (((c2 >> j) & 1u) << 2) | (((c3 >> j) & 1u) << 3) | (((c4 >> j) & 1u) << 4));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    area += __shfl_xor(area, o, 64);
+    miny = min(miny, __shfl_xor(miny, o, 64)); maxy = max(maxy, __shfl_xor(maxy, o, 64));
+    minx = min(minx, __shfl_xor(minx, o, 64)); maxx = max(maxx, __shfl_xor(maxx, o, 64));
+  }
+  if (lane == 0) { s_red[0][wave] = area; s_red[1][wave] = miny; s_red[2][wave] = maxy; s_red[3][wave] = minx; s_red[4][wave] = maxx; }
+  __syncthreads();
+  FRLE_STAMP(2);
+  // ---- per column: exclusive prefix over the chunks (in place), then a block scan of the column totals -> coloff
+  int ctot = 0;
+  if (tid < L.Wp) {
+    for (int sc = 0; sc < L.S; ++sc) { const int v = part[(long)sc * L.Wp + tid]; part[(long)sc * L.Wp + tid] = (unsigned short)ctot; ctot += v; }
+  }
+  int inc = ctot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int wbase = 0, nt = 0;
+  for (int w = 0; w < nw; ++w) { if (w < wave) wbase += s_w[w]; nt += s_w[w]; }
+  if (tid < L.Wp) coloff[tid] = wbase + inc - ctot;
+  int* info = a.info + (long)mi * 8;
+  if (tid == 0) {
+    int A = 0, y0 = H, y1 = -1, x0 = W, x1 = -1;
+    for (int w = 0; w < nw; ++w) { A += s_red[0][w]; y0 = min(y0, s_red[1][w]); y1 = max(y1, s_red[2][w]); x0 = min(x0, s_red[3][w]); x1 = max(x1, s_red[4][w]); }
+    info[2] = x0; info[3] = y0; info[4] = x1; info[5] = y1; info[6] = A; info[7] = nt;
+  }
+  if (nt > a.max_runs) {
+    if (tid == 0) { info[0] = 0; info[1] = -1; }
+    return;
+  }
+  const int lead = (int)(B32[0] & 1u), nc = nt + 1 + lead;
+  __syncthreads();
+  FRLE_STAMP(3);
+  // ---- pass 2: the same threads write their transitions to their places in the list, column by column
+  for (int it = tid; it < nitems; it += nthr) {
+    const int p = it % L.P, sc = it / L.P, y0 = sc * FRLE_ROWS;
+    unsigned t[FRLE_ROWS], ored = 0;
+    if (it == tid) {
+#pragma unroll
+      for (int i = 0; i < FRLE_ROWS; ++i) t[i] = t_first[i];
+    } else {
+      int d0 = 0, d1 = 0, d2 = 0;
+      item_words(p, sc, t, d0, d1, d2, ored);
+    }
+    unsigned any = 0;
+#pragma unroll
+    for (int i = 0; i < FRLE_ROWS; ++i) any |= t[i];
+    const unsigned short* pc = part + (long)sc * L.Wp + 32 * p;
+    const int* co = coloff + 32 * p;
+    // per column with a transition: its 16 row bits gathered into one word, then one store per set bit; the NEXT column's place is
+    // requested from LDS before this column's stores (the two loads were a third of the pass when they sat in front of every column)
+    int j = any ? __ffs((int)any) - 1 : 0;
+    int o = co[j] + pc[j];
+    while (any) {
+      any &= any - 1;
+      const int jn = any ? __ffs((int)any) - 1 : j;
+      const int on = co[jn] + pc[jn];
+      unsigned cw = 0;
+#pragma unroll
+      for (int i = 0; i < FRLE_ROWS; ++i) cw |= ((t[i] >> j) & 1u) << i;
+      const int v = (32 * p + j) * H + y0;
+      while (cw) { list[o++] = v + __ffs((int)cw) - 1; cw &= cw - 1; }
+      j = jn; o = on;
+    }
+  }
+  __syncthreads();
+  FRLE_STAMP(4);
+  // ---- the string (see mask_rle_kernel) into LDS, over the dead bits / counts
+  unsigned char* cbuf = dyn;
+  auto run = [&](int k) -> long {
+    if (lead) { if (k == 0) return 0; --k; }
+    const long lo = k == 0 ? 0 : list[k - 1], hi = k == nt ? HW : list[k];
+    return hi - lo;
+  };
+  auto put = [&](unsigned char* q, long x) {
+    bool more = true;
+    while (more) {
+      long ch = x & 0x1f;
+      x >>= 5;
+      more = (ch & 0x10) ? x != -1 : x != 0;
+      if (more) ch |= 0x20;
+      *q++ = (unsigned char)(ch + 48);
+    }
+  };
+  int base = 0;
+  for (int k0 = 0; k0 < nc; k0 += 2 * nthr) {                 // two consecutive runs per thread and step (half the barriers)
+    const int k = k0 + 2 * tid;
+    long xa = 0, xb = 0;
+    int na = 0, nb = 0;
+    if (k < nc) { xa = run(k); if (k > 2) xa -= run(k - 2); na = rle_groups(xa); }
+    if (k + 1 < nc) { xb = run(k + 1); if (k + 1 > 2) xb -= run(k - 1); nb = rle_groups(xb); }
+    int in2 = na + nb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(in2, d, 64); if (lane >= d) in2 += t; }
+    __syncthreads();                                        // (the previous step's s_w reads are done)
+    if (lane == 63) s_w[wave] = in2;
+    __syncthreads();
+    int wb = 0, total = 0;
+    for (int w = 0; w < nw; ++w) { if (w < wave) wb += s_w[w]; total += s_w[w]; }
+    unsigned char* q = cbuf + base + wb + in2 - na - nb;
+    if (k < nc) put(q, xa);
+    if (k + 1 < nc) put(q + na, xb);
+    base += total;
+  }
+  if (tid == 0) {
+    const int off = atomicAdd(a.cursor, base);
+    const bool fits = (long)off + base <= a.out_cap;
+    info[0] = off; info[1] = fits ? base : -1;
+    s_off = fits ? off : -1;
+  }
+  __syncthreads();
+  FRLE_STAMP(5);
+  if (s_off < 0) return;
+  unsigned char* o = a.out + s_off;
+  for (int i = tid; i < base; i += nthr) o[i] = cbuf[i];
+  FRLE_STAMP(6);
+}
+static size_t rle_fused_lds(int H, int W, int max_runs) { return frle_layout(H, W, max_runs).total; }
+extern "C" int zh_mask_rle_fused_supported(int H, int W, int max_runs) {
+  return H > 0 && W > 0 && W <= 1024 && max_runs > 0 && (long)H * W < (1L << 31) && rle_fused_lds(H, W, max_runs) <= 150 * 1024;
+}
+extern "C" int zh_mask_rle_fused_kept(const unsigned char* masks, const unsigned long long* bits, const int* kept_index, const int* kept_count,
+                                      int B, int Q, int H, int W, int max_runs, unsigned char* out, long out_capacity, int* cursor, int* info,
+                                      hipStream_t stream) {
+  ZH_CHECK_ARG((masks || bits) && kept_index && kept_count && out && cursor && info && B > 0 && Q > 0 && out_capacity > 0 && (long)B * Q < (1L << 31),
+               "zh_mask_rle_fused_kept: bad arguments");
+  ZH_CHECK_ARG(zh_mask_rle_fused_supported(H, W, max_runs), "zh_mask_rle_fused_kept: H=%d W=%d max_runs=%d not supported (W <= 1024, bits + tables + list <= 150 KB of LDS)",
+               H, W, max_runs);
+  FusedRleArgs a{masks, bits, kept_index, kept_count, Q, H, W, max_runs, out, out_capacity, cursor, info};
+  const size_t lds = rle_fused_lds(H, W, max_runs);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mask_rle_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(mask_rle_fused_kernel, dim3(B * Q), dim3(((W + 63) / 64) * 64), lds, stream, a);     // >= one thread per column (W <= 1024)
+  ZH_CHECK_LAUNCH("zh_mask_rle_fused_kept");
+  return ZH_OK;
+}
+
 // ---- greedy per-category mask NMS on the device (networks/zutis.py:211-299, copy at coco20k_eval.py:54-136).
 // One workgroup per image; inputs are the exact integer intersection / union counts of zh_mask_iou_counts, so every IoU is
 // inter / (union + 1e-7) in float64 exactly as utils/iou.py:30-32 computes it on boolean masks.  Control flow of the

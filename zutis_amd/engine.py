@@ -392,13 +392,58 @@ class ZutisEngine(_EngineBase):
         inter = torch.empty((B, Q, Q), dtype=torch.int32, device=dev)
         uni = torch.empty((B, Q, Q), dtype=torch.int32, device=dev)
         m = masks_u8.contiguous()
+        bits = torch.empty((B, Q, (H * W + 63) // 64), dtype=torch.int64, device=dev)     # the IoU step's bit-packed masks, read again below
         for b in range(B):
-            ops.mask_iou_counts(m[b], Q, H * W, inter[b], uni[b])
+            ops.mask_iou_counts(m[b], Q, H * W, inter[b], uni[b], workspace=bits[b])
+        per_image = (ZutisEngine.PACK_HEAD if B <= 4 else ZutisEngine.PACK_HEAD // 4) if pack_head is None else pack_head
+        if ops.mask_rle_fused_supported(H, W, max_runs):
+            # ONE launch behind the NMS loop does runs, boxes, areas and strings (zh_mask_rle_fused_kept: one workgroup per kept mask);
+            # ONE buffer = one copy for everything the host needs: [kept triples + categories + count + status (f64) | info | cursor | strings]
+            n1, n2 = B * (4 * Q + 2) * 8, B * Q * 8 * 4
+            cap = int(max(64, 4 * B * per_image))                    # bytes of strings that ride along (a string is ~2.2 B per transition)
+            small = torch.empty((n1 + n2 + 8 + cap,), dtype=torch.uint8, device=dev)
+            packed = small[:n1].view(torch.float64).view(B, 4 * Q + 2)
+            info = small[n1:n1 + n2].view(torch.int32).view(B * Q, 8)
+            cursor = small[n1 + n2:n1 + n2 + 8].view(torch.int32)
+            cursor.zero_()
+            idx, _, _, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma, threshold,
+                                          packed=packed, range_flag=range_flag)
+            ops.mask_rle_fused_kept(m, idx, cnt, max_runs, small[n1 + n2 + 8:], cursor, info, bits=bits)
+            host = _to_host(small)                                   # the one synchronisation of the predict
+            pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)
+            info_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 8)
+            chars_h = host[n1 + n2 + 8:]
+            cnt_l = pk[:, 4 * Q].astype(np.int64).tolist()
+            range_bad = int(pk[:, 4 * Q + 1].max()) if range_flag is not None else 0  # the status word as the NMS kernel read it (ops.STATUS_*)
+            kept, rles, boxes, areas = [], [], [], []
+            size = [int(H), int(W)]
+            redo = []                                                # (position in the output lists, flat mask index): strings the device did not write
+            for b in range(B):
+                n = cnt_l[b]
+                if n == 0:
+                    continue
+                row, inf = pk[b].tolist(), info_h[b, :n].tolist()
+                # the kernel walks the categories in ascending id; the reference walks `set(category_ids_per_image)` (zutis.py:237-238):
+                # order the per-category groups by that very set (stable inside a category: the kernel's = the reference's selection order)
+                rank = {int(c): i for i, c in enumerate(set(pk[b, 3 * Q:4 * Q].astype(np.int64)))}
+                for j in sorted(range(n), key=lambda j: rank[int(row[2 * Q + j])]):
+                    q, (c0, ln, x0, y0, x1, y1, ar, _) = int(row[j]), inf[j]
+                    if ln < 0:                                       # over max_runs transitions, or the strings outgrew `cap`
+                        redo.append((len(kept), b * Q + q))
+                    kept.append((b, int(row[2 * Q + j]), q, float(row[Q + j])))
+                    rles.append({"size": size, "counts": chars_h[c0:c0 + ln].tobytes()} if ln >= 0 else None)
+                    boxes.append([float(x0), float(y0), float(x1), float(y1)])
+                    areas.append(int(ar))
+            if redo:
+                r2, _, _ = ZutisEngine.encode_masks(self, masks_u8.view(B * Q, H, W), np.array([f for _, f in redo], dtype=np.int32))
+                for (at, _), r in zip(redo, r2):
+                    rles[at] = r
+            return kept, rles, boxes, areas, range_bad
         # ONE buffer for everything the host needs: [kept triples + categories + count + status (f64) | run counts | boxes + areas | string
         # lengths | the RLE strings of the kept masks, written by the device (zh_mask_rle_kept) from the packed transition list].  The list
         # itself (PACK_HEAD ints per image) stays on the device.
         n1, n2, n3, n4 = B * (4 * Q + 2) * 8, B * Q * 2 * 4, B * Q * 5 * 4, B * Q * 4
-        head = int(min(B * Q * max_runs, B * ((ZutisEngine.PACK_HEAD if B <= 4 else ZutisEngine.PACK_HEAD // 4) if pack_head is None else pack_head)))
+        head = int(min(B * Q * max_runs, B * per_image))
         small = torch.empty((n1 + n2 + n3 + n4 + 5 * head + 16 * B * Q,), dtype=torch.uint8, device=dev)
         packed = small[:n1].view(torch.float64).view(B, 4 * Q + 2)
         nr = small[n1:n1 + n2].view(torch.int32).view(B * Q, 2)

@@ -436,10 +436,14 @@ def instance_classify(avg, text, conf, temperature, rows, n, E, category, score)
                                       _stream()), "zh_instance_classify")
 
 
-def mask_iou_counts(masks_u8, n, pixels, inter, uni):
+def mask_iou_counts(masks_u8, n, pixels, inter, uni, workspace=None):
+    """workspace (optional, >= zh_mask_iou_workspace_size bytes, any dtype): kept by the caller, it holds the masks bit-packed afterwards
+    (u64 [n][(pixels + 63) // 64]: the `bits` of mask_rle_fused_kept)."""
     L = _lib.load()
     need = L.zh_mask_iou_workspace_size(n, pixels)
-    ws = torch.empty(need, dtype=torch.uint8, device=masks_u8.device)
+    ws = workspace if workspace is not None else torch.empty(need, dtype=torch.uint8, device=masks_u8.device)
+    if ws.numel() * ws.element_size() < need:
+        raise ZutisHipError(f"mask_iou_counts: workspace holds {ws.numel() * ws.element_size()} bytes, {need} needed")
     _lib.check(L.zh_mask_iou_counts(_p(masks_u8), n, pixels, _p(inter), _p(uni), _p(ws), need, _stream()), "zh_mask_iou_counts")
 
 
@@ -492,6 +496,27 @@ def mask_rle_kept(pos_packed, nr, kept_count, B, Q, max_runs, HW, out, out_len):
     _chk(out, torch.uint8, "mask_rle_kept out"); _chk(out_len, torch.int32, "mask_rle_kept out_len")
     _lib.check(L.zh_mask_rle_kept(_p(pos_packed), pos_packed.numel(), _p(nr), _p(kept_count), B, Q, max_runs, HW, _p(out), out.numel(), _p(out_len),
                                   _stream()), "zh_mask_rle_kept")
+
+
+def mask_rle_fused_supported(H, W, max_runs) -> bool:
+    return bool(_lib.load(raw=True).zh_mask_rle_fused_supported(int(H), int(W), int(max_runs)))
+
+
+def mask_rle_fused_kept(masks_u8, kept_index, kept_count, max_runs, out, cursor, info, bits=None):
+    """Runs, box, area and COCO RLE string of the kept masks in one launch (include/zutis_hip.h): masks u8 [B,Q,H,W], kept_index int32
+    [B,Q] / kept_count int32 [B] = zh_mask_nms' outputs; out u8 (any length) takes the strings, cursor int32 [1] (zeroed by the caller)
+    places them, info int32 [B*Q, 8] = (offset, length or -1, xmin, ymin, xmax, ymax, area, transitions) per kept slot.  bits: the masks
+    bit-packed by mask_iou_counts(..., workspace=) — int64 [B, Q, (H*W + 63) // 64] — read instead of the bytes."""
+    L = _lib.load()
+    _chk(masks_u8, torch.uint8, "mask_rle_fused_kept masks"); _chk(kept_index, torch.int32, "kept_index"); _chk(kept_count, torch.int32, "kept_count")
+    _chk(out, torch.uint8, "mask_rle_fused_kept out"); _chk(cursor, torch.int32, "cursor"); _chk(info, torch.int32, "info")
+    B, Q, H, W = masks_u8.shape
+    if bits is not None:
+        _chk(bits, torch.int64, "mask_rle_fused_kept bits")
+        if bits.numel() != B * Q * ((H * W + 63) // 64):
+            raise ZutisHipError(f"mask_rle_fused_kept: bits holds {bits.numel()} words, {B * Q * ((H * W + 63) // 64)} expected")
+    _lib.check(L.zh_mask_rle_fused_kept(_p(masks_u8), None if bits is None else _p(bits), _p(kept_index), _p(kept_count), B, Q, H, W, max_runs,
+                                        _p(out), out.numel(), _p(cursor), _p(info), _stream()), "zh_mask_rle_fused_kept")
 
 
 # ---------------------------------------------------------------------------------------- bilateral solver (float64)
