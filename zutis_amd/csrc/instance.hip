@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float* tokens, c
     sm[q][m] = (q < nq && m < mc) ? binary[((long)b * Q + q0 + q) * M + m0 + m] : 0;
   }
   __syncthreads();
-#pragma unroll 8                                         // eight rows of loads in flight (same summation order per accumulator)
+#pragma unroll 8                                         // eight rows of loads in flight (same summation order per accumulator; 16: 208 VGPRs)
   for (int m = 0; m < mc; ++m) {
     float v[CPT];
 #pragma unroll
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void instance_classify_kernel(const float* avg
     float d[CPP];
 #pragma unroll
     for (int j = 0; j < CPP; ++j) { t[j] = text + (long)(cls + 4 * j < n ? cls + 4 * j : cls) * E; d[j] = 0.f; }
+#pragma unroll 8                                         // E = 512: all 8 x CPP loads of a pass in flight (same summation order per class)
     for (int c = lane; c < E; c += 64) {
       const float x = sv[c] * inv;
 #pragma unroll
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void mask_iou_counts_kernel(const unsigned lon
   for (int a = 0; a < IOU_T; ++a)
 #pragma unroll
     for (int b = 0; b < IOU_T; ++b) { ci[a][b] = 0; cu[a][b] = 0; }
+#pragma unroll 4                                             // 32 loads in flight per thread (19 dependent rounds for 480 x 640 otherwise)
   for (long w = threadIdx.x; w < W64; w += 256) {
     unsigned long long x[IOU_T], y[IOU_T];
 #pragma unroll
@@ -1067,6 +1069,7 @@ __global__ __launch_bounds__(256) void mask_nms_wave_kernel(const int* inter, co
   inter += (long)img * Q * Q; uni += (long)img * Q * Q;
   scores += (long)img * Q; cats += (long)img * Q;
   out_idx += (long)img * Q; out_score += (long)img * Q; out_cat += (long)img * Q;
+#pragma unroll 8                                             // eight pairs of loads in flight (40 dependent round trips for Q = 100 otherwise: ~25 of this kernel's 37 us)
   for (int i = tid; i < Q * Q; i += 256) s_iou[i] = (double)inter[i] / ((double)uni[i] + 1e-7);
   for (int q = tid; q < Q; q += 256) s_empty[q] = inter[q * Q + q] <= 0;       // area of the mask = |m & m|: empty masks are not emitted
   __syncthreads();
