@@ -43,7 +43,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 223 /* 223: zh_mask_rle_fused_kept; 222: zh_mask_rle_kept; 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list), packed form of zh_rle_from_transitions_host; 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 224 /* 224: zero_word of zh_mask_nms; 223: zh_mask_rle_fused_kept; 222: zh_mask_rle_kept; 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list), packed form of zh_rle_from_transitions_host; 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -302,9 +302,10 @@ int zh_topk_rows(const float* scores, long ld, int rows, long N, int k, const lo
 int zh_mask_nms(const int* inter, const int* uni, const float* scores, const long long* category_ids, int B, int Q,
                 int nms_type, double nms_threshold, double sigma, double score_threshold,
                 int* out_index, double* out_score, long long* out_category, int* out_count, double* packed, const int* range_flag,
-                zh_stream_t stream);
+                int* zero_word, zh_stream_t stream);
 /* packed (may be NULL): f64 [B, 4Q + 2] = per image [out_index (-1 past the count) | out_score | out_category | category_ids | count,
- * *range_flag] — everything the host needs in one device -> host copy. */
+ * *range_flag] — everything the host needs in one device -> host copy.  zero_word (may be NULL): one int32 the kernel sets to 0 — the
+ * cursor of the zh_mask_rle_fused_kept launched behind it (saves the caller a fill launch). */
 
 /* Device-side run extraction for COCO RLE + boxes + areas of selected masks (masks u8 [n,H,W] row-major; sel int32
  * [n_sel] mask indices): positions int32 [n_sel, max_runs] = column-major pixel indices where the value changes;

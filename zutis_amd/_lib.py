@@ -82,7 +82,7 @@ _SIGS = {
     "zh_plan_run": (_i, [_vp, _i, _vp]),
     "zh_plan_run_multi": (_i, [_vp, _vp, _vp, _i]),
     "zh_plan_run2": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
-    "zh_mask_nms": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zh_mask_nms": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zh_mask_iou_workspace_size": (_sz, [_i, _l]),
     "zh_mask_iou_counts": (_i, [_vp, _i, _l, _vp, _vp, _vp, _sz, _vp]),
 }

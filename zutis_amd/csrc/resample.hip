@@ -459,35 +459,22 @@ __global__ __launch_bounds__(256) void bilinear_mask_rows_kernel(const float* x,
 #pragma unroll
   for (int k = 0; k < 4; ++k) wx[k] = lin_weights(ox0 + k, w, W, scale_w);
   const float* px = x + (long)pl * h * w;
-  // four rows at a time: their 64 taps are requested together (a row at a time was eight dependent rounds of 16 loads per block); rows past
-  // H read row H - 1's taps (in range) and are not stored
 #pragma unroll
-  for (int r0 = 0; r0 < MASK_ROWS; r0 += 4) {
-    float tap[4][4][4];
-    LinW wy[4];
+  for (int r = 0; r < MASK_ROWS; ++r) {
+    const int oy = (int)rg * MASK_ROWS + r;
+    if (oy >= H) break;
+    const LinW wy = lin_weights(oy, h, H, scale_h);
+    const float* p0 = px + (long)wy.i0 * w;
+    const float* p1 = px + (long)wy.i1 * w;
+    unsigned packed = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int oy = min((int)rg * MASK_ROWS + r0 + r, H - 1);
-      wy[r] = lin_weights(oy, h, H, scale_h);
-      const float* p0 = px + (long)wy[r].i0 * w;
-      const float* p1 = px + (long)wy[r].i1 * w;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { tap[r][k][0] = p0[wx[k].i0]; tap[r][k][1] = p0[wx[k].i1]; tap[r][k][2] = p1[wx[k].i0]; tap[r][k][3] = p1[wx[k].i1]; }
+    for (int k = 0; k < 4; ++k) {
+      const float r0 = __fmaf_rn(p0[wx[k].i0], wx[k].l0, __fmul_rn(p0[wx[k].i1], wx[k].l1));
+      const float r1 = __fmaf_rn(p1[wx[k].i0], wx[k].l0, __fmul_rn(p1[wx[k].i1], wx[k].l1));
+      const float v = __fmaf_rn(r0, wy.l0, __fmul_rn(r1, wy.l1));
+      packed |= (v > threshold ? 1u : 0u) << (8 * k);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int oy = (int)rg * MASK_ROWS + r0 + r;
-      if (oy >= H) break;
-      unsigned packed = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float a0 = __fmaf_rn(tap[r][k][0], wx[k].l0, __fmul_rn(tap[r][k][1], wx[k].l1));
-        const float a1 = __fmaf_rn(tap[r][k][2], wx[k].l0, __fmul_rn(tap[r][k][3], wx[k].l1));
-        const float v = __fmaf_rn(a0, wy[r].l0, __fmul_rn(a1, wy[r].l1));
-        packed |= (v > threshold ? 1u : 0u) << (8 * k);
-      }
-      *(unsigned*)(mask + ((long)pl * H + oy) * W + ox0) = packed;
-    }
+    *(unsigned*)(mask + ((long)pl * H + oy) * W + ox0) = packed;
   }
 }
 

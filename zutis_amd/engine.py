@@ -404,10 +404,9 @@ class ZutisEngine(_EngineBase):
             small = torch.empty((n1 + n2 + 8 + cap,), dtype=torch.uint8, device=dev)
             packed = small[:n1].view(torch.float64).view(B, 4 * Q + 2)
             info = small[n1:n1 + n2].view(torch.int32).view(B * Q, 8)
-            cursor = small[n1 + n2:n1 + n2 + 8].view(torch.int32)
-            cursor.zero_()
+            cursor = small[n1 + n2:n1 + n2 + 8].view(torch.int32)    # zeroed by the NMS kernel (zero_word), used by the launch behind it
             idx, _, _, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma, threshold,
-                                          packed=packed, range_flag=range_flag)
+                                          packed=packed, range_flag=range_flag, zero_word=cursor)
             ops.mask_rle_fused_kept(m, idx, cnt, max_runs, small[n1 + n2 + 8:], cursor, info, bits=bits)
             host = _to_host(small)                                   # the one synchronisation of the predict
             pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)

@@ -451,7 +451,7 @@ NMS_TYPES = {"hard": 0, "linear": 1, "gaussian": 2}
 
 
 def mask_nms(inter, uni, scores, category_ids, nms_type="hard", nms_threshold=0.3, sigma=0.5, score_threshold=0.001, packed=None,
-             range_flag=None):
+             range_flag=None, zero_word=None):
     """Greedy per-category mask NMS on the device (zutis.py:211-299).  inter / uni int32 [B,Q,Q], scores f32 [B,Q], category_ids
     int64 [B,Q] -> (index int32 [B,Q], score f64 [B,Q], category int64 [B,Q], count int32 [B]); the first count[b] entries of
     row b are the kept queries in the reference's emission order."""
@@ -467,8 +467,8 @@ def mask_nms(inter, uni, scores, category_ids, nms_type="hard", nms_threshold=0.
     cat = torch.empty((B, Q), dtype=torch.int64, device=dev)
     cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     _lib.check(L.zh_mask_nms(_p(inter), _p(uni), _p(scores), _p(category_ids), B, Q, NMS_TYPES[nms_type], float(nms_threshold),
-                             float(sigma), float(score_threshold), _p(idx), _p(sc), _p(cat), _p(cnt), _p(packed), _p(range_flag), _stream()),
-               "zh_mask_nms")
+                             float(sigma), float(score_threshold), _p(idx), _p(sc), _p(cat), _p(cnt), _p(packed), _p(range_flag),
+                             None if zero_word is None else _p(zero_word), _stream()), "zh_mask_nms")
     return idx, sc, cat, cnt
 
 
