@@ -540,7 +540,8 @@ def test_device_mask_nms_matches_reference_control_flow(dev, nms_type, Q):
     assert rles2 == rles1 and boxes2 == boxes1 and areas2 == areas1
     # the kept masks' run positions ride along with the small tables as ONE packed list: a head too short for them (second copy of the
     # whole list) and a run capacity below some masks' transitions (those are re-encoded from the mask) give the same strings
-    for kw in (dict(pack_head=8), dict(max_runs=3), dict(max_runs=3, pack_head=8)):
+    for kw in (dict(pack_head=8), dict(max_runs=3), dict(max_runs=3, pack_head=8), dict(fused=False), dict(fused=False, pack_head=8),
+               dict(fused=False, max_runs=3), dict(fused=True)):
         kept3, rles3, boxes3, areas3, _ = ZutisEngine.instance_nms_encode(None, md, torch.from_numpy(scores).to(dev), torch.from_numpy(cats).to(dev),
                                                                           nms_type, **kw)
         assert kept3 == eng_kept and rles3 == rles1 and boxes3 == boxes1 and areas3 == areas1, kw

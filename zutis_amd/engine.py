@@ -377,7 +377,8 @@ class ZutisEngine(_EngineBase):
 
     def instance_nms_encode(self, masks_u8: torch.Tensor, scores: torch.Tensor, category_ids: torch.Tensor, nms_type: str = "hard",
                             nms_threshold: float = 0.3, sigma: float = 0.5, threshold: float = 0.001,
-                            range_flag: Optional[torch.Tensor] = None, max_runs: int = 8192, pack_head: Optional[int] = None):
+                            range_flag: Optional[torch.Tensor] = None, max_runs: int = 8192, pack_head: Optional[int] = None,
+                            fused: Optional[bool] = None):
         """instance_nms + encode_masks chained on the device (zutis.py:211-299,423-469): popcount IoU counts, the greedy per-category
         loop, then the run extraction of the kept masks straight from the loop's device outputs (zh_mask_runs_kept) — the NMS result
         does not visit the host in between.  ONE device -> host copy brings the kept triples, every query's category, the counts, the
@@ -385,7 +386,8 @@ class ZutisEngine(_EngineBase):
         run list; the host encodes only when that list outgrows its PACK_HEAD ints per image (a second copy) or a mask its max_runs.
         Returns (kept [(batch index, category, query index, score)] in the reference's emission order, rles, boxes, areas, status) — status =
         the word behind `range_flag` as the NMS kernel read it (bit ops.STATUS_RANGE: a proposal outside [0, 1]; the engine's own
-        status_word() also carries ops.STATUS_NONFINITE from the forward)."""
+        status_word() also carries ops.STATUS_NONFINITE from the forward).  fused (None = where supported): runs, boxes, areas and strings
+        from ONE launch (zh_mask_rle_fused_kept) instead of run extraction (two launches) + string kernel; same results."""
         from . import rle
         B, Q, H, W = masks_u8.shape
         dev = masks_u8.device
@@ -396,7 +398,9 @@ class ZutisEngine(_EngineBase):
         for b in range(B):
             ops.mask_iou_counts(m[b], Q, H * W, inter[b], uni[b], workspace=bits[b])
         per_image = (ZutisEngine.PACK_HEAD if B <= 4 else ZutisEngine.PACK_HEAD // 4) if pack_head is None else pack_head
-        if ops.mask_rle_fused_supported(H, W, max_runs):
+        if fused is None:
+            fused = ops.mask_rle_fused_supported(H, W, max_runs)     # masks up to 1024 columns whose bits + tables fit the LDS; else three launches
+        if fused:
             # ONE launch behind the NMS loop does runs, boxes, areas and strings (zh_mask_rle_fused_kept: one workgroup per kept mask);
             # ONE buffer = one copy for everything the host needs: [kept triples + categories + count + status (f64) | info | cursor | strings]
             n1, n2 = B * (4 * Q + 2) * 8, B * Q * 8 * 4
