@@ -15,7 +15,8 @@
  *     pointer and lo = f16(x - hi) `lo_plane` ELEMENTS further on (22 significand bits).  Producers take a `lo_plane`
  *     argument (0 = write the plain fp16 tensor only; the hi plane alone IS that tensor); zh_gemm_f16x3 and the split-pair
  *     form of zh_attention_f16 consume them.
- *   - Re-entrant; no global mutable state.
+ *   - Re-entrant.  Process-wide state: none on the product path; the developer entry zh_dev_set_gemm_overrides() (forced GEMM tile /
+ *     super-tile height, used by tests and tools only) is process-wide by design, and zh_last_error() text is thread-local.
  */
 #ifndef ZUTIS_HIP_H
 #define ZUTIS_HIP_H

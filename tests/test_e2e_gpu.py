@@ -417,7 +417,7 @@ def test_forward_graphed_shape_a_b_a_and_fork(dev):
     assert torch.equal(ga2["patch_tokens"], ref_a["patch_tokens"]) and torch.equal(ga2["mask_proposals"], ref_a["mask_proposals"])
     assert all(bool((c == float(i)).all()) for i, c in enumerate(canaries))
     f = eng.fork()
-    assert not any(isinstance(k, tuple) and k and k[0] == "graph" for k in f._geo)
+    assert len(f._graphs) == 0 and len(eng._graphs) == 2
     assert torch.equal(f.forward(xa)["patch_tokens"], ref_a["patch_tokens"])
     # a parameter update invalidates the captured graph (it holds the old packed weights)
     with torch.no_grad():

@@ -5,7 +5,10 @@ contract as the reference (networks/zutis.py:15-549), so main.py / trainer.py / 
 utils.utils.get_network run unchanged.  The *insides* are different: torch modules are used only as parameter
 containers; forward()/predict() execute hand-written HIP kernels from libzutis_hip.so through
 zutis_amd.engine.ZutisEngine.  There is no torch-op or CPU fallback: without the HIP library or a GPU the calls
-raise.  Training (autograd) is out of scope and refused explicitly.
+raise.  Training (autograd) is out of scope for the HIP path: under autograd forward() DELEGATES to the reference's own
+networks/zutis.py when a maintainer has made it importable beside this overlay (see `reference_zutis_class`), sharing this
+module's Parameters so that trainer.py's optimizer, checkpoints and the later HIP evaluation all see one set of weights; when it
+is not importable the call raises NotImplementedError.  Inference (no_grad / frozen parameters) never takes that route.
 
 Differences a maintainer should know:
   * `clip` is optional.  If it is importable the constructor does what the reference does (clip.load, encode_text,
@@ -13,6 +16,9 @@ Differences a maintainer should know:
     `clip_state_dict=`); the architecture comes from the clip_arch name.
   * pycocotools / torchvision are optional (zutis_amd.rle restates encode / masks_to_boxes).
 """
+import importlib
+import os
+import sys
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -39,6 +45,30 @@ _VIT_ARCHS = {
     "ViT-L/14": (1024, 24, 14, 16, 768),
     "ViT-L/14@336px": (1024, 24, 14, 24, 768),
 }
+
+
+# Where the reference's own ZUTIS class is looked up for the TRAINING branch of main.py (trainer.py:136 back-propagates through
+# forward): this overlay shadows `networks.zutis`, so the original has to be importable under another name.  One line in the launch
+# script does it, BEFORE the overlay's directory is put on sys.path ("Training"):
+#     import networks.zutis as m; sys.modules["zutis_reference_networks_zutis"] = m
+# or set ZUTIS_REFERENCE_MODULE to the dotted name of a module that holds the reference's ZUTIS class.
+REFERENCE_MODULE_NAMES = ("zutis_reference_networks_zutis", "zutis_reference.networks.zutis")
+
+
+def reference_zutis_class():
+    """The reference's ZUTIS class if a maintainer made it importable (see REFERENCE_MODULE_NAMES), else None."""
+    names = tuple(n for n in (os.environ.get("ZUTIS_REFERENCE_MODULE"),) if n) + REFERENCE_MODULE_NAMES
+    for name in names:
+        mod = sys.modules.get(name)
+        if mod is None:
+            try:
+                mod = importlib.import_module(name)
+            except ImportError:
+                continue
+        cls = getattr(mod, "ZUTIS", None)
+        if cls is not None and cls is not globals().get("ZUTIS"):
+            return cls
+    return None
 
 
 def convert_weight_like_reference(key: str, value: torch.Tensor) -> torch.Tensor:
@@ -145,6 +175,11 @@ class ZUTIS(nn.Module):
     ):
         super(ZUTIS, self).__init__()
         assert segmentation_type in ["semantic", "instance"], f"Invalid segmentation type: {segmentation_type}."
+        # the reference constructor's own arguments (zutis.py:16-29), kept for the training delegate (_training_delegate)
+        self._ctor_args = dict(categories=categories, segmentation_type=segmentation_type, clip_arch=clip_arch, n_queries=n_queries,
+                               n_decoder_layers=n_decoder_layers, n_heads=n_heads, device=device, encoder_type=encoder_type,
+                               frozen_bn=frozen_bn, stop_gradient=stop_gradient, decoder_image_n_dims=decoder_image_n_dims)
+        object.__setattr__(self, "_delegate", None)      # not a registered submodule: its parameters ARE this module's
         if encoder_type is None:
             encoder_type = "clip"
         if encoder_type != "clip":
@@ -228,6 +263,34 @@ class ZUTIS(nn.Module):
         self._engine = None                      # parameters may have moved: rebuild the plan lazily
         return out
 
+    def _training_delegate(self):
+        """The reference's own ZUTIS (stock torch ops, autograd) over THIS module's Parameter objects — built once, only when a
+        caller back-propagates through forward() and the reference class is importable (reference_zutis_class).  Same 275 keys,
+        so every parameter slot of the delegate is re-pointed at ours: the optimizer main.py built over self.parameters() trains
+        the weights the HIP engine later evaluates (its pack is keyed on the parameters' versions)."""
+        d = self._delegate
+        if d is None:
+            cls = reference_zutis_class()
+            if cls is None:
+                return None
+            d = cls(**self._ctor_args)
+            mine = dict(self.named_parameters())
+            theirs = dict(d.named_parameters())
+            if set(mine) != set(theirs):
+                raise RuntimeError("training delegate: the reference module's parameter names differ from this overlay's "
+                                   f"({sorted(set(mine) ^ set(theirs))[:4]} ...)")
+            for name, p in mine.items():
+                mod, _, leaf = name.rpartition(".")
+                owner = d.get_submodule(mod) if mod else d
+                if leaf in owner._parameters:
+                    owner._parameters[leaf] = p
+                else:                                     # a bare Parameter attribute (query_embed = nn.Embedding(...).weight, zutis.py:131-134)
+                    setattr(owner, leaf, p)
+            d.text_embeddings = self.text_embeddings
+            object.__setattr__(self, "_delegate", d)
+        d.train(self.training)
+        return d
+
     def update_text_embeddings(self, categories):
         if _clip is None:
             raise ImportError("update_text_embeddings needs the `clip` package (reference zutis.py:333-338)")
@@ -245,13 +308,21 @@ class ZUTIS(nn.Module):
         """x: b x 3 x h x w  ->  {"mask_proposals": b x L x Q x 2h' x 2w' (sigmoid), "patch_tokens": b x 2h' x 2w' x dim}"""
         eng = self._get_engine()
 
-        def refuse_training():
+        def wants_grad():
             # the engine's flat parameter table, not self.parameters(): the module walk is ~0.2 ms of Python per call, and in a batch-1
             # evaluation loop the GPU idles through whatever the host does between one image's predict and the next image's launch
-            if torch.is_grad_enabled() and any(p.requires_grad for p in eng.params.values()):
-                raise NotImplementedError(
-                    "ZUTIS on MI355X is inference-only (the training loop is out of scope): wrap the call in "
-                    "torch.no_grad() or call .requires_grad_(False) as trainer.evaluate / coco20k_eval.py do")
+            return torch.is_grad_enabled() and any(p.requires_grad for p in eng.params.values())
+
+        def train_or_refuse():
+            # trainer.py:136 back-propagates through forward: the reference's own module over this module's Parameters when it is importable
+            d = self._training_delegate()
+            if d is not None:
+                return d(x)
+            raise NotImplementedError(
+                "ZUTIS on MI355X is inference-only (the training loop is out of scope) and the reference's networks/zutis.py is not "
+                "importable as a training delegate (zutis_amd.dropin.networks.zutis.REFERENCE_MODULE_NAMES / ZUTIS_REFERENCE_MODULE, "
+                "INTEGRATION.md): wrap the call in torch.no_grad() or call .requires_grad_(False) as trainer.evaluate / "
+                "coco20k_eval.py do")
         if self.use_hip_graph and x.shape[0] <= 4:       # host-bound regime: replay a captured hipGraph per input shape
             # ... from the SECOND time a shape is seen: capturing costs three eager forwards, and a native-resolution evaluation set holds
             # shapes that occur once (they run eagerly, as before round 4) next to the few that most images share (480x640, 640x480, ...)
@@ -261,15 +332,19 @@ class ZUTIS(nn.Module):
                 if len(self._shapes_seen) > 4096:
                     self._shapes_seen.clear()
                 self._shapes_seen[key] = seen + 1
-            if seen >= 2:                                # a replay: launch first, check behind the launch (the outputs are dropped by the raise)
+            if seen >= 2 and self._delegate is None:     # a replay: launch first, check behind the launch (a training call drops the outputs;
+                #                                          once a delegate exists — a training run — the check comes first)
                 out = eng.forward_graphed(x.float().contiguous())
-                refuse_training()
+                if wants_grad():
+                    return train_or_refuse()
                 return out
-            refuse_training()
+            if wants_grad():
+                return train_or_refuse()
             if seen >= 1:
                 return eng.forward_graphed(x.float().contiguous())
             return eng.forward(x.float())
-        refuse_training()
+        if wants_grad():
+            return train_or_refuse()
         return eng.forward(x.float())
 
     # ------------------------------------------------------------------ predict

@@ -2,8 +2,10 @@
 
 extract_image_embeddings(p_images, model_name, fp, device, batch_size, n_workers) -> Dict[basename, FloatTensor[E]]
 keeps the reference signature and on-disk pickle format (utils/extract_image_embeddings.py:21-86).  The reference runs
-third-party `clip`'s fp16 `encode_image`; here the ViT tower runs in zutis_amd.engine.ClipImageEncoder (fp16 MFMA
-operands, fp32 accumulate/residual).  Weights come from `clip.load` when the package is present, else from `state_dict=`.
+third-party `clip`'s fp16 `encode_image` (`clip.load` leaves the model in half precision on a GPU, :43,72-76); here the ViT
+tower runs in zutis_amd.engine.ClipImageEncoder.  `precision="exact"` (the default) computes every contraction in the fp32-class
+f16x3 / f16x2 mode (fp16 split pairs, fp32 accumulate / residual / LayerNorm) — MORE precise than the reference's own run;
+`precision="fast"` is the reference's arithmetic class for this path (fp16 MFMA operands in the transformer body, fp32 accumulate).  Weights come from `clip.load` when the package is present, else from `state_dict=`.
 Pre-processing (bicubic resize of the shorter side, centre crop, CLIP mean/std; SimpleDataset :90-116) is PIL + NumPy
 on the host — data loading is outside the hot path.
 """

@@ -18,19 +18,18 @@ from .engine_base import (ALL_SITES, DECODER_SITES, ENCODER_SITES, HEAD_SITES, P
 from .ops import Act
 
 
-_PINNED: Dict[Tuple[int, int], torch.Tensor] = {}
-
-
-def _to_host(t: torch.Tensor) -> np.ndarray:
+def _to_host(t: torch.Tensor, cache: Dict[int, torch.Tensor]) -> np.ndarray:
     """A 1-D uint8 device tensor on the host: one asynchronous copy into a cached PINNED buffer + one stream synchronisation (`.cpu()`
-    goes through pageable memory: an allocation, a staged copy and its own synchronisation).  The array is a view of the cached buffer:
-    valid until the next call with the same size (callers take what they need out of it before they return)."""
-    key = (t.device.index or 0, t.numel())
-    buf = _PINNED.get(key)
+    goes through pageable memory: an allocation, a staged copy and its own synchronisation).  `cache` belongs to ONE engine instance
+    (forks — one per stream / thread — have their own: a shared buffer would be overwritten by a sibling's predict).  The array is a
+    view of the cached buffer: valid until that engine's next call with the same size (callers take what they need out of it before
+    they return); a buffer that falls out of the cache stays alive as long as a view of it does."""
+    n = t.numel()
+    buf = cache.get(n)
     if buf is None:
-        if len(_PINNED) >= 16:
-            _PINNED.clear()
-        buf = _PINNED[key] = torch.empty((t.numel(),), dtype=torch.uint8, pin_memory=True)
+        while len(cache) >= 8:
+            cache.pop(next(iter(cache)))
+        buf = cache[n] = torch.empty((n,), dtype=torch.uint8, pin_memory=True)
     buf.copy_(t, non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
     return buf.numpy()
@@ -82,6 +81,7 @@ class ZutisEngine(_EngineBase):
         self._pack_decoder(w, P, D, self.dec_layers, memory_linear=(P["ffn1.layers.2.weight"], P["ffn1.layers.2.bias"]))
         self._w, self._packed_key = w, key
         self._geo.clear()
+        self._graphs.clear()
 
     def _geometry(self, h: int, w: int):
         """Input-independent tables per token grid: bicubic pos-embed (clip_arch.py:356-374) and sine PE
@@ -188,9 +188,13 @@ class ZutisEngine(_EngineBase):
         """Same result as forward(), replayed from a hipGraph captured once per input shape.  At batch 1-4 the eager path is
         host-bound (~230 launches x ~11 us of Python/ctypes = 2.7 ms per forward regardless of B); COCO-20K evaluation
         (coco20k_eval.py:241-268) runs batch 1.  Outputs are fresh tensors (copied out of the graph's static buffers)."""
-        key = ("graph", tuple(x.shape))
-        g = self._geo.get(key)
+        key = tuple(x.shape)
+        graphs = self._graphs
+        g = graphs.get(key)
         if g is not None and g["weights"] is self._packed_key:
+            graphs.move_to_end(key)                  # LRU: the shapes most images share stay
+            if g["graph"] is None:                   # capture failed for this shape before: eager from then on
+                return self.forward(x)
             # Launch first, check the parameters' versions behind the launch: walking the 275 parameters (_version_key) is 55 - 150 us of
             # Python, and in a batch-1 evaluation loop the GPU idles through everything the host does between one image's predict and the
             # next image's launch.  A parameter that changed since the capture (rare: load_state_dict after the first forward) makes
@@ -202,7 +206,7 @@ class ZutisEngine(_EngineBase):
                 return out
             self.status_word().zero_()               # whatever the stale weights raised
         self._pack()                                 # (drops every graph when the parameters changed)
-        g = self._geo.get(key)
+        g = graphs.get(key)
         if g is not None and g["weights"] is not self._packed_key:
             g = None
         if g is None:
@@ -214,15 +218,26 @@ class ZutisEngine(_EngineBase):
                     self.forward(static_x)
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.forward(static_x)
+            try:
+                # "thread_local": only THIS thread's calls are checked against the capture.  The reference's validation loaders run with
+                # pin_memory=True (configs/*.yaml val_dataloader_kwargs): their pin-memory thread calls hipHostMalloc / records events
+                # while we capture, which the default "global" mode turns into hipErrorStreamCaptureUnsupported in THAT thread (it kills
+                # the loader) or invalidates the capture.
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = self.forward(static_x)
+            except Exception as e:                   # a capture that cannot be made: this shape runs eagerly from now on, loudly once
+                import warnings
+                warnings.warn(f"hipGraph capture failed for input shape {key} ({type(e).__name__}: {e}); this shape runs eagerly")
+                torch.cuda.synchronize()
+                g = {"x": None, "graph": None, "out": None, "weights": self._packed_key, "keep": None}
+                self._graph_put(key, g)
+                return self.forward(x)
             # The graph bakes in raw pointers to this shape's scratch buffers, geometry tables and packed weights.  _buf()
             # drops a name's buffers when another shape arrives and _geo is a bounded cache, so the graph keeps its own
             # references: shape A, then B, then A again replays A into memory that is still A's.
             g = {"x": static_x, "graph": graph, "out": out, "weights": self._packed_key,
-                 "keep": (dict(self._bufs), {k: v for k, v in self._geo.items() if not (isinstance(k, tuple) and k and k[0] == "graph")},
-                          self._w)}
-            self._geo_put(key, g)
+                 "keep": (dict(self._bufs), dict(self._geo), self._w)}
+            self._graph_put(key, g)
         g["x"].copy_(x)
         g["graph"].replay()
         return {k: v.clone() for k, v in g["out"].items()}
@@ -270,16 +285,25 @@ class ZutisEngine(_EngineBase):
         pt16 = self._abuf("pt16", (B * h * w, E), xl, unit_norm=True)
         src = self._pt16_of
         if not (src is not None and src[0]() is patch_tokens and src[1] == patch_tokens._version):
-            ops.cast_f16(patch_tokens.contiguous(), pt16, B * h * w, E)     # tokens not produced by the last forward()
+            # tokens not produced by the last forward(): a caller's own tensor.  The 2^10 storage scale of unit-norm rows would push
+            # |x| >= 64 past the fp16 range (inf -> NaN logits -> a silent argmax), so rows that are not unit-norm-like keep scale 1
+            # (one max-abs read on this rare path; forward()'s own tokens are unit-norm by construction and never come here)
+            if pt16.out_scale != 1.0 and not self._unit_scale_ok(patch_tokens):
+                pt16 = Act(pt16.t)
+            ops.cast_f16(patch_tokens.contiguous(), pt16, B * h * w, E)
             self._pt16_of = None
         t32 = text.detach().to(device=patch_tokens.device, dtype=f32).contiguous()
         t16 = self._abuf("text16", (n, E), xl, unit_norm=True)
         recording = _lib.RECORDER is not None                              # a launch plan always contains the cast
         src = self._text16_of
         same = src is not None and src[0]() is text and src[1] == text._version and src[2] == self._buf_gen
+        # caller-supplied category embeddings: checked ONCE per (tensor, version) — un-normalised text features take scale 1
+        scaled = src[3] if same else (t16.out_scale == 1.0 or self._unit_scale_ok(t32))
+        if not scaled:
+            t16 = Act(t16.t)
         if recording or not same:                                            # eager: the category embeddings rarely change
             ops.cast_f16(t32, t16, n, E)
-            self._text16_of = None if recording else (weakref.ref(text), text._version, self._buf_gen)
+            self._text16_of = None if recording else (weakref.ref(text), text._version, self._buf_gen, scaled)
         lo = torch.empty((B, n, h, w), dtype=f32, device=patch_tokens.device)
         self._gemm("logits", t16, pt16, lo, M=n, N=h * w, K=E, lda=E, ldw=E, ldc=h * w, batch=B, strideA=0, strideW=h * w * E,
                    strideC=n * h * w)
@@ -412,7 +436,7 @@ class ZutisEngine(_EngineBase):
             idx, _, _, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma, threshold,
                                           packed=packed, range_flag=range_flag, zero_word=cursor)
             ops.mask_rle_fused_kept(m, idx, cnt, max_runs, small[n1 + n2 + 8:], cursor, info, bits=bits)
-            host = _to_host(small)                                   # the one synchronisation of the predict
+            host = _to_host(small, self._pinned)                                   # the one synchronisation of the predict
             pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)
             info_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 8)
             chars_h = host[n1 + n2 + 8:]
@@ -458,7 +482,7 @@ class ZutisEngine(_EngineBase):
                                       packed=packed, range_flag=range_flag)
         ops.mask_runs_kept(m, idx, cnt, max_runs, pos_head, nr, ba, packed=True)
         ops.mask_rle_kept(pos_head, nr, cnt, B, Q, max_runs, H * W, chars, slen)
-        host = _to_host(small)                                       # the one synchronisation of the predict
+        host = _to_host(small, self._pinned)                                       # the one synchronisation of the predict
         pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)
         nr_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 2)
         ba_h = host[n1 + n2:n1 + n2 + n3].view(np.int32).reshape(B, Q, 5)

@@ -23,6 +23,8 @@ Reference call sites are cited per step (paths relative to the reference root).
 """
 from __future__ import annotations
 
+import collections
+
 import math
 import os
 import weakref
@@ -94,7 +96,11 @@ class _EngineBase:
         self._packed_key = None
         self._w: Dict[str, torch.Tensor] = {}
         self._geo: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
+        # captured hipGraphs per input shape: a small LRU of their own (each pins a whole activation-buffer set; they used to share the
+        # FIFO of the geometry tables, where a native-resolution set's many shapes evicted the tables and each other)
+        self._graphs: "collections.OrderedDict" = collections.OrderedDict()
         self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._pinned: Dict[int, torch.Tensor] = {}    # pinned staging buffers of the predict's one device -> host copy (per engine instance)
         self._buf_gen = 0             # bumped on every (re)allocation: launch plans check it
         self._buf_const: Dict[str, torch.Tensor] = {}   # buffers with constant regions: name -> the tensor that was initialised
         self._pt16_of = self._text16_of = None   # which tensors the cached f16 copies "pt16" / "text16" were made from
@@ -108,7 +114,9 @@ class _EngineBase:
         e = copy.copy(self)
         e._bufs, e._buf_gen, e._buf_const = {}, 0, {}
         # input-independent tables are shared; captured graphs are not (they replay into the parent's buffers and stream)
-        e._geo = {k: v for k, v in self._geo.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
+        e._geo = dict(self._geo)
+        e._graphs = collections.OrderedDict()
+        e._pinned = {}
         e._pt16_of = e._text16_of = None       # provenance of the f16 copies held in the (new, empty) buffer cache
         e._status = None                       # a status word of its own (it is written on the fork's stream)
         return e
@@ -154,6 +162,13 @@ class _EngineBase:
             self._geo.pop(next(iter(self._geo)))
         self._geo[key] = value
 
+    _GRAPH_CAP = 6    # captured input shapes kept (least recently replayed goes first); an evicted shape is captured again on its next run
+
+    def _graph_put(self, key, value):
+        while len(self._graphs) >= self._GRAPH_CAP:
+            self._graphs.popitem(last=False)
+        self._graphs[key] = value
+
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
         k = (name, tuple(shape), dtype)
         b = self._bufs.get(k)
@@ -173,6 +188,12 @@ class _EngineBase:
         a split pair of them is stored times 2^10 so that its lo half is a normal fp16 number (ops.UNIT_NORM_SCALE; the consumer GEMM
         multiplies the factor out through Act.out_scale)."""
         return Act(self._buf(name, ((2 if split else 1),) + tuple(shape), f16), out_scale=(1.0 / ops.UNIT_NORM_SCALE) if (unit_norm and split) else 1.0)
+
+    @staticmethod
+    def _unit_scale_ok(t: torch.Tensor) -> bool:
+        """True when `t` times ops.UNIT_NORM_SCALE stays inside the fp16 range with margin (|x| < 32; unit-norm rows are <= 1).
+        Synchronises (one max-abs read): callers use it on rare / cached paths only."""
+        return float(t.detach().abs().max()) * ops.UNIT_NORM_SCALE < 32768.0
 
     @staticmethod
     def _h(t):
@@ -390,7 +411,9 @@ class _EngineBase:
         # the extra occupancy gives there).  The split is a property of the ENGINE INSTANCE (throughput: 1, the engine's default
         # and what bench.py runs; the drop-in modules set 8, they serve batch-1 evaluation loops — at the COCO-20K shape, 480x640 = 4800
         # keys, the forward is 4.25 / 3.56 / 3.04 ms for splits 1 / 2 / 8) and never of the batch — image
-        # i's result is bitwise the same alone and inside a batch (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
+        # i's result is bitwise independent of its position in the batch and of the other images, and bitwise equal across batch sizes that
+        # fall on the same side of the shape thresholds of DESIGN 3b (split-K rows, key-split items, skinny rows); across a threshold the
+        # sums are re-associated: ~1e-7 on tokens, ~5e-7 on masks (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
         ksplit = self.cross_ksplit if (Q <= 128 and M >= 1024) else 1
         ktiles = -(-M // (32 if xk else 64))               # key tiles of the kernel (32 keys for split pairs, 64 for fp16)
         while ksplit > 1 and (ksplit - 1) * -(-ktiles // ksplit) >= ktiles:

@@ -64,6 +64,7 @@ class SelfMaskEngine(_EngineBase):
             w[f"ffn.{j}.w"], w[f"ffn.{j}.b"] = hw(P[f"ffn.layers.{j}.weight"], "ffn2"), c32(P[f"ffn.layers.{j}.bias"])
         self._w, self._packed_key = w, key
         self._geo.clear()
+        self._graphs.clear()
 
     def _pos(self, h: int, w: int) -> torch.Tensor:
         """vision_transformer.py:377-401: bicubic `size=` resample of the 28x28 grid (scale = g/h); returned
