@@ -76,7 +76,7 @@ def live_pmc_traffic(extra_args, split: int, timeout_s=240):
         d = tempfile.mkdtemp(prefix="zh_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--inflight", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-second-precision",
-               "--no-live-traffic", "--no-batch1"] + list(extra_args)
+               "--no-live-traffic", "--no-batch1", "--no-configs"] + list(extra_args)
         try:
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=timeout_s, check=True)
@@ -274,7 +274,7 @@ def bench_c5(args):
         parity = {"embedding_max_abs_err": float((got - ref).abs().max()), "tolerance": 1e-3,
                   "against": "fp32 oracle on the same %d images (unit-norm embeddings)" % ns}
     generic = None
-    if rank == 0 and world == 1 and not args.c5_fp32_weights and not args.no_second_precision:
+    if rank == 0 and world == 1 and not args.c5_fp32_weights and not args.no_second_precision and args.precision == "exact":
         # the same tower with generic fp32 VALUES in the GEMM weights (a fine-tuned tower): every weight keeps its lo plane, the
         # three-product kernel runs — reported next to the headline so that both cases are on the line
         del lanes, embs
@@ -292,11 +292,17 @@ def bench_c5(args):
                            "products per accumulator"}
         del enc3, e3
     second = None
-    if rank == 0 and world == 1 and not args.no_second_precision and args.precision == "exact":
-        # the `fast` precision (fp16 MFMA operands in the transformer body, fp32 accumulate / residual stream / LayerNorm / softmax).  The
-        # reference itself runs THIS config in half precision on a GPU (clip.load leaves the model in fp16 unless the device is the CPU;
-        # extract_image_embeddings.py:76 converts the fp16 embeddings back), so `fast` is at least its precision here
-        encf = ClipImageEncoder(P, p, prefix="visual.", precision="fast")
+    if rank == 0 and world == 1 and not args.no_second_precision and args.precision in ("exact", "fast"):
+        # the other precision on the same line.  The reference itself runs THIS config in half precision on a GPU (clip.load leaves the
+        # model in fp16 unless the device is the CPU; extract_image_embeddings.py:76 converts the fp16 embeddings back): `fast` (fp16 MFMA
+        # operands in the transformer body, fp32 accumulate / residual stream / LayerNorm / softmax) is its arithmetic class and the
+        # headline; `exact` (fp32-class split pairs) is MORE precise than the reference here
+        oprec = "fast" if args.precision == "exact" else "exact"
+        try:
+            del lanes, embs
+        except NameError:
+            pass
+        encf = ClipImageEncoder(P, p, prefix="visual.", precision=oprec)
         ef = encf.encode_image(x)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -305,9 +311,10 @@ def bench_c5(args):
             ef = encf.encode_image(x)
         torch.cuda.synchronize()
         dtf = (time.perf_counter() - t1) / nf
-        second = {"mode": "fast", "dtype": PRECISION_DTYPE["fast"], "value": round(B / dtf, 1), "unit": "images/s", "ms_per_step": round(dtf * 1e3, 3),
-                  "steps": nf, "embedding_max_abs_diff_vs_exact": float((ef - emb).abs().max()),
-                  "note": "the reference runs config 5 in fp16 on a GPU (third-party clip.load; extract_image_embeddings.py:76)"}
+        second = {"mode": oprec, "dtype": PRECISION_DTYPE[oprec], "value": round(B / dtf, 1), "unit": "images/s", "ms_per_step": round(dtf * 1e3, 3),
+                  "steps": nf, "embedding_max_abs_diff_vs_headline": float((ef - emb).abs().max()),
+                  "note": "the reference runs config 5 in fp16 on a GPU (third-party clip.load; extract_image_embeddings.py:76): fast is its "
+                          "arithmetic class, exact is fp32-class"}
         del encf, ef
     if world > 1:
         dist.barrier()                    # rank 0 measured the roofline after the timed region: leave together
@@ -480,24 +487,8 @@ def bench_c3(args):
         parity = c3_parity(preds, g, tag)
     if rank == 0 and world == 1:
         # ---- bilateral solver at the pseudo-label size: one image per call and 8 per call (zh_bilateral_solve_batch)
-        Hs, Ws = 512, 683
-        yy, xx = np.mgrid[:Hs, :Ws]
-        solver = {"size": [Hs, Ws], "unit": "ms per image", "bound": "hbm", "peak_TBps": 8.0,
-                  "algorithmic_bytes_note": "N*(3+1+8+16) + V*250*(25 CG + 11 bistochastisation iterations) per image (SURVEY 8d)"}
-        for Bs in (1, 8):
-            rgb = torch.from_numpy(np.stack([detgen.selfmask_like_rgb(Hs, Ws, seed=3 + i) for i in range(Bs)])).to(dev)
-            tg = torch.from_numpy(np.stack([(((yy - 250) ** 2 + (xx - 300 - 3 * i) ** 2) < 150 ** 2).astype(np.uint8) for i in range(Bs)])).to(dev)
-            soft, stats = ops.bilateral_solve(rgb, tg)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(20):
-                ops.bilateral_solve(rgb, tg)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / 20
-            V = float(stats[:, 0].float().mean().item())
-            byts = Hs * Ws * (3 + 1 + 8 + 16) + V * 250 * 36
-            solver[f"batch{Bs}"] = {"ms_per_image": round(dt / Bs * 1e3, 4), "vertices": round(V), "achieved_TBps": round(byts * Bs / dt / 1e12, 3),
-                                    "frac": round(byts * Bs / dt / 8e12, 3), "cg_iterations": [int(v) for v in stats[:, 1].tolist()[:2]]}
+        solver = solver_object(dev)
+        yy, xx = np.mgrid[:512, :683]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import torch.nn.functional as F
         from oracle import zutis_ref as O
@@ -543,6 +534,224 @@ def bench_c3(args):
             "config": {"workload": f"C3: batch 1, {H}x{W}, 81 categories, 100 queries, threshold {thr}, hard NMS; drop-in networks.zutis.ZUTIS "
                                    "(coco20k_eval.py:241-268 evaluates image by image)", "global_batch": world, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "bilateral_solver": solver}), flush=True)
+
+
+def build_lanes(eng, x, text, S, n, n_lanes, world=1, dist_on=False, h2d=False, d2h=False):
+    """The lanes bench.py times: lane i = a fork of `eng` (own activation buffers, shared packed weights), ONE step recorded into
+    a native launch plan (zutis_amd/plan.py) — forward + low-res class logits + fused upsample/argmax to [B, S, S] int64 labels — a HIP
+    stream and (N > 1) a gather buffer.  With one lane the step runs eagerly on the current stream.  tests/test_timed_path_gpu.py
+    builds its lanes through this function, so what the test checks is what the bench times."""
+    from zutis_amd import distributed as zd
+    from zutis_amd import ops
+    from zutis_amd import plan as zplan
+    B, dev = x.shape[0], x.device
+    lanes = []
+    for li in range(n_lanes):
+        e = eng if li == 0 else eng.fork()       # own activation buffers, shared packed weights
+        e.forward(x)                             # eager warm-up: packs weights, sizes the buffer cache
+        plan = None
+        xin = x.clone() if h2d else x            # h2d: the lane's own input buffer, refilled from the host every step
+
+        def one_step(e=e, xin=xin):
+            out = e.forward(xin)
+            lo = e.semantic_logits_lowres(out["patch_tokens"], text)
+            labels = torch.empty((B, S, S), dtype=torch.int64, device=dev)
+            ops.upsample_argmax(lo, labels, B, n, lo.shape[2], lo.shape[3], S, S)
+            return lo, labels
+        if n_lanes > 1:
+            with zplan.Recorder() as rec:
+                lo, labels = one_step()
+            plan = rec.build()
+        else:
+            lo, labels = one_step()
+        hw2 = lo.shape[2] * lo.shape[3]
+        lanes.append(zd.Lane(lo.view(B, n, hw2), gathered=torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) if dist_on else None,
+                             stream=torch.cuda.Stream(device=dev) if n_lanes > 1 else None,
+                             state={"eng": e, "plan": plan, "labels": labels, "step": one_step, "xin": xin, "lo_shape": tuple(lo.shape),
+                                    "host_labels": torch.empty((B, S, S), dtype=torch.int64).pin_memory() if d2h else None}))
+    return lanes
+
+
+def make_launch(n_lanes, host_x=None, h2d=False, d2h=False):
+    """The `launch(group, step_ids)` callback of zutis_amd.distributed.StepPipeline for lanes from build_lanes()."""
+    from zutis_amd import plan as zplan
+
+    def launch(grp, ids):
+        if h2d:              # the step's batch crosses PCIe first, in stream order before the step's kernels
+            for ln in grp:
+                with torch.cuda.stream(ln.stream) if ln.stream is not None else contextlib.nullcontext():
+                    ln.state["xin"].copy_(host_x, non_blocking=True)
+        if n_lanes > 1:      # consecutive steps replayed interleaved, one stream each, from one C loop
+            zplan.run_many([ln.state["plan"] for ln in grp], [ln.stream.cuda_stream for ln in grp])
+        else:                # plain eager loop on the current stream (payload tensor is re-bound: eager steps allocate)
+            for ln in grp:
+                lo, ln.state["labels"] = ln.state["step"]()
+                ln.payload = lo.view(ln.payload.shape)
+        if d2h:              # networks/zutis.py:372 `.cpu().numpy()`: the label maps leave the device, in stream order
+            for ln in grp:
+                with torch.cuda.stream(ln.stream) if ln.stream is not None else contextlib.nullcontext():
+                    ln.state["host_labels"].copy_(ln.state["labels"], non_blocking=True)
+    return launch
+
+
+def check_timed_outputs(lanes):
+    """What the timed region produced, checked AFTER it (round-4 review: the replayed plans' own outputs were never looked at):
+    every lane's label maps and low-res logits — as the last replay of its plan left them — against ONE eager step of that lane's
+    engine on the same input, bitwise.  Returns (ok, lo, labels): lane 0's timed outputs (clones) for the oracle parity leg."""
+    torch.cuda.synchronize()
+    kept = [(ln.payload.clone(), ln.state["labels"].clone()) for ln in lanes]
+    ok = True
+    for ln, (lo_t, lab_t) in zip(lanes, kept):
+        lo_e, lab_e = ln.state["step"]()             # eager launches on the current stream, the lane's own engine and input
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.equal(lo_e.reshape(lo_t.shape), lo_t)) and bool(torch.equal(lab_e, lab_t))
+    lo0, lab0 = kept[0]
+    return ok, lo0.view(lanes[0].state["lo_shape"]), lab0
+
+
+def solver_object(dev, reps=20):
+    """Bilateral-solver refinement (utils/bilateral_solver.py; BASELINE config 3's second half) at the pseudo-label size 512x683, natural-image
+    colour statistics: ms per image at 1 and 8 images per call, HBM roofline on SURVEY 8d's algorithmic bytes."""
+    from zutis_amd import detgen, ops
+    Hs, Ws = 512, 683
+    yy, xx = np.mgrid[:Hs, :Ws]
+    solver = {"size": [Hs, Ws], "unit": "ms per image", "bound": "hbm", "peak_TBps": 8.0,
+              "algorithmic_bytes_note": "N*(3+1+8+16) + V*250*(25 CG + 11 bistochastisation iterations) per image (SURVEY 8d)"}
+    for Bs in (1, 8):
+        rgb = torch.from_numpy(np.stack([detgen.selfmask_like_rgb(Hs, Ws, seed=3 + i) for i in range(Bs)])).to(dev)
+        tg = torch.from_numpy(np.stack([(((yy - 250) ** 2 + (xx - 300 - 3 * i) ** 2) < 150 ** 2).astype(np.uint8) for i in range(Bs)])).to(dev)
+        soft, stats = ops.bilateral_solve(rgb, tg)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ops.bilateral_solve(rgb, tg)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        V = float(stats[:, 0].float().mean().item())
+        byts = Hs * Ws * (3 + 1 + 8 + 16) + V * 250 * 36
+        solver[f"batch{Bs}"] = {"ms_per_image": round(dt / Bs * 1e3, 4), "vertices": round(V), "achieved_TBps": round(byts * Bs / dt / 1e12, 3),
+                                "frac": round(byts * Bs / dt / 8e12, 3), "cg_iterations": [int(v) for v in stats[:, 1].tolist()[:2]]}
+    return solver
+
+
+def c4_object(P, cfg, dev, precision, steps=12, warmup=4, n_lanes=3, cpu_images=1, cpu_threads=16):
+    """BASELINE config 4 on one GPU, bounded: ViT-B/16 @518 px, 920 classes, 8 images per step (the reference's own batch for this
+    config, configs/imagenet_s919_*.yaml), three launch plans in flight exactly as the headline — value, roofline fraction of the
+    dominant GEMM, timed outputs bitwise an eager step, parity of the TIMED outputs against the oracle on `cpu_images` image(s)."""
+    from zutis_amd import detgen, ops
+    from zutis_amd import distributed as zd
+    from zutis_amd.engine import ZutisEngine
+    B, S, n = 8, 518, 920
+    text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
+    x = torch.randn((B, 3, S, S), generator=torch.Generator(device="cpu").manual_seed(4000)).to(dev)
+    eng = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
+    lanes = build_lanes(eng, x, text, S, n, n_lanes)
+    torch.cuda.synchronize()
+    pipe = zd.StepPipeline(lanes, make_launch(n_lanes), gather=False)
+    pipe.run(max(warmup, n_lanes))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok, lo_t, lab_t = check_timed_outputs(lanes)
+
+    def one_eager_step():
+        out = eng.forward(x)
+        eng.predict_semantic(out["patch_tokens"], text, (S, S))
+    roof = gemm_roofline(ops, one_eager_step, dt / steps)
+    obj = {"what": f"C4: ViT-B/16 @{S}px, {n} classes, {B} images per step, {n_lanes} launch plans in flight (`bench.py --workload c4` is the full line)",
+           "value": round(B * steps / dt, 1), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "precision": precision,
+           "dtype": PRECISION_DTYPE[precision], "timed_outputs_bitwise_equal_eager": bool(ok),
+           "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step", "gemm_share_of_step")}}
+    for an in ("attention_f16x3_tflops", "attention_f16x3_share_of_step", "attention_f16_tflops", "attention_f16_share_of_step"):
+        if an in roof:
+            obj["roofline"][an] = roof[an]
+    if cpu_images:
+        from oracle import zutis_ref as O
+        from oracle.parity import unexplained_label_mismatches
+        from oracle import resample as R
+        torch.set_num_threads(max(1, min(cpu_threads, os.cpu_count() or 1)))
+        Pc = O.to_torch_params(detgen.zutis_state_dict(cfg))
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            o = O.zutis_forward(Pc, x[:cpu_images].cpu(), cfg.patch, cfg.dec_heads)
+            lo_ref = O.semantic_logits_lowres(o["patch_tokens"], text.cpu()).numpy()
+            lab_ref = R.bilinear_argmax_nchw(lo_ref, S, S)
+            dtc = time.perf_counter() - t1
+        lo = lo_t[:cpu_images].cpu().numpy()
+        lab = lab_t[:cpu_images].cpu().numpy()
+        err = float(np.abs(lo - lo_ref).max())
+        n_mis, n_bad, worst = unexplained_label_mismatches(lab, lab_ref, lo_ref, err, (S, S))
+        obj["parity"] = {"logit_max_abs_err": err, "label_mismatches": n_mis, "unexplained_label_mismatches": n_bad, "tolerance": 1e-3,
+                         "against": f"fp32 oracle on the first {cpu_images} image(s) of the timed batch, outputs of the timed plans (lane 0)"}
+        obj["cpu_baseline"] = {"value": round(cpu_images / dtc, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{cpu_images} image(s), one pass (oracle forward + 920-class semantic predict)"}
+    for ln in lanes:
+        ln.state["eng"]._bufs.clear()
+    return obj
+
+
+def c5_object(dev, precision="fast", steps=3, cpu_images=1, cpu_threads=16):
+    """BASELINE config 5 on one GPU, bounded: CLIP ViT-L/14@336 `encode_image`, ONE 256-image batch per step, at the reference's own
+    arithmetic class for this config (fp16 on a GPU: utils/extract_image_embeddings.py:43,72-76 -> `fast`).  Weights are random values of
+    the architecture drawn on the device (fp16-valued conv / Linear / attention / proj tensors as convert_weights leaves them); the full
+    line with the deterministic host-generated weights is `bench.py --workload c5`."""
+    from zutis_amd import ops
+    from zutis_amd.engine import ClipImageEncoder
+    D, L, p, g, E, B = 1024, 24, 14, 24, 768, 256
+    gen = torch.Generator(device=dev).manual_seed(5005)
+
+    def w(shape, std, mean=0.0, f16v=True):
+        t = torch.randn(shape, generator=gen, device=dev, dtype=torch.float32) * std + mean
+        return t.half().float() if f16v else t
+    P = {"visual.class_embedding": w((D,), D ** -0.5, f16v=False), "visual.positional_embedding": w((g * g + 1, D), D ** -0.5, f16v=False),
+         "visual.proj": w((D, E), D ** -0.5), "visual.conv1.weight": w((D, 3, p, p), (3 * p * p) ** -0.5)}
+    for ln in ("ln_pre", "ln_post"):
+        P[f"visual.{ln}.weight"], P[f"visual.{ln}.bias"] = w((D,), 0.1, 1.0, False), w((D,), 0.1, 0.0, False)
+    for i in range(L):
+        q = f"visual.transformer.resblocks.{i}."
+        P[q + "attn.in_proj_weight"], P[q + "attn.in_proj_bias"] = w((3 * D, D), D ** -0.5), w((3 * D,), 0.02)
+        P[q + "attn.out_proj.weight"], P[q + "attn.out_proj.bias"] = w((D, D), D ** -0.5 * (2 * L) ** -0.5), w((D,), 0.02)
+        P[q + "mlp.c_fc.weight"], P[q + "mlp.c_fc.bias"] = w((4 * D, D), (2 * D) ** -0.5), w((4 * D,), 0.02)
+        P[q + "mlp.c_proj.weight"], P[q + "mlp.c_proj.bias"] = w((D, 4 * D), D ** -0.5 * (2 * L) ** -0.5), w((D,), 0.02)
+        for ln in ("ln_1", "ln_2"):
+            P[q + ln + ".weight"], P[q + ln + ".bias"] = w((D,), 0.1, 1.0, False), w((D,), 0.1, 0.0, False)
+    enc = ClipImageEncoder(P, p, prefix="visual.", precision=precision)
+    x = torch.randn((B, 3, 336, 336), generator=gen, device=dev, dtype=torch.float32)
+    emb = enc.encode_image(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        emb = enc.encode_image(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    roof = gemm_roofline(ops, lambda: enc.encode_image(x), dt)
+    T = g * g + 1
+    flop = L * (2 * T * (D * 3 * D + D * D + 2 * D * 4 * D) + 4 * T * T * D) + 2 * g * g * 3 * p * p * D + 2 * D * E
+    obj = {"what": f"C5: CLIP ViT-L/14@336 encode_image, one {B}-image batch per step, one stream (`bench.py --workload c5` is the full line)",
+           "value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps, "precision": precision,
+           "dtype": PRECISION_DTYPE[precision], "model_tflops": round(B * flop / dt / 1e12, 1),
+           "precision_note": "the reference runs this config in fp16 on a GPU (clip.load; extract_image_embeddings.py:43,72-76): `fast` is its arithmetic class",
+           "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step", "gemm_share_of_step")}}
+    for an in ("attention_f16x3_tflops", "attention_f16_tflops"):
+        if an in roof:
+            obj["roofline"][an] = roof[an]
+    if cpu_images:
+        from oracle import zutis_ref as O
+        torch.set_num_threads(max(1, min(cpu_threads, os.cpu_count() or 1)))
+        Pc = {k.replace("visual.", "encoder."): v.cpu() for k, v in P.items()}
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            ref = O.clip_encode_image(Pc, x[:cpu_images].cpu(), p)
+            dtc = time.perf_counter() - t1
+        got = emb[:cpu_images].cpu()             # rows of the TIMED step's output (the last of the timed encode_image calls)
+        obj["parity"] = {"embedding_max_abs_err": float((got - ref).abs().max()), "tolerance": 1e-3,
+                         "against": f"fp32 oracle on the first {cpu_images} image(s) of the timed batch (unit-norm embeddings); the compared rows are the timed step's output"}
+        obj["cpu_baseline"] = {"value": round(cpu_images / dtc, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{cpu_images} image(s), one pass (oracle encode_image, 24-layer ViT-L/14@336)"}
+    enc._bufs.clear()
+    return obj
 
 
 def rank_launch_command(n_gpus: int, argv, port: int):
@@ -594,7 +803,7 @@ def main():
                     "reference's build_model -> convert_weights leaves there (forces the three-product kernel)")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
-    ap.add_argument("--precision", default="exact", choices=["fast", "exact", "f16"],
+    ap.add_argument("--precision", default=None, choices=["fast", "exact", "f16"],
                     help="engine precision (zutis_amd/engine.py): exact (default, the headline) = every contraction in the f16x3 mode, the "
                          "reference's fp32 arithmetic class; fast = fp16 MFMA operands in the transformer bodies + x3 on the output-facing "
                          "contractions (passes tests/test_precision_gpu.py at the north-star 1e-3; reported as second_precision)")
@@ -606,6 +815,7 @@ def main():
                     "step's stream (the reference's predict ends in .cpu().numpy(), networks/zutis.py:372)")
     ap.add_argument("--no-io-rates", action="store_true", help="skip the short extra runs that report the PCIe-inclusive rates (N = 1)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the bounded batch-1 object (one 480x640 image per call through the drop-in module)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the bounded objects for BASELINE configs 4 / 5 and the bilateral solver (N = 1, default workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the extra CPU-baseline pass with one thread per physical core")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
@@ -618,6 +828,10 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="print the rank launcher's command line (JSON) for --gpus N and exit; no GPU is touched")
     args = ap.parse_args()
     args.inflight_given = any(a == "--inflight" or a.startswith("--inflight=") for a in sys.argv[1:])
+    if args.precision is None:
+        # the reference's own arithmetic class per config: fp32 for the ZUTIS network (zutis.py:55 casts the encoder back to fp32) -> exact;
+        # config 5 runs third-party clip's HALF-precision tower on a GPU (utils/extract_image_embeddings.py:43,72-76) -> fast (fp16 MFMA operands)
+        args.precision = "fast" if args.workload == "c5" else "exact"
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
         return launch_ranks(args.gpus, sys.argv[1:], args.dry_launch)
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and not args.force_dist:
@@ -664,7 +878,7 @@ def main():
 
     engines = {}
 
-    def timed_run(precision: str, steps: int, warmup: int, h2d: bool = False, d2h: bool = False):
+    def timed_run(precision: str, steps: int, warmup: int, h2d: bool = False, d2h: bool = False, check: bool = False):
         """Builds the engine for `precision`, one lane (engine fork + launch plan + stream + gather buffer) per step in
         flight, and times `steps` steps through zutis_amd.distributed.StepPipeline.  Returns (engine, seconds).
         h2d: every step first copies its batch from pinned host memory; d2h: every step ends with its label maps copied to
@@ -672,47 +886,10 @@ def main():
         eng = engines.get(precision)
         if eng is None:
             eng = engines[precision] = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
-        lanes = []
         host_x = x.cpu().pin_memory() if h2d else None
-        for li in range(n_lanes):
-            e = eng if li == 0 else eng.fork()       # own activation buffers, shared packed weights
-            e.forward(x)                             # eager warm-up: packs weights, sizes the buffer cache
-            plan = None
-            xin = x.clone() if h2d else x            # h2d: the lane's own input buffer, refilled from the host every step
-
-            def one_step(e=e, xin=xin):
-                out = e.forward(xin)
-                lo = e.semantic_logits_lowres(out["patch_tokens"], text)
-                labels = torch.empty((B, S, S), dtype=torch.int64, device=dev)
-                ops.upsample_argmax(lo, labels, B, n, lo.shape[2], lo.shape[3], S, S)
-                return lo, labels
-            if n_lanes > 1:
-                with zplan.Recorder() as rec:
-                    lo, labels = one_step()
-                plan = rec.build()
-            else:
-                lo, labels = one_step()
-            lanes.append(zd.Lane(lo.view(B, n, hw2), gathered=torch.empty((world * B, n, hw2), dtype=torch.float32, device=dev) if dist_on else None,
-                                 stream=torch.cuda.Stream(device=dev) if n_lanes > 1 else None,
-                                 state={"eng": e, "plan": plan, "labels": labels, "step": one_step, "xin": xin,
-                                        "host_labels": torch.empty((B, S, S), dtype=torch.int64).pin_memory() if d2h else None}))
+        lanes = build_lanes(eng, x, text, S, n, n_lanes, world=world, dist_on=dist_on, h2d=h2d, d2h=d2h)
         torch.cuda.synchronize()
-
-        def launch(grp, ids):
-            if h2d:              # the step's batch crosses PCIe first, in stream order before the step's kernels
-                for ln in grp:
-                    with torch.cuda.stream(ln.stream) if ln.stream is not None else contextlib.nullcontext():
-                        ln.state["xin"].copy_(host_x, non_blocking=True)
-            if n_lanes > 1:      # consecutive steps replayed interleaved, one stream each, from one C loop
-                zplan.run_many([ln.state["plan"] for ln in grp], [ln.stream.cuda_stream for ln in grp])
-            else:                # plain eager loop on the current stream (payload tensor is re-bound: eager steps allocate)
-                for ln in grp:
-                    lo, ln.state["labels"] = ln.state["step"]()
-                    ln.payload = lo.view(B, n, hw2)
-            if d2h:              # networks/zutis.py:372 `.cpu().numpy()`: the label maps leave the device, in stream order
-                for ln in grp:
-                    with torch.cuda.stream(ln.stream) if ln.stream is not None else contextlib.nullcontext():
-                        ln.state["host_labels"].copy_(ln.state["labels"], non_blocking=True)
+        launch = make_launch(n_lanes, host_x, h2d, d2h)
         pipe = zd.StepPipeline(lanes, launch, gather=dist_on)
         pipe.run(max(warmup, n_lanes))
         pipe.drain()
@@ -730,23 +907,25 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return eng, dt
+        # the outputs of the plans that were just timed (outside the timed region): bitwise an eager step, lane by lane
+        checked = check_timed_outputs(lanes) if check else None
+        return eng, dt, checked
 
-    eng, elapsed = timed_run(args.precision, args.steps, args.warmup, h2d=args.h2d, d2h=args.d2h)
+    eng, elapsed, timed_out = timed_run(args.precision, args.steps, args.warmup, h2d=args.h2d, d2h=args.d2h, check=True)
     # second line (N = 1 only, bounded): the same workload at the other precision (default: "fast", narrower than the reference
     # in the transformer bodies — reported, not the headline)
     other = None
     if world == 1 and not args.no_second_precision:
         oprec = "exact" if args.precision != "exact" else "fast"
         osteps = args.steps
-        oeng, odt = timed_run(oprec, osteps, max(1, args.warmup // 2), h2d=args.h2d, d2h=args.d2h)
-        other = {"precision": oprec, "eng": oeng, "value": round(B * osteps / odt, 2), "ms_per_step": round(odt / osteps * 1e3, 3), "steps": osteps}
+        oeng, odt, otimed = timed_run(oprec, osteps, max(1, args.warmup // 2), h2d=args.h2d, d2h=args.d2h, check=True)
+        other = {"precision": oprec, "eng": oeng, "timed": otimed, "value": round(B * osteps / odt, 2), "ms_per_step": round(odt / osteps * 1e3, 3), "steps": osteps}
     # PCIe-inclusive rates of the headline precision (N = 1, same number of steps): labels out, and batch in + labels out
     io_rates = None
     if world == 1 and not args.no_io_rates and not (args.h2d or args.d2h):
         io_rates = {}
         for key, kw in (("d2h", dict(d2h=True)), ("h2d_d2h", dict(h2d=True, d2h=True))):
-            _, idt = timed_run(args.precision, args.steps, max(1, args.warmup // 2), **kw)
+            _, idt, _ = timed_run(args.precision, args.steps, max(1, args.warmup // 2), **kw)
             io_rates[key] = {"value": round(B * args.steps / idt, 2), "ms_per_step": round(idt / args.steps * 1e3, 3)}
         io_rates["what"] = ("same run with, per step, d2h: the int64 label maps [%d,%d,%d] (%.1f MB) copied to pinned host memory on the step's "
                             "stream (networks/zutis.py:372 ends in .cpu().numpy()); h2d_d2h: additionally the fp32 batch (%.1f MB) copied in "
@@ -765,7 +944,7 @@ def main():
             roof["traffic"], roof["traffic_source"] = live_pmc_traffic(extra, 1 if "SPLIT=1" in roof["kernel"] else (2 if "SPLIT=2" in roof["kernel"] else 0))
         if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 2)
-        roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r04_bench_%s_kernel_stats.csv"
+        roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r05_bench_%s_kernel_stats.csv"
                                 % args.precision)
 
     # ---- CPU baseline: the oracle (CPU port of the reference path) on a bounded sample, rank 0 at N=1 only
@@ -810,10 +989,12 @@ def main():
                                          "sample": f"{n2} images, one pass after a 1-image warm-up"}
             torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
 
-        def parity_of(e):
-            out = e.forward(x[:ns])
-            lo = e.semantic_logits_lowres(out["patch_tokens"], text).cpu().numpy()
-            lab = e.predict_semantic(out["patch_tokens"], text, (S, S)).cpu().numpy()
+        def parity_of(timed):
+            # the oracle against what the TIMED launch plans left behind (lane 0's last replay: the first `ns` images of the very batch
+            # the timed steps ran), not a separate eager forward at another batch size
+            ok, lo_t, lab_t = timed
+            lo = lo_t[:ns].cpu().numpy()
+            lab = lab_t[:ns].cpu().numpy()
             hist = O.confusion_hist(lab_ref, lab, n)
             from oracle.parity import unexplained_label_mismatches
             err = float(np.abs(lo - lo_ref).max())
@@ -823,10 +1004,12 @@ def main():
                     "label_note": "a differing pixel is explained when the oracle's own full-resolution logits separate the two labels by "
                                   "<= 2 x logit_max_abs_err (largest such margin: %.2e); the argmax kernel is bit-exact on equal logits" % worst,
                     "miou_vs_oracle_labels": float(O.scores_from_hist(hist)[0]["Mean IoU"]), "tolerance": 1e-3,
-                    "against": "fp32 oracle (CPU restatement of the reference path) on the same %d images" % ns}
-        parity = parity_of(eng)
+                    "timed_outputs_bitwise_equal_eager": bool(ok),
+                    "against": "fp32 oracle (CPU restatement of the reference path) on the first %d images of the timed batch; the compared "
+                               "logits / labels are the outputs of the timed launch plans themselves (lane 0, last replay)" % ns}
+        parity = parity_of(timed_out)
         if other is not None:
-            other["parity"] = parity_of(other["eng"])
+            other["parity"] = parity_of(other["timed"])
 
     torch_gpu = None
     if rank == 0 and world == 1 and args.torch_gpu_baseline and not args.no_torch_gpu_baseline:
@@ -874,6 +1057,20 @@ def main():
         for e in engines.values():                    # the headline's engines are done: free their buffers first
             e._bufs.clear()
         batch1 = batch1_object(args.precision, dev)
+    # ---- the other BASELINE configs, bounded, in the driver-run line (N = 1, default workload only): c4 (518 px / 920 classes / 8 per step),
+    # c5 (ViT-L/14@336 embedding extraction, one 256-image step, at the reference's fp16 arithmetic class) and the bilateral solver
+    c4o = c5o = solvero = None
+    if rank == 0 and world == 1 and not args.no_configs and args.workload == "c2" and (S, n) == (336, 81):
+        for e in engines.values():
+            e._bufs.clear()
+        engines.clear()
+        torch.cuda.empty_cache()
+        ncpu = 0 if args.no_cpu_baseline else 1
+        c4o = c4_object(P, cfg, dev, args.precision, cpu_images=ncpu, cpu_threads=args.cpu_threads)
+        torch.cuda.empty_cache()
+        c5o = c5_object(dev, "fast", cpu_images=ncpu, cpu_threads=args.cpu_threads)
+        torch.cuda.empty_cache()
+        solvero = solver_object(dev)
     if rank == 0:
         total_images = world * B * args.steps
         line = {
@@ -895,8 +1092,13 @@ def main():
             "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1) if (S, n) == (336, 81) else None,
             "model_tflops_note": "images/s x the REFERENCE model's 124.5 GFLOP per image (SURVEY 8d; MFU convention) per GPU — not executed flops: "
                                  "the engine executes fewer (roofline.executed_algorithmic_flops_per_step, DESIGN 2a)",
+            "timed_outputs_checked": bool(timed_out is not None and timed_out[0]),
+            "timed_outputs_note": "after the timed region every lane's label maps and low-res logits (as the last replay of its launch plan "
+                                  "left them) were compared bitwise with one eager step of the lane's engine on the same batch; `parity` "
+                                  "compares lane 0's timed outputs with the oracle",
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             **({"batch1": batch1} if batch1 else {}),
+            **({"c4": c4o} if c4o else {}), **({"c5": c5o} if c5o else {}), **({"bilateral_solver": solvero} if solvero else {}),
             **({"torch_gpu_baseline": torch_gpu} if torch_gpu else {}),
             **({"io_inclusive": io_rates} if io_rates else {}),
         }
@@ -908,6 +1110,35 @@ def main():
             line["vs_torch_gpu_fp32_eager"] = round(line["value"] / torch_gpu["value"], 2)
             if other is not None:
                 line["second_precision"]["vs_torch_gpu_fp32_eager"] = round(other["value"] / torch_gpu["value"], 2)
+        # LAST key, compact (the driver keeps the last ~2000 characters of stdout): the numbers of every object above, no prose
+        sm = {"c2_" + args.precision: line["value"], "frac": roof["frac"] if roof else None, "checked": line["timed_outputs_checked"]}
+        if parity:
+            sm["c2_err"] = float("%.2g" % parity["logit_max_abs_err"]); sm["c2_bad_labels"] = parity["unexplained_label_mismatches"]
+        if other is not None:
+            sm["c2_" + other["precision"]] = other["value"]
+            if other.get("parity"):
+                sm["c2_" + other["precision"] + "_err"] = float("%.2g" % other["parity"]["logit_max_abs_err"])
+                sm["c2_" + other["precision"] + "_checked"] = other["parity"]["timed_outputs_bitwise_equal_eager"]
+        if torch_gpu:
+            sm["torch_eager"] = torch_gpu["value"]
+            sm["x_torch"] = [line["vs_torch_gpu_fp32_eager"]] + ([line["second_precision"]["vs_torch_gpu_fp32_eager"]] if other is not None else [])
+        if cpu:
+            sm["cpu"] = cpu["value"]
+        if batch1:
+            sm["b1_ms"] = [batch1["ms_per_image"], batch1["forward_ms"], batch1["instance_predict_ms"]]
+            sm["b1_calls"] = batch1["library_calls_forward"]
+        if c4o:
+            sm["c4"] = {"v": c4o["value"], "frac": c4o["roofline"]["frac"], "ok": c4o["timed_outputs_bitwise_equal_eager"],
+                        **({"err": float("%.2g" % c4o["parity"]["logit_max_abs_err"]), "bad": c4o["parity"]["unexplained_label_mismatches"]} if "parity" in c4o else {})}
+        if c5o:
+            sm["c5_" + c5o["precision"]] = {"v": c5o["value"], "frac": c5o["roofline"]["frac"], "tf": c5o["model_tflops"],
+                                            **({"err": float("%.2g" % c5o["parity"]["embedding_max_abs_err"])} if "parity" in c5o else {})}
+        if solvero:
+            sm["solver_ms"] = [solvero["batch1"]["ms_per_image"], solvero["batch8"]["ms_per_image"]]
+            sm["solver_frac"] = [solvero["batch1"]["frac"], solvero["batch8"]["frac"]]
+        if io_rates:
+            sm["io"] = [io_rates["d2h"]["value"], io_rates["h2d_d2h"]["value"]]
+        line["summary"] = sm
     if dist_on:
         dist.barrier()                    # rank 0 measured the roofline / baselines after the timed region: leave together
         dist.destroy_process_group()      # first: RCCL prints its version banner on stdout when the communicator goes away

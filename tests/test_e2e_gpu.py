@@ -57,12 +57,15 @@ def test_engine_vs_reference_golden(dev, golden_dir, tag, cfgname, precision):
           f"top-2 margin <= 2 err; largest {worst:.2e})")
 
 
-def test_engine_vs_oracle_ragged_batch(dev):
-    """Non-square, non-multiple-of-patch input, batch 3, against the CPU oracle on the same seeded inputs."""
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_engine_vs_oracle_ragged_batch(dev, precision):
+    """Non-square, non-multiple-of-patch input, batch 3, against the CPU oracle on the same seeded inputs — at the product default
+    (`exact`, fp32-reordering-class tolerances) and at `fast`."""
     from zutis_amd import detgen
     from oracle import zutis_ref as O
     cfg = detgen.TINY
-    eng = _engine(cfg, dev)
+    eng = _engine(cfg, dev, precision)
+    LOGIT_TOL, MASK_TOL = TOLS[precision]
     P = O.to_torch_params(detgen.zutis_state_dict(cfg))
     x = torch.from_numpy(detgen.images(3, 75, 123))
     text = torch.from_numpy(detgen.text_embeddings(5, cfg.embed_dim))
@@ -426,6 +429,39 @@ def test_forward_graphed_shape_a_b_a_and_fork(dev):
     assert not torch.equal(upd["patch_tokens"], ref_a["patch_tokens"])
     assert torch.equal(upd["patch_tokens"], eng.forward(xa)["patch_tokens"].clone())
     assert torch.equal(eng.forward_graphed(xa)["patch_tokens"], upd["patch_tokens"])
+
+
+def test_dropin_behind_a_pinned_dataloader_across_the_first_capture(dev):
+    """The reference's validation loaders run with pin_memory=True (configs/*.yaml val_dataloader_kwargs, index_dataset.py:189): their
+    pin-memory thread allocates pinned host memory and records events WHILE the drop-in captures its hipGraph on the second occurrence of
+    a shape.  The capture is thread-local, so neither the loader thread nor the capture breaks; every output equals the eager one bit for
+    bit; and the graphs live in their own small LRU (not in the geometry cache)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from zutis_amd import detgen
+    cfg = detgen.TINY
+    net = _dropin_zutis(cfg, dev, 5).requires_grad_(False)
+    imgs = torch.cat([torch.from_numpy(detgen.images(1, 80, 112, seed=s)) for s in range(10)])
+    net.use_hip_graph = False
+    want = [net(imgs[i:i + 1].to(dev))["patch_tokens"].clone() for i in range(10)]
+    net.use_hip_graph = True
+    loader = DataLoader(TensorDataset(imgs), batch_size=1, num_workers=2, pin_memory=True)
+    got = []
+    for (xb,) in loader:                                  # image 0 eager, image 1 captures (loader threads busy), 2.. replay
+        assert xb.is_pinned()
+        got.append(net(xb.to(dev, non_blocking=True))["patch_tokens"].clone())
+    assert len(got) == 10 and all(torch.equal(a, b) for a, b in zip(got, want))
+    eng = net._get_engine()
+    assert len(eng._graphs) == 1 and next(iter(eng._graphs.values()))["graph"] is not None
+    # LRU of its own: more shapes than the cap keep only the newest, and the geometry tables are not evicted by graphs
+    for k, (H, W) in enumerate([(64, 96), (96, 64), (64, 64), (80, 96), (96, 80), (64, 112), (112, 64)]):
+        xk = torch.from_numpy(detgen.images(1, H, W, seed=k)).to(dev)
+        for _ in range(3):
+            o = net(xk)
+        net.use_hip_graph = False
+        assert torch.equal(o["patch_tokens"], net(xk)["patch_tokens"])
+        net.use_hip_graph = True
+    assert len(eng._graphs) == eng._GRAPH_CAP and not any(isinstance(k, tuple) and k and k[0] == "graph" for k in eng._geo)
+    assert torch.equal(net(imgs[3:4].to(dev))["patch_tokens"], want[3])       # an evicted shape: eager / re-captured, same bits
 
 
 @pytest.mark.parametrize("precision,t_mask,t_tok", [("exact", 2e-5, 2e-6), ("fast", 2e-3, 2e-4)])

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries and bench lines under profiles/ (run on the GPU box from the repo root, e.g.
-#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r04'
+#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r05'
 # then copy gpurun_out/<round>_* into profiles/).  One rocprofv3 --kernel-trace --stats pass per configuration; the PMC traffic
 # passes are the ones bench.py spawns itself (roofline.traffic of the default line).  The headline precision is `exact` (bench.py's
 # default); `fast` is profiled as the second precision.
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 mkdir -p gpurun_out
-Q="--no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision --no-io-rates --no-batch1 --steps 10 --warmup 3"
+Q="--no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision --no-io-rates --no-batch1 --no-configs --steps 10 --warmup 3"
 prof() {
   name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_$name -- python3 bench.py "$@" > gpurun_out/p_$name.log 2>&1
@@ -35,7 +35,7 @@ python3 bench.py 2> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench.
 python3 bench.py --workload c4 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c4.json
 python3 bench.py --workload c5 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c5.json
 python3 bench.py --workload c3 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c3.json
-python3 bench.py --inflight 1 --no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision --no-io-rates --no-batch1 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_inflight1.json
+python3 bench.py --inflight 1 --no-cpu-baseline --no-torch-gpu-baseline --no-live-traffic --no-second-precision --no-io-rates --no-batch1 --no-configs 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_inflight1.json
 head -c 600 gpurun_out/${R}_bench.json; echo
 for f in gpurun_out/${R}_bench_c3.json gpurun_out/${R}_bench_c4.json gpurun_out/${R}_bench_c5.json gpurun_out/${R}_bench_inflight1.json; do python3 -c "
 import json,sys; d=json.load(open('$f')); print('$f', d['value'], d['unit'], d['ms_per_step'], d.get('roofline',{}) and d['roofline'].get('achieved'))"; done
