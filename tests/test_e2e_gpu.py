@@ -121,7 +121,7 @@ def test_dropin_replays_a_graph_from_the_second_occurrence_of_a_shape(dev):
     net = _dropin_zutis(cfg, dev, 7)
     xa = torch.from_numpy(detgen.images(1, 64, 96, seed=1)).to(dev)
     xb = torch.from_numpy(detgen.images(1, 64, 96, seed=2)).to(dev)
-    graphs = lambda: [k for k in net._get_engine()._geo if isinstance(k, tuple) and k and k[0] == "graph"]
+    graphs = lambda: [k for k, v in net._get_engine()._graphs.items() if v["graph"] is not None]
     with torch.no_grad():
         o1 = {k: v.clone() for k, v in net(xa).items()}
         assert graphs() == []

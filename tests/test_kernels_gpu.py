@@ -145,6 +145,33 @@ def test_gemm_every_tile_variant_every_ring_phase(dev, tile):
         L.zh_dev_set_gemm_overrides(0, 0, 0)
 
 
+def test_gemm_tail_peel_is_bitwise_one_launch(dev):
+    """zh_gemm_f16's tail peel (round 5; the f16x3 dispatcher has had it since round 3): 257 m-tiles x 4 n-tiles of 256 x 256 = 4 rounds
+    of the chip + 4 tiles run as the whole rounds + a second call on the last m-tile row — bitwise the single forced-tile launch, for
+    the fp32 + residual and the fp16 + activation epilogues, ragged last tile included."""
+    from zutis_amd import ops, _lib
+    L = _lib.load(raw=True)
+    M, N, K = 257 * 256 - 37, 1024, 128
+    A, W = _randn((M, K), 1, 0.5).to(f16).to(dev), _randn((N, K), 2, 0.05).to(f16).to(dev)
+    bias, res = _randn((N,), 3).to(dev), _randn((M, N), 4).to(dev)
+
+    def run():
+        o = torch.empty((M, N), dtype=f32, device=dev)
+        ops.gemm(A, W, o, bias=bias, residual=res)
+        h = torch.empty((M, N), dtype=f16, device=dev)
+        ops.gemm(A, W, h, bias=bias, act=ops.ACT_QUICKGELU)
+        return o, h
+    o_p, h_p = run()                                    # cost model: 256 x 256 tiles, 1028 of them -> peeled
+    try:
+        _lib.check(L.zh_dev_set_gemm_overrides(0, 256, 0), "zh_dev_set_gemm_overrides")
+        o_1, h_1 = run()                                # forced tile: one launch, no peel
+    finally:
+        L.zh_dev_set_gemm_overrides(0, 0, 0)
+    assert torch.equal(o_p, o_1) and torch.equal(h_p, h_1)
+    ref = A.double() @ W.double().t() + bias.double() + res.double()
+    assert float((o_p.double() - ref).abs().max()) < 1e-3
+
+
 def test_gemm_forced_tile_is_really_forced(dev):
     """The override reaches the launcher: an unknown tile code is an argument error (it would be ignored if the setter did
     nothing), and clearing it restores the cost model."""

@@ -27,11 +27,18 @@ struct BgDims { int Nx, Ny, Nl, Nu, Nv; long cells; };
 
 __device__ __forceinline__ double blur_gather(const double* __restrict__ x, const int* __restrict__ nb, double xv) {
   double out = 10.0 * xv;                                     // 2 * dim * x   (bilateral_solver.py:97)
+  // selects, not branches: the ten gathers are requested together (absent neighbours read x[0] and are deselected) — same values, same
+  // order of additions; these kernels are ~1 us of dependent latency each
+  int j[10];
+  double g[10];
+#pragma unroll
+  for (int e = 0; e < 10; ++e) j[e] = nb[e];
+#pragma unroll
+  for (int e = 0; e < 10; ++e) g[e] = x[j[e] >= 0 ? j[e] : 0];
 #pragma unroll
   for (int d = 0; d < 5; ++d) {
-    const int lo = nb[2 * d], hi = nb[2 * d + 1];
-    double t = lo >= 0 ? x[lo] : 0.0;
-    if (hi >= 0) t = t + x[hi];
+    double t = j[2 * d] >= 0 ? g[2 * d] : 0.0;
+    t = j[2 * d + 1] >= 0 ? t + g[2 * d + 1] : t;
     out = out + t;
   }
   return out;
@@ -316,27 +323,56 @@ __global__ __launch_bounds__(256) void bg_bisto_step(const double* n_in, const d
     n_out[v] = sqrt(nvv * m0[v] / blur_gather(n_in, nbr + v * 10, nvv));
   }
 }
-__global__ __launch_bounds__(256) void bg_bisto_final(const double* n, const int* nbr, const int* nv, double* m, BgBatch bt) {
-  n = ws_img(n, bt); nbr = ws_img(nbr, bt); nv = ws_img(nv, bt); m = ws_img(m, bt);
+// the first step, from n = 1 (bilateral_solver.py:110): 1 * m0 / blur(ones) — the same operations on the constant, without the fill
+// launch that used to write the ones (blur(ones) = 10 + the number of neighbours that exist: small integers, exact in any order)
+__global__ __launch_bounds__(256) void bg_bisto_first(const double* m0, const int* nbr, const int* nv, double* n_out, BgBatch bt) {
+  m0 = ws_img(m0, bt); nbr = ws_img(nbr, bt); nv = ws_img(nv, bt); n_out = ws_img(n_out, bt);
   FOR_VERTEX_BLOCKS(vb, nv) {
     const int v = vb * 256 + threadIdx.x;
-    if (v < *nv) m[v] = n[v] * blur_gather(n, nbr + v * 10, n[v]);
+    if (v >= *nv) continue;
+    const int* nb = nbr + v * 10;
+    double out = 10.0 * 1.0;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      double t = nb[2 * d] >= 0 ? 1.0 : 0.0;
+      if (nb[2 * d + 1] >= 0) t = t + 1.0;
+      out = out + t;
+    }
+    n_out[v] = sqrt(1.0 * m0[v] / out);
   }
 }
-
-// ---- PCG (scipy.sparse.linalg.cg semantics, Jacobi preconditioner; bilateral_solver.py:133-147)
+// ---- PCG (scipy.sparse.linalg.cg semantics, Jacobi preconditioner; bilateral_solver.py:133-147), single-reduction form
+//
+// Round 5.  A solve at 512 x 683 is ~20 k vertices: every launch is ~1 us of work behind ~5 us of launch latency, so the solve costs
+// what its LAUNCH COUNT costs.  The textbook loop SciPy runs (z = M^-1 r; rho = r.z; p = z + beta p; q = A p; alpha = rho / p.q;
+// x += alpha p; r -= alpha q) has two grid-wide reductions per iteration, i.e. two launches (rounds 3 - 4: 2 + 2 x 25 launches).
+// The Chronopoulos - Gear rearrangement has ONE: with w = A z, gamma = r.z and delta = w.z taken in the same sweep,
+//     beta = gamma / gamma_prev,  alpha = gamma / (delta - beta gamma / alpha_prev),
+//     p = z + beta p,  s = w + beta s  (= A p),  x += alpha p,  r -= alpha s
+// — the same iterates in exact arithmetic (p.q = delta - beta gamma / alpha_prev), different rounding (measured against the reference's
+// goldens: tests/test_bilateral_gpu.py holds 1e-9 on the soft output, equality on the > 0.5 mask and on the iteration counts).
+// ONE launch per iteration: kernel K(it) first reduces the partials K(it - 1) left (gamma, delta, ||r||^2 — every block re-derives the
+// scalars from the same partials in the same order: deterministic, no flag race), tests convergence as SciPy does at the top of
+// iteration `it`, then for its vertex AND, on the fly, for the vertex's (up to) ten neighbours forms s, r, z of the NEW iterate (the
+// same uncontracted expressions: every copy of a value is the same double), applies A to the new z, and leaves the next partials.
+// State {r, w, s, p} per vertex is one 32-byte record, ping-ponged between two buffers by iteration parity (a thread reads its
+// neighbours' old records while others write new ones); {1 / diag, n} is a 16-byte record.  K(-1) starts the chain (w = A z of the
+// initial residual; no update), K(maxiter - 1) only finishes x: maxiter + 1 launches, 26 for the reference's 25 iterations.
+struct __attribute__((aligned(32))) CgDyn { double r, w, s, p; };
+struct __attribute__((aligned(16))) CgCst { double minv, n; };
 struct CgPtrs {
   const double *n, *m, *wsplat, *b; const int* nbr; const int* nv;
-  double *minv, *x, *r, *z, *p, *p2, *q;   // p / p2: search direction, ping-pong by iteration parity (see cg_phase_pq)
-  double *part_rz, *part_rr, *part_pq;   // per-block partial sums; three arrays => no cross-block WAR
-  double* sc;                            // scalars: [0],[1] rho ping-pong, [2] atol, [3] converged flag, [4] iterations
+  double* mw;                            // m again, writable: the init kernel computes it
+  CgCst* cst; CgDyn *dyn0, *dyn1; double* x;
+  double* part;                          // per-block partial sums: 2 sets (iteration parity) x {gamma, delta, rr}; set 0 first holds b.b
+  int nblocks;
+  double* sc;                            // scalars: [0],[1] gamma ping-pong, [2] atol, [3] converged flag, [4] iterations, [5],[6] alpha ping-pong
   double lam, a_diag_min, rtol;
 };
 __device__ __forceinline__ CgPtrs cg_img(CgPtrs c, const BgBatch& bt) {
   c.n = ws_img(c.n, bt); c.m = ws_img(c.m, bt); c.wsplat = ws_img(c.wsplat, bt); c.b = ws_img(c.b, bt); c.nbr = ws_img(c.nbr, bt);
-  c.nv = ws_img(c.nv, bt); c.minv = ws_img(c.minv, bt); c.x = ws_img(c.x, bt); c.r = ws_img(c.r, bt); c.z = ws_img(c.z, bt);
-  c.p = ws_img(c.p, bt); c.p2 = ws_img(c.p2, bt); c.q = ws_img(c.q, bt); c.part_rz = ws_img(c.part_rz, bt); c.part_rr = ws_img(c.part_rr, bt);
-  c.part_pq = ws_img(c.part_pq, bt); c.sc = ws_img(c.sc, bt);
+  c.nv = ws_img(c.nv, bt); c.mw = ws_img(c.mw, bt); c.cst = ws_img(c.cst, bt); c.dyn0 = ws_img(c.dyn0, bt); c.dyn1 = ws_img(c.dyn1, bt); c.x = ws_img(c.x, bt);
+  c.part = ws_img(c.part, bt); c.sc = ws_img(c.sc, bt);
   return c;
 }
 // blocks that hold vertices: the launch grid is sized for the worst case (one vertex per pixel); everything past this exits
@@ -350,31 +386,38 @@ __device__ __forceinline__ double block_sum(double s, double* red) {   // determ
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
+// three sums at once: one LDS exchange and two barriers instead of three of each (a step kernel is ~1 us of work: every barrier shows)
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[w] = a; red[4 + w] = b; red[8 + w] = c; }
+  __syncthreads();
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  b = (red[4] + red[5]) + (red[6] + red[7]);
+  c = (red[8] + red[9]) + (red[10] + red[11]);
+}
 __device__ __forceinline__ double sum_partials(const double* part, int nb, double* red) {
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
   return block_sum(s, red);
 }
 
-__global__ __launch_bounds__(256) void bg_fill_kernel(double* x, double val, const int* nv, BgBatch bt) {
-  x = ws_img(x, bt); nv = ws_img(nv, bt);
-  FOR_VERTEX_BLOCKS(vb, nv) {
-    const int v = vb * 256 + threadIdx.x;
-    if (v < *nv) x[v] = val;
-  }
-}
+// x0 = splat(xw) / splat(w) (the flat initialisation, bilateral_solver.py:141 — formed for the vertex and, on the fly, for its
+// neighbours: the same division, the same double), r0 = b - A x0, the Jacobi preconditioner, per-block partials of b.b (for atol)
 __global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c0, BgBatch bt) {
   __shared__ double red[4];
   const CgPtrs c = cg_img(c0, bt);
   FOR_VERTEX_BLOCKS(vb, c.nv) {
     const int v = vb * 256 + threadIdx.x;
-    double rz = 0.0, rr = 0.0, bb = 0.0;
+    double bb = 0.0;
     if (v < *c.nv) {
-      const double diag = c.lam * (c.m[v] - c.n[v] * 10.0 * c.n[v]) + c.wsplat[v];
+      // m = n .* blur(n) (bilateral_solver.py:114; only the vertex's own m is needed below: it was a launch of its own)
+      const double mv = c.n[v] * blur_gather(c.n, c.nbr + v * 10, c.n[v]);
+      c.mw[v] = mv;
+      const double diag = c.lam * (mv - c.n[v] * 10.0 * c.n[v]) + c.wsplat[v];
       const double mi = 1.0 / fmax(diag, c.a_diag_min);
-      c.minv[v] = mi;
-      // the flat initialisation y0 = splat(xw) / splat(w) (bilateral_solver.py:141) formed here — for the vertex and, on the fly, for
-      // its neighbours (the same division: the same double) — instead of by a launch of its own in front of this one
+      c.cst[v] = CgCst{mi, c.n[v]};
       auto xval = [&](int j) { return c.b[j] / c.wsplat[j]; };
       const double xv = xval(v);
       c.x[v] = xv;
@@ -388,135 +431,144 @@ __global__ __launch_bounds__(256) void cg_init_kernel(CgPtrs c0, BgBatch bt) {
         if (hi >= 0) t = t + c.n[hi] * xval(hi);
         bl = bl + t;
       }
-      const double r = c.b[v] - (c.lam * (c.m[v] * xv - c.n[v] * bl) + c.wsplat[v] * xv);
-      c.r[v] = r;
-      const double z = mi * r;
-      c.z[v] = z;
-      rz = r * z; rr = r * r; bb = c.b[v] * c.b[v];
+      const double r = c.b[v] - (c.lam * (mv * xv - c.n[v] * bl) + c.wsplat[v] * xv);
+      c.dyn0[v] = CgDyn{r, 0.0, 0.0, 0.0};
+      bb = c.b[v] * c.b[v];
     }
-    const double s1 = block_sum(rz, red), s2 = block_sum(rr, red), s3 = block_sum(bb, red);
-    if (threadIdx.x == 0) { c.part_rz[vb] = s1; c.part_rr[vb] = s2; c.part_pq[vb] = s3; }
+    const double s3 = block_sum(bb, red);
+    if (threadIdx.x == 0) c.part[vb] = s3;
   }
 }
-__global__ __launch_bounds__(256) void cg_atol_kernel(CgPtrs c0, BgBatch bt) {        // one block per image: atol = rtol * ||b||
-  __shared__ double red[4];
+// K(it), it = -1 .. maxiter - 1 (see the header of this section)
+// Everything a vertex's update reads, requested BEFORE the kernel's scalars are known (none of it depends on alpha / beta): a step is a
+// chain of dependent memory round trips (partials -> scalars | indices -> records -> sums), and with the vertex's operands in flight
+// under the reduction of the partials the chain is two trips shorter (7.8 -> see profiles/NOTES.md round 5, us per launch at 20 k vertices).
+struct CgVtxIn { bool ok; CgCst cv; CgDyn dv; double mv, wv, xv; int nbi[10]; CgCst cj[10]; double rj[10], wj[10], sj[10]; };
+__global__ __launch_bounds__(256) void cg_step_kernel(CgPtrs c0, int it, int last, BgBatch bt) {
+  __shared__ double red[12];
   const CgPtrs c = cg_img(c0, bt);
-  const double bb = sum_partials(c.part_pq, cg_active_blocks(c), red);
-  if (threadIdx.x == 0) { c.sc[2] = c.rtol * sqrt(bb); c.sc[3] = 0.0; c.sc[4] = 0.0; }
-}
-// One PCG iteration = TWO launches (it was three: p update, matvec, x / r / z update — a solve at 512 x 683 is ~100 launches of
-// ~1 us of work each, i.e. launch-latency bound, and 75 of them were these).  The p update needs a grid-wide barrier before the
-// matvec only because the matvec reads its neighbours' p: here every thread forms p_new = z + beta p_old for its vertex AND for its
-// (up to) ten neighbours on the fly — the same expression, evaluated without contraction, so every copy of a value is the same
-// double — and p ping-pongs between two buffers by iteration parity so that no thread reads a p another one has already replaced.
-// Results are bitwise those of the three-launch form (goldens: iteration counts exact, batched == single bitwise).
-// phases 1 + 2: convergence test at the top of iteration `it` (every block re-derives it from the same partials: deterministic, no
-// flag race), p_new, q = A p_new, per-block partials of p.q.  Returns false when converged (||r|| < atol).
-__device__ __forceinline__ bool cg_phase_pq(const CgPtrs& c, int it, int nb, double rho_prev, double& rho, double* red, int g, int G) {
-  rho = sum_partials(c.part_rz, nb, red);
-  const double rr = sum_partials(c.part_rr, nb, red);
-  if (sqrt(rr) < c.sc[2]) {
-    if (g == 0 && threadIdx.x == 0 && c.sc[3] == 0.0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
-    return false;
-  }
-  const double beta = it == 0 ? 0.0 : rho / rho_prev;
-  const bool first = it == 0;
-  const double* __restrict__ po = (it & 1) ? c.p : c.p2;      // p of iteration it - 1 (never read when it == 0)
-  double* __restrict__ pn = (it & 1) ? c.p2 : c.p;
-  const double* __restrict__ z = c.z;
-  const double* __restrict__ n = c.n;
-  auto pval = [&](int j) { return first ? z[j] : z[j] + beta * po[j]; };
-  FOR_VERTEX_BLOCKS_G(vb, c.nv, g, G) {
-    const int v = vb * 256 + threadIdx.x;
-    double pq = 0.0;
-    if (v < *c.nv) {
-      // q = A p = lam * (m*p - n * blur(n .* p)) + wsplat*p   (p formed on the fly)
-      const double pv = pval(v);
-      const int* nb10 = c.nbr + v * 10;
-      const double ny = n[v] * pv;
-      double bl = 10.0 * ny;
+  const int nv = *c.nv, nb = (nv + 255) >> 8;
+  if ((int)blockIdx.x >= nb) return;
+  const bool plain = it <= 0;                                               // no previous direction: s = w, p = z
+  const CgDyn* __restrict__ dold = ((it + 1) & 1) ? c.dyn1 : c.dyn0;
+  CgDyn* __restrict__ dnew = ((it + 1) & 1) ? c.dyn0 : c.dyn1;
+  const CgCst* __restrict__ cst = c.cst;
+  auto load_vtx = [&](int v, CgVtxIn& in) {
+    in.ok = v < nv;
+    const int vv = in.ok ? v : 0;                                           // surplus threads of the last block read vertex 0 and store nothing
+    in.cv = cst[vv]; in.dv = dold[vv]; in.mv = c.m[vv]; in.wv = c.wsplat[vv]; in.xv = c.x[vv];
+    const int* nb10 = c.nbr + (size_t)vv * 10;
 #pragma unroll
-      for (int d = 0; d < 5; ++d) {
-        const int lo = nb10[2 * d], hi = nb10[2 * d + 1];
-        double t = lo >= 0 ? n[lo] * pval(lo) : 0.0;
-        if (hi >= 0) t = t + n[hi] * pval(hi);
-        bl = bl + t;
+    for (int e = 0; e < 10; ++e) in.nbi[e] = nb10[e];
+    if (!last) {
+#pragma unroll
+      for (int e = 0; e < 10; ++e) {                                        // selects, not branches: absent neighbours read the vertex's own
+        const int j = in.nbi[e] >= 0 ? in.nbi[e] : vv;                      // record and are deselected in the sum — 30 loads in flight together
+        in.cj[e] = cst[j];
+        const CgDyn dj = dold[j];
+        in.rj[e] = dj.r; in.wj[e] = dj.w; in.sj[e] = dj.s;
       }
-      const double q = c.lam * (c.m[v] * pv - n[v] * bl) + c.wsplat[v] * pv;
-      pn[v] = pv;
-      c.q[v] = q;
-      pq = pv * q;
     }
-    const double s = block_sum(pq, red);
-    if (threadIdx.x == 0) c.part_pq[vb] = s;
+  };
+  int vb = blockIdx.x;
+  CgVtxIn in;
+  load_vtx(vb * 256 + threadIdx.x, in);
+  // ---- the iteration's scalars from the partials K(it - 1) left (it = -1: the init kernel's b.b)
+  double alpha = 0.0, beta = 0.0;
+  const double* pin = c.part + (size_t)((it + 1) & 1) * 3 * c.nblocks;
+  double* pout = c.part + (size_t)(it & 1) * 3 * c.nblocks;
+  const double flag = c.sc[3], atol = c.sc[2];                               // both written by EARLIER kernels only
+  const double gp = c.sc[it >= 1 ? ((it - 1) & 1) : 0], ap = c.sc[it >= 1 ? 5 + ((it - 1) & 1) : 5];
+  if (it < 0) {
+    const double bb = sum_partials(pin, nb, red);                           // atol = rtol * ||b||
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[2] = c.rtol * sqrt(bb);
+  } else {
+    if (flag != 0.0) return;                                                // converged earlier
+    double gamma = 0.0, delta = 0.0, rr = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) { gamma += pin[i]; delta += pin[c.nblocks + i]; rr += pin[2 * c.nblocks + i]; }
+    block_sum3(gamma, delta, rr, red);
+    if (sqrt(rr) < atol) {                                                  // SciPy's test at the top of iteration `it`
+      if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
+      return;
+    }
+    if (it == 0) { beta = 0.0; alpha = gamma / delta; }
+    else {
+      beta = gamma / gp;
+      alpha = gamma / (delta - beta * gamma / ap);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc[it & 1] = gamma; c.sc[5 + (it & 1)] = alpha; }
   }
-  return true;
-}
-// phase 3: x += alpha p, r -= alpha q, z = M^-1 r, per-block partials of r.z and r.r
-__device__ __forceinline__ void cg_phase_x(const CgPtrs& c, const double* p, int nb, double rho, double* red, int g, int G) {
-  const double pq = sum_partials(c.part_pq, nb, red);
-  const double alpha = rho / pq;
-  FOR_VERTEX_BLOCKS_G(vb, c.nv, g, G) {
+  for (;;) {
     const int v = vb * 256 + threadIdx.x;
-    double rz = 0.0, rr = 0.0;
-    if (v < *c.nv) {
-      c.x[v] += alpha * p[v];
-      const double r = c.r[v] - alpha * c.q[v];
-      c.r[v] = r;
-      const double z = c.minv[v] * r;
-      c.z[v] = z;
-      rz = r * z; rr = r * r;
+    double g = 0.0, d = 0.0, rr = 0.0;
+    if (in.ok) {
+      const double z = in.cv.minv * in.dv.r;
+      const double sn = plain ? in.dv.w : in.dv.w + beta * in.dv.s;
+      const double pn = plain ? z : z + beta * in.dv.p;
+      const double rn = in.dv.r - alpha * sn;
+      const double zn = in.cv.minv * rn;
+      if (it >= 0) c.x[v] = in.xv + alpha * pn;
+      if (!last) {
+        // w = A z_new = lam * (m z - n * blur(n .* z)) + wsplat z; a neighbour's n z_new from its OLD record, by the expressions of
+        // the vertex's own update above, term for term (every copy of a value is the same double)
+        const double ny = in.cv.n * zn;
+        double bl = 10.0 * ny;
+        double nzv[10];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) {
+          const double sj = plain ? in.wj[e] : in.wj[e] + beta * in.sj[e];
+          const double rj = in.rj[e] - alpha * sj;
+          nzv[e] = in.cj[e].n * (in.cj[e].minv * rj);
+        }
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {                                       // same values, same order of additions as blur_gather
+          double t = in.nbi[2 * e] >= 0 ? nzv[2 * e] : 0.0;
+          t = in.nbi[2 * e + 1] >= 0 ? t + nzv[2 * e + 1] : t;
+          bl = bl + t;
+        }
+        const double wn = c.lam * (in.mv * zn - in.cv.n * bl) + in.wv * zn;
+        dnew[v] = CgDyn{rn, wn, sn, pn};
+        g = rn * zn; d = wn * zn; rr = rn * rn;
+      }
     }
-    const double s1 = block_sum(rz, red), s2 = block_sum(rr, red);
-    if (threadIdx.x == 0) { c.part_rz[vb] = s1; c.part_rr[vb] = s2; }
+    if (!last) {
+      block_sum3(g, d, rr, red);
+      if (threadIdx.x == 0) { pout[vb] = g; pout[c.nblocks + vb] = d; pout[2 * c.nblocks + vb] = rr; }
+    }
+    vb += gridDim.x;                                                        // more than VGRID blocks of vertices: noise images only
+    if (vb >= nb) break;
+    load_vtx(vb * 256 + threadIdx.x, in);
   }
 }
 
-__global__ __launch_bounds__(256) void cg_pq_kernel(CgPtrs c0, int it, BgBatch bt) {
-  __shared__ double red[4];
-  const CgPtrs c = cg_img(c0, bt);
-  const int nb = cg_active_blocks(c);
-  if ((int)blockIdx.x >= nb) return;
-  double rho;
-  if (!cg_phase_pq(c, it, nb, it == 0 ? 1.0 : c.sc[(it - 1) & 1], rho, red, blockIdx.x, gridDim.x)) return;   // once converged the partials are
-  if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[it & 1] = rho;                           // frozen: the decision repeats for all later iterations
-}
-__global__ __launch_bounds__(256) void cg_update_kernel(CgPtrs c0, int it, BgBatch bt) {
-  __shared__ double red[4];
-  const CgPtrs c = cg_img(c0, bt);
-  const int nb = cg_active_blocks(c);
-  if ((int)blockIdx.x >= nb) return;
-  if (c.sc[3] != 0.0) return;                                             // written by an EARLIER kernel only
-  cg_phase_x(c, (it & 1) ? c.p2 : c.p, nb, c.sc[it & 1], red, blockIdx.x, gridDim.x);
-}
-
-// (Round 3 measured two persistent single-launch forms of this loop — all iterations in one kernel with image-local barriers
+// (Round 3 measured two persistent single-launch forms of the two-reduction loop — all iterations in one kernel with image-local barriers
 // between the phases — and kept neither; both are in the git history.  With portable agent-scope release / acquire fences, as
 // cooperative-groups grid sync does, a barrier costs ~26 us on this 8-XCD part (L2 write-back + invalidate): 2.15 ms per
 // 512x683 solve against 0.49 ms for the 75 separate launches.  With one image per XCD (blocks b, b+8, ... share an XCD; placement
 // verified through HW_REG_XCC_ID) and barriers that stay inside that XCD's L2 (s_waitcnt vmcnt(0) + an L2-executed atomic + poll +
 // buffer_inv sc0) a barrier still costs ~5 us with 32 blocks polling one line — the price of a launch: 0.538 vs 0.477 ms at batch 1,
 // 0.711 vs 0.740 ms at batch 8.  A phase is ~1 us of work on 20 k vertices; the solve is bound by the synchronisation latency
-// itself, whichever mechanism provides it.  DESIGN.md section 3, "Bilateral solver".)
+// itself, whichever mechanism provides it — so round 5 removed synchronisation POINTS instead: the single-reduction loop above.)
 
-__global__ void cg_finish_kernel(CgPtrs c0, int maxiter, int* stats, const double* n_src, const double* m_src, double* n_out, double* m_out,
-                                 BgBatch bt) {
-  const CgPtrs c = cg_img(c0, bt);
-  if (threadIdx.x == 0) {
-    if (c.sc[3] == 0.0) c.sc[4] = (double)maxiter;
-    if (stats) { stats[2 * blockIdx.y] = *c.nv; stats[2 * blockIdx.y + 1] = (int)c.sc[4]; }
-  }
-  if (n_out || m_out) {                                                       // debug copies of the bistochastisation vectors
-    n_src = ws_img(n_src, bt); m_src = ws_img(m_src, bt);
-    for (int v = threadIdx.x; v < *c.nv; v += blockDim.x) {
-      if (n_out) n_out[(size_t)blockIdx.y * bt.dbg + v] = n_src[v];
-      if (m_out) m_out[(size_t)blockIdx.y * bt.dbg + v] = m_src[v];
-    }
+// debug copies of the bistochastisation vectors (tests only: launched when n_out / m_out are given)
+__global__ void cg_debug_copy_kernel(const int* nv, const double* n_src, const double* m_src, double* n_out, double* m_out, BgBatch bt) {
+  nv = ws_img(nv, bt); n_src = ws_img(n_src, bt); m_src = ws_img(m_src, bt);
+  for (int v = threadIdx.x; v < *nv; v += blockDim.x) {
+    if (n_out) n_out[(size_t)blockIdx.y * bt.dbg + v] = n_src[v];
+    if (m_out) m_out[(size_t)blockIdx.y * bt.dbg + v] = m_src[v];
   }
 }
 
-__global__ __launch_bounds__(256) void bg_slice_kernel(const double* y, const int* pix2v, long N, double* out, BgBatch bt) {   // S^T y
+// S^T y (bilateral_solver.py:148) + the solve's statistics {vertices, iterations} (one thread of the image's first block: it was a
+// launch of its own)
+__global__ __launch_bounds__(256) void bg_slice_kernel(const double* y, const int* pix2v, long N, double* out, const int* nv, const double* sc,
+                                                       int maxiter, int* stats, BgBatch bt) {
   y = ws_img(y, bt); pix2v = ws_img(pix2v, bt);
+  if (stats && blockIdx.x == 0 && threadIdx.x == 0) {
+    nv = ws_img(nv, bt); sc = ws_img(sc, bt);
+    stats[2 * blockIdx.y] = *nv;
+    stats[2 * blockIdx.y + 1] = sc[3] == 0.0 ? maxiter : (int)sc[4];
+  }
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p < N) out[(size_t)blockIdx.y * bt.N + p] = y[pix2v[p]];
 }
@@ -551,8 +603,8 @@ static BgLayout bg_layout(int H, int W, const BgDims& d) {
   L.vcell = o; o += al((size_t)L.Vmax * 4);
   L.nbr = o; o += al((size_t)L.Vmax * 40);
   L.ints = o; o += al((size_t)L.Vmax * 4) * 2 + 256;  // cnt_i, tsum_i, nonbinary flag
-  L.dbl = o; o += al((size_t)L.Vmax * 8) * 13;      // cnt, wsplat, bsplat, nA, nB, m, minv, x, r, z, p, q, spare
-  L.part = o; o += al((size_t)L.nblocks * 8 * 3);
+  L.dbl = o; o += al((size_t)L.Vmax * 8) * 17;      // cnt, wsplat, bsplat, nA, nB, m, {minv, n} records (2), {r, w, s, p} records x 2 (8), x
+  L.part = o; o += al((size_t)L.nblocks * 8 * 6);   // two sets (iteration parity) of {gamma, delta, rr} per 256-vertex block
   L.sc = o; o += 256;
   L.nv = o; o += 256;
   L.total = al(o);
@@ -618,8 +670,8 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
   unsigned* tsum_i = (unsigned*)(ws + L.ints + istride);
   unsigned* nonbin = (unsigned*)(ws + L.ints + 2 * istride);
   const size_t dstride = al((size_t)L.Vmax * 8);
-  double* D[13];
-  for (int i = 0; i < 13; ++i) D[i] = (double*)(ws + L.dbl + dstride * i);
+  double* D[17];
+  for (int i = 0; i < 17; ++i) D[i] = (double*)(ws + L.dbl + dstride * i);
   double *cnt = D[0], *wsplat = D[1], *bsplat = D[2], *nA = D[3], *nB = D[4], *m = D[5];
   double* part = (double*)(ws + L.part);
   double* sc = (double*)(ws + L.sc);
@@ -640,27 +692,24 @@ extern "C" int zh_bilateral_solve_batch(const unsigned char* rgb, const unsigned
   hipLaunchKernelGGL(bg_splat_final_kernel, gV, blk, 0, stream, cnt_i, tsum_i, nonbin, pix2v, vcell, nv, target_u8, target_f64, H, W,
                      sigma_spatial, d, confidence, cnt, wsplat, bsplat, bt);
   // bistochastise: n = 1; 10x n = sqrt(n*m0/blur(n)); m = n*blur(n)
-  hipLaunchKernelGGL(bg_fill_kernel, gV, blk, 0, stream, nA, 1.0, nv, bt);
+  hipLaunchKernelGGL(bg_bisto_first, gV, blk, 0, stream, cnt, nbr, nv, nA, bt);
   double *ncur = nA, *nnext = nB;
-  for (int i = 0; i < 10; ++i) {
+  for (int i = 1; i < 10; ++i) {
     hipLaunchKernelGGL(bg_bisto_step, gV, blk, 0, stream, ncur, cnt, nbr, nv, nnext, bt);
     double* t = ncur; ncur = nnext; nnext = t;
   }
-  hipLaunchKernelGGL(bg_bisto_final, gV, blk, 0, stream, ncur, nbr, nv, m, bt);
+  // (m = n .* blur(n) is formed by the PCG's init kernel)
   // PCG
   CgPtrs c;
-  c.n = ncur; c.m = m; c.wsplat = wsplat; c.b = bsplat; c.nbr = nbr; c.nv = nv;
-  c.minv = D[6]; c.x = D[7]; c.r = D[8]; c.z = D[9]; c.p = D[10]; c.q = D[11]; c.p2 = D[12];
-  c.part_rz = part; c.part_rr = part + (size_t)L.nblocks; c.part_pq = part + 2 * (size_t)L.nblocks; c.sc = sc;
+  c.n = ncur; c.m = m; c.mw = m; c.wsplat = wsplat; c.b = bsplat; c.nbr = nbr; c.nv = nv;
+  c.cst = (CgCst*)D[6]; c.dyn0 = (CgDyn*)D[8]; c.dyn1 = (CgDyn*)D[12]; c.x = D[16];     // dstride is a multiple of 256 bytes: records stay aligned
+  c.part = part; c.nblocks = L.nblocks; c.sc = sc;
   c.lam = lam; c.a_diag_min = a_diag_min; c.rtol = cg_tol;
   hipLaunchKernelGGL(cg_init_kernel, gV, blk, 0, stream, c, bt);
-  hipLaunchKernelGGL(cg_atol_kernel, g1, blk, 0, stream, c, bt);
-  for (int it = 0; it < cg_maxiter; ++it) {
-    hipLaunchKernelGGL(cg_pq_kernel, gV, blk, 0, stream, c, it, bt);
-    hipLaunchKernelGGL(cg_update_kernel, gV, blk, 0, stream, c, it, bt);
-  }
-  hipLaunchKernelGGL(bg_slice_kernel, gN, blk, 0, stream, c.x, pix2v, N, out_soft, bt);
-  hipLaunchKernelGGL(cg_finish_kernel, g1, blk, 0, stream, c, cg_maxiter, stats, ncur, m, n_out, m_out, bt);
+  for (int it = -1; it < cg_maxiter; ++it)
+    hipLaunchKernelGGL(cg_step_kernel, gV, blk, 0, stream, c, it, (int)(it == cg_maxiter - 1), bt);
+  hipLaunchKernelGGL(bg_slice_kernel, gN, blk, 0, stream, c.x, pix2v, N, out_soft, nv, sc, cg_maxiter, stats, bt);
+  if (n_out || m_out) hipLaunchKernelGGL(cg_debug_copy_kernel, g1, blk, 0, stream, nv, ncur, m, n_out, m_out, bt);
   ZH_CHECK_LAUNCH("zh_bilateral_solve");
   return ZH_OK;
 }

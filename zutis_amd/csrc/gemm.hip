@@ -81,6 +81,27 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   // 16-byte row stores need 16-B aligned rows; an f16 residual is not supported (none on the hot path)
   const bool wide_ok = p.vec_ok && (((uintptr_t)C & 15) == 0) && ((ldc * esz) % 16 == 0) && ((strideC * esz) % 16 == 0) &&
                        ((N * esz) % 16 == 0) && !(out_f16 && residual);
+  // Tail peel (the f16x3 dispatcher's, gemm_x3.hip): a big-tile GEMM a few tiles over whole rounds of the 256-CU chip pays a full
+  // round for them (config 5's out_proj / c_proj at fp16, 147712 x 1024: 2308 tiles of 256 x 256 = 9 rounds + 4 tiles).  When the
+  // surplus is at most a quarter round, the last m-tile rows that hold it go into a second call on the row range [M', M) (its own
+  // tile choice; the K order of a tile does not depend on the tile shape: bitwise one launch).  Plain pointer offsets only: no
+  // batch, no pos tables, a residual with a row of its own per output row.
+  if ((pick == 256 || pick == 192) && wide_ok && batch == 1 && !pos_y && (!residual || res_rows >= M) && !forced) {
+    const long BNp = pick == 256 ? 256 : 192;
+    const long nbm = zh_cdiv(M, 256), nbn = zh_cdiv(N, BNp), tiles = nbm * nbn, rem = tiles % 256;
+    if (tiles > 4 * 256 && rem > 0 && rem <= 64) {
+      const long r = (rem + nbn - 1) / nbn;                       // m-tile rows to peel
+      const long M1 = (nbm - r) * 256;                            // rows that stay: whole tiles, whole rounds (or just under)
+      if (r * nbn <= 64 && M1 > 0 && M1 < M) {
+        int rc = zh_gemm_f16(A, lda, strideA, W, ldw, strideW, C, ldc, strideC, out_f16, bias, residual, ldr, strideR, residual ? res_rows : 0,
+                             pos_y, pos_x, ld_pos, pos_h, pos_w, pos_f16, act, (int)M1, N, K, 1, stream);
+        if (rc != ZH_OK) return rc;
+        return zh_gemm_f16((const char*)A + M1 * lda * 2, lda, strideA, W, ldw, strideW, (char*)C + M1 * ldc * esz, ldc, strideC, out_f16, bias,
+                           residual ? residual + M1 * ldr : nullptr, ldr, strideR, residual ? (int)(res_rows - M1) : 0,
+                           pos_y, pos_x, ld_pos, pos_h, pos_w, pos_f16, act, (int)(M - M1), N, K, 1, stream);
+      }
+    }
+  }
   bool ok;
   if (!p.vec_ok) ok = launch_gemm<2, 2, 4, 4, 4, 0>(p, batch, out_f16, stream);      // scalar-store fallback: small tile only
   else if (!wide_ok) ok = launch_gemm<2, 2, 4, 4, 4, 1>(p, batch, out_f16, stream);  // direct 8/16-B stores

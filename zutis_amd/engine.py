@@ -25,6 +25,8 @@ def _to_host(t: torch.Tensor, cache: Dict[int, torch.Tensor]) -> np.ndarray:
     view of the cached buffer: valid until that engine's next call with the same size (callers take what they need out of it before
     they return); a buffer that falls out of the cache stays alive as long as a view of it does."""
     n = t.numel()
+    if cache is None:                                 # called without an engine instance (tests drive the predict's pieces that way)
+        cache = {}
     buf = cache.get(n)
     if buf is None:
         while len(cache) >= 8:
@@ -436,7 +438,7 @@ class ZutisEngine(_EngineBase):
             idx, _, _, cnt = ops.mask_nms(inter, uni, scores.contiguous(), category_ids.contiguous(), nms_type, nms_threshold, sigma, threshold,
                                           packed=packed, range_flag=range_flag, zero_word=cursor)
             ops.mask_rle_fused_kept(m, idx, cnt, max_runs, small[n1 + n2 + 8:], cursor, info, bits=bits)
-            host = _to_host(small, self._pinned)                                   # the one synchronisation of the predict
+            host = _to_host(small, getattr(self, "_pinned", None))                                   # the one synchronisation of the predict
             pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)
             info_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 8)
             chars_h = host[n1 + n2 + 8:]
@@ -482,7 +484,7 @@ class ZutisEngine(_EngineBase):
                                       packed=packed, range_flag=range_flag)
         ops.mask_runs_kept(m, idx, cnt, max_runs, pos_head, nr, ba, packed=True)
         ops.mask_rle_kept(pos_head, nr, cnt, B, Q, max_runs, H * W, chars, slen)
-        host = _to_host(small, self._pinned)                                       # the one synchronisation of the predict
+        host = _to_host(small, getattr(self, "_pinned", None))                                       # the one synchronisation of the predict
         pk = host[:n1].view(np.float64).reshape(B, 4 * Q + 2)
         nr_h = host[n1:n1 + n2].view(np.int32).reshape(B, Q, 2)
         ba_h = host[n1 + n2:n1 + n2 + n3].view(np.int32).reshape(B, Q, 5)
