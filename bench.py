@@ -177,12 +177,15 @@ def bench_c5(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29532")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     from zutis_amd import detgen, ops
     from zutis_amd.engine import ClipImageEncoder
-    D, L, p, g, E = 1024, 24, 14, 24, 768
+    D, L, p, g, E = 1024, args.c5_layers, 14, 24, 768
     B = 256 if args.batch == 32 else args.batch
 
     def w(name, shape, std, mean=0.0):
@@ -229,7 +232,7 @@ def bench_c5(args):
         return l
     for i in range(max(n_lanes, args.warmup)):
         step(i)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -237,17 +240,47 @@ def bench_c5(args):
         last = step(i)
     torch.cuda.synchronize()
     emb = embs[last]
-    if world > 1:
+    if dist_on:
         allemb = torch.empty((world * B, E), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(allemb, emb)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- the pipeline's second half (datasets/index_dataset.py:158-167): per-category top-500 retrieval over the extracted embeddings.
+    # Rank r holds the embeddings of images [r*B, (r+1)*B) of the last step; every rank takes the exact top-k of ITS shard, the [C, k]
+    # candidates are all-gathered (the only collective of this config besides the embeddings gather) and merged identically everywhere.
+    # Outside the timed region (the metric is extraction rate); timed on its own and checked against the unsharded form on rank 0.
+    from zutis_amd import retrieval as zr
+    Ccat, ktop = 919, 500
+    tcat = torch.nn.functional.normalize(torch.randn((Ccat, E), generator=torch.Generator(device="cpu").manual_seed(77)), dim=1).to(dev)
+    retr = None
+    if dist_on:
+        zr.retrieve_topk_sharded(tcat, emb, rank * B, ktop)
+        torch.cuda.synchronize(); dist.barrier()
+        t1 = time.perf_counter()
+        ridx, rval = zr.retrieve_topk_sharded(tcat, emb, rank * B, ktop)
+        torch.cuda.synchronize(); dist.barrier()
+        dtr = time.perf_counter() - t1
+        same = None
+        if rank == 0:
+            fidx, fval = zr.retrieve_topk(tcat, allemb, ktop)             # the gathered embeddings, unsharded
+            same = bool(torch.equal(fidx, ridx) and torch.equal(fval, rval))
+        retr = {"form": "sharded: local exact top-k + all-gather of [C, k] candidates + merge", "ms": round(dtr * 1e3, 3),
+                "equals_unsharded_on_rank0": same}
+    else:
+        zr.retrieve_topk(tcat, emb, ktop)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ridx, rval = zr.retrieve_topk(tcat, emb, ktop)
+        torch.cuda.synchronize()
+        retr = {"form": "one rank: similarity GEMM (f16x3) + exact radix top-k", "ms": round((time.perf_counter() - t1) * 1e3, 3)}
+    retr.update({"categories": Ccat, "k": min(ktop, world * B), "images": world * B,
+                 "what": "top-k image indices per category over the last step's embeddings (datasets/index_dataset.py:158-167), outside the timed region"})
     T = g * g + 1
     flop = L * (2 * T * (D * 3 * D + D * D + 2 * D * 4 * D) + 4 * T * T * D) + 2 * g * g * 3 * p * p * D + 2 * D * E
     roof = cpu = parity = None
@@ -316,7 +349,7 @@ def bench_c5(args):
                   "note": "the reference runs config 5 in fp16 on a GPU (third-party clip.load; extract_image_embeddings.py:76): fast is its "
                           "arithmetic class, exact is fp32-class"}
         del encf, ef
-    if world > 1:
+    if dist_on:
         dist.barrier()                    # rank 0 measured the roofline after the timed region: leave together
         dist.destroy_process_group()
     if rank == 0:
@@ -327,7 +360,8 @@ def bench_c5(args):
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
             "precision": {"mode": args.precision, "what": PRECISION_TEXT[args.precision]},
-            "config": {"workload": f"C5: CLIP ViT-L/14@336 encode_image, {B}x3x336x336 per GPU per step, embeddings fp32 [{B},{E}], "
+            "config": {"workload": ("" if L == 24 else f"NOT CONFIG 5 ({L} layers, --c5-layers): ") +
+                                   f"C5: CLIP ViT-L/14@336 encode_image, {B}x3x336x336 per GPU per step, embeddings fp32 [{B},{E}], "
                                    "one all-gather of the last step's embeddings", "global_batch": world * B, "parallelism": f"dp{world}",
                        "flops_per_image": flop,
                        "weights": ("generic fp32 values in every tensor (--c5-fp32-weights)" if args.c5_fp32_weights else
@@ -335,7 +369,7 @@ def bench_c5(args):
                                    "leaves them (clip_arch.py:566-587,625); the engine detects it per weight at pack time and skips the "
                                    "product with the all-zero lo plane (f16x2: bit-identical to f16x3)")},
             "model_tflops": round(total * flop / elapsed / 1e12 / world, 1), "roofline": roof, "cpu_baseline": cpu, "parity": parity,
-            "generic_fp32_weights": generic, "second_precision": second,
+            "generic_fp32_weights": generic, "second_precision": second, "retrieval": retr,
             "embedding_norm": round(float(emb.norm(dim=1).mean().item()), 6)}), flush=True)
 
 
@@ -801,6 +835,7 @@ def main():
                          "c3: instance segmentation image by image at 480x640 + the bilateral solver at 512x683 (config 3)")
     ap.add_argument("--c5-fp32-weights", action="store_true", help="c5: generic fp32 values in the GEMM weights instead of the fp16 values the "
                     "reference's build_model -> convert_weights leaves there (forces the three-product kernel)")
+    ap.add_argument("--c5-layers", type=int, default=24, help="developer (tests): depth of the c5 tower; anything but 24 is not config 5")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
     ap.add_argument("--precision", default=None, choices=["fast", "exact", "f16"],

@@ -30,6 +30,20 @@ def test_dry_launch_builds_one_rank_per_gpu():
     assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_dry_launch_for_every_sharded_workload():
+    """BASELINE configs 4 and 5 at N GPUs go through the same launcher as the headline: `bench.py --workload c4|c5 --gpus N` = N ranks
+    under torch.distributed.run with the workload's arguments passed on (c4: StepPipeline + per-step all-gather of the logits; c5: rank-
+    sharded extraction + sharded retrieval — both covered at world 2 on gloo in tests/test_distributed_cpu.py)."""
+    for wl, extra in (("c4", ["--batch", "8"]), ("c5", ["--inflight", "1"]), ("c3", [])):
+        r = subprocess.run([sys.executable, BENCH, "--workload", wl, "--gpus", "8", "--dry-launch"] + extra, capture_output=True, text=True,
+                           env=_env(), timeout=120)
+        assert r.returncode == 0, r.stderr
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        cmd = d["cmd"]
+        assert d["n_ranks"] == 8 and "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+        assert cmd[cmd.index(BENCH) + 1:] == ["--workload", wl, "--gpus", "8"] + extra
+
+
 def test_launch_command_starts_n_ranks(tmp_path):
     """The launcher's command with a stand-in script: two processes, RANK 0 and 1, WORLD_SIZE 2, a gloo all-reduce between them."""
     sys.path.insert(0, ROOT)

@@ -19,3 +19,25 @@ def test_rccl_one_rank_step_pipeline(dev):
     env = {**os.environ, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     r = subprocess.run([sys.executable, worker, str(port)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_SMOKE_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_rccl_one_rank_bench_c5_sharded_retrieval(dev):
+    """`bench.py --workload c5` on its N > 1 path with ONE rank (--force-dist: RCCL group, the embeddings all-gather, the sharded
+    retrieval = local exact top-k + all-gather of the [C, k] candidates + merge): the line carries a retrieval object whose result
+    equals the unsharded retrieve_topk over the gathered embeddings.  A 2-layer tower (--c5-layers 2) keeps the host-side weight
+    generation short; the collective path does not depend on the depth."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**os.environ, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c5", "--force-dist", "--c5-layers", "2", "--batch", "16",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-second-precision"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["retrieval"]["equals_unsharded_on_rank0"] is True and d["retrieval"]["k"] == 16 and d["retrieval"]["categories"] == 919
+    assert d["value"] > 0 and "NOT CONFIG 5" in d["config"]["workload"]
