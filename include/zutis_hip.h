@@ -44,7 +44,7 @@ typedef struct ihipStream_t* zh_stream_t; /* == hipStream_t */
 /* ABI version: bumped whenever an entry point's signature changes.  zh_version() returns the value the library was BUILT
  * with; a binding compiled / written against this header must refuse a library that reports another one (zutis_amd/_lib.py
  * does) — ctypes cannot see a changed argument list. */
-#define ZH_ABI_VERSION 224 /* 224: zero_word of zh_mask_nms; 223: zh_mask_rle_fused_kept; 222: zh_mask_rle_kept; 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list), packed form of zh_rle_from_transitions_host; 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
+#define ZH_ABI_VERSION 225 /* 225: zh_dev_set_gemm_persist; 224: zero_word of zh_mask_nms; 223: zh_mask_rle_fused_kept; 222: zh_mask_rle_kept; 221: packed_capacity of zh_mask_runs_kept (the kept masks' transitions as one list), packed form of zh_rle_from_transitions_host; 220: flags argument of zh_gemm_f16x3 (ZH_GEMM_FIXED_K_ORDER); 219: workspace of zh_mask_runs / zh_mask_runs_kept (two-launch run extraction); 218: status word of the LayerNorm family, f16_scale of the unit-norm producers; 217: zh_mask_runs_kept, range_flag / packed arguments of zh_instance_mask_stats / zh_mask_nms; 216: zh_sum_layernorm_f32, few-row kernel behind zh_gemm_f16x3; 215: zh_rle_from_transitions_host; 214: zh_gemm_f16x3 accepts planeW = 0 (fp16-valued weight: two products); 213: workspace argument of zh_masked_mean_tokens; 212: zh_attention_f16_splitk; 211: zh_dev_set_gemm_overrides; 210: pos_y / pos_x tables on zh_gemm_f16 / zh_gemm_f16x3 */
 int zh_version(void);
 const char* zh_arch(void);
 const char* zh_last_error(void);
@@ -54,6 +54,12 @@ const char* zh_last_error(void);
  * zh_gemm_f16x3 (64|96|192|256|448|512|3064; 5122 / 5124 = the planeW = 0 form of 512 on two slots / as 2 x 4 waves of 128 x 64, 4484 = of 448 as 4 x 2 waves of 48 x 128), 0 = the cost model's choice; tile_small = the same, applied to M <= 4096 only.  Process-wide;
  * the initial values come from ZH_GEMM_GROUP_M / ZH_GEMM_TILE / ZH_GEMM_TILE_SMALL, read once. */
 int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small);
+
+/* DEVELOPER entry: the big plain-fp16 GEMM tiles (256 x 256 / 256 x 192) are persistent — `workgroups` of them walk a launch's tiles and
+ * request the next tile's first K slices under the current tile's epilogue (csrc/gemm_kernel.h PERS; bitwise the one-workgroup-per-
+ * tile results).  Default 256 (one per CU; ZH_GEMM_PERSIST read once); 0 = one workgroup per tile; any multiple of 8 forces that many
+ * (tests use 8 to make small problems walk several tiles per workgroup).  Process-wide. */
+int zh_dev_set_gemm_persist(int workgroups);
 
 /* C[b][m][n] = act(sum_k A[b][m][k]*W[b][n][k] + bias[n] + pos[m][n]) + residual[b][m % res_rows][n]
  * A [M,K] f16 (lda), W [N,K] f16 (ldw) — torch Linear layout; C f32 or f16 (out_f16); bias/residual f32 or NULL.

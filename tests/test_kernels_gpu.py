@@ -172,6 +172,44 @@ def test_gemm_tail_peel_is_bitwise_one_launch(dev):
     assert float((o_p.double() - ref).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("tile,N", [("256", 1024), ("192", 960)])
+def test_gemm_persistent_tiles_are_bitwise_one_workgroup_per_tile(dev, tile, N):
+    """The big plain-fp16 tiles walk a launch's tiles with persistent workgroups and request the next tile's first K slices under the
+    current tile's epilogue (gemm_kernel.h PERS).  Forced grids of 8 / 16 / 40 workgroups (3 - 20 tiles each, ragged last tiles, K from
+    one slice to many, batched) against one workgroup per tile (persist = 0): bit for bit, for the fp16 + activation epilogue and — on
+    the 256 x 192 tile — fp32 + bias + residual; repeated launches identical (the LDS hand-over between epilogue slabs and the next
+    prologue is what a race would break)."""
+    from zutis_amd import ops, _lib
+    L = _lib.load(raw=True)
+    M = 5 * 256 + 77
+    try:
+        _lib.check(L.zh_dev_set_gemm_overrides(0, int(tile), 0), "zh_dev_set_gemm_overrides")
+        for K, batch in ((64, 1), (128, 1), (192, 2), (768, 1), (1024, 3)):
+            A = _randn((batch, M, K), 500 + K, 0.5).to(f16).to(dev)
+            W = _randn((batch, N, K), 600 + K, 0.05).to(f16).to(dev)
+            bias = _randn((N,), 7).to(dev)
+            res = _randn((M, N), 8).to(dev)
+
+            def run():
+                h = torch.empty((batch, M, N), dtype=f16, device=dev)
+                ops.gemm(A, W, h, bias=bias, act=ops.ACT_QUICKGELU, batch=batch, strideA=M * K, strideW=N * K, strideC=M * N)
+                o = torch.empty((batch, M, N), dtype=f32, device=dev)
+                ops.gemm(A, W, o, bias=bias, residual=res, res_rows=M, batch=batch, strideA=M * K, strideW=N * K, strideC=M * N)
+                return h, o
+            _lib.check(L.zh_dev_set_gemm_persist(0), "zh_dev_set_gemm_persist")
+            h0, o0 = run()
+            ref = torch.einsum("bmk,bnk->bmn", A.float(), W.float()) + bias + res
+            assert torch.allclose(o0, ref, atol=2e-3 * math.sqrt(K / 64), rtol=1e-3)
+            for g in (8, 16, 40):
+                _lib.check(L.zh_dev_set_gemm_persist(g), "zh_dev_set_gemm_persist")
+                for _ in range(3):
+                    h1, o1 = run()
+                    assert torch.equal(h1, h0) and torch.equal(o1, o0), (tile, K, batch, g)
+    finally:
+        L.zh_dev_set_gemm_overrides(0, 0, 0)
+        L.zh_dev_set_gemm_persist(256)
+
+
 def test_gemm_forced_tile_is_really_forced(dev):
     """The override reaches the launcher: an unknown tile code is an argument error (it would be ignored if the setter did
     nothing), and clearing it restores the cost model."""

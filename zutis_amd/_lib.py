@@ -30,6 +30,7 @@ _SIGS = {
     "zh_arch": (C.c_char_p, []),
     "zh_last_error": (C.c_char_p, []),
     "zh_dev_set_gemm_overrides": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "zh_dev_set_gemm_persist": (C.c_int, [C.c_int]),
     "zh_gemm_f16": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "zh_gemm_f16x3": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _f, _vp, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i,
                            _i, _vp]),

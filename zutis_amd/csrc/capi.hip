@@ -40,6 +40,15 @@ extern "C" int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small) 
   return ZH_OK;
 }
 
+// persistent big-tile GEMMs (gemm_kernel.h PERS): workgroups per launch = CUs of the chip; developer override for tests / A-B
+static int g_gemm_persist = [] { const char* e = getenv("ZH_GEMM_PERSIST"); return e ? atoi(e) : 256; }();
+int gemm_persist_cus() { return g_gemm_persist; }
+extern "C" int zh_dev_set_gemm_persist(int workgroups) {
+  ZH_CHECK_ARG(workgroups >= 0 && workgroups % 8 == 0, "zh_dev_set_gemm_persist: %d is not 0 (off) or a multiple of 8", workgroups);
+  g_gemm_persist = workgroups;
+  return ZH_OK;
+}
+
 // ---- host-side COCO RLE (pycocotools maskApi.c rleEncode + rleToString restated): the reference encodes every kept
 //      instance mask with pycocotools.mask.encode(np.asfortranarray(m)) (networks/zutis.py:290,448).  HOST pointers.
 //      mask u8 [H,W] row-major; runs are taken in column-major order starting with the zeros run.  Returns the string

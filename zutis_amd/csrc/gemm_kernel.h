@@ -54,6 +54,7 @@ struct GemmArgs {
   // the accumulator before the activation — the tile's accumulators START from it, loaded under the ring's prologue
   const void* pos_y; const void* pos_x; long ld_pos; int pos_hw, pos_w, pos_f16;   // tables fp32, or fp16 (pos_f16)
   int M, N, K, act, nbm, nbn, vec_ok, group_m;
+  int total;                     // tiles x batch items of the launch (the persistent big tiles walk them with stride gridDim.x)
 #ifdef ZH_GEMM_PROBE
   long long* probe;   // developer build (tools/gemm_probe.py): 4 timestamps per block
 #endif
@@ -123,35 +124,51 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   constexpr int AHEAD = SPLIT ? 1 : DIST - 2; // whole stages that may still be in flight at a steady-state barrier
   static_assert(AHEAD >= 1 && AHEAD * NP < 64, "ring too shallow / vmcnt overflow");
   constexpr int STAGE_HALVES = ROWS * KB;
-  __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE_HALVES];
+  // PERS (round 5): the big plain-fp16 tiles (8 waves, 4-slot ring) are PERSISTENT — a workgroup walks tiles vb, vb + gridDim.x, ... and
+  // requests the next tile's first DIST slices right behind the barrier that opens this tile's epilogue, so the ~2 us of first-byte
+  // latency (and the dispatch of a new workgroup) land under the epilogue's 3.5 - 13 us of stores instead of in front of the next K
+  // loop (in-kernel probe, QKV 14144 x 2304 x 768: prologue 2.1 / K loop 19.0 / epilogue 3.5 us per tile).  The epilogue's slabs live
+  // in the ring slot the prologue does not use plus the LDS beyond the ring (the kernel takes all 160 KiB), in smaller passes.
+  // Same arithmetic per output element: results are bitwise those of one workgroup per tile (the launcher picks the grid).
+  // (the fp32-output 256 x 256 form stays one workgroup per tile: with the tile loop around it hipcc spills 36 bytes in its epilogue)
+  constexpr bool PERS = !SPLIT && NW == 8 && STAGES == 4 && VEC == 2 && (OUT == 1 || TN == 3);
+  constexpr int SLAB_OFF = PERS ? (STAGES - 1) * STAGE_HALVES * 2 : 0;                       // bytes: slot STAGES - 1 and what follows
+  constexpr int LDS_BYTES = PERS ? 160 * 1024 : STAGES * STAGE_HALVES * 2;
+  constexpr int SLAB_CAP = LDS_BYTES - SLAB_OFF;
+  __shared__ __attribute__((aligned(16))) half_t smem[LDS_BYTES / 2];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform values live in SGPRs
   const int wr = wave / WN, wc = wave % WN;
   ZH_PROBE(0);
 
-  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous id range
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tiles = p.nbm * p.nbn;
-  const int batch = wg / tiles;
-  const int trem = wg - batch * tiles;
-  // super-tile order: GROUP_M consecutive ids walk GROUP_M m-tiles of one n-tile
-  const int gsz = p.group_m * p.nbn;
-  const int gid = trem / gsz;
-  const int gfirst = gid * p.group_m;
-  const int grows = min(p.nbm - gfirst, p.group_m);
-  const int gl = trem - gid * gsz;
+  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous id range.  `vb` is the virtual block
+  // id: blockIdx.x for one workgroup per tile; blockIdx.x + i * gridDim.x for the i-th tile of a persistent workgroup (gridDim.x is
+  // a multiple of 8 then: every tile of a workgroup keeps its XCD's id range, and at any moment an XCD runs consecutive ids)
+  auto decode = [&](int vb, int& batch_, int& tm_, int& tn_) {
+    const int nwg = PERS ? p.total : (int)gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int tiles = p.nbm * p.nbn;
+    const int xcd = vb & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+    batch_ = wg / tiles;
+    const int trem = wg - batch_ * tiles;
+    // super-tile order: GROUP_M consecutive ids walk GROUP_M m-tiles of one n-tile
+    const int gsz = p.group_m * p.nbn;
+    const int gid = trem / gsz;
+    const int gfirst = gid * p.group_m;
+    const int grows = min(p.nbm - gfirst, p.group_m);
+    const int gl = trem - gid * gsz;
 #ifdef ZH_X_WALK_N                                      // developer A/B: consecutive ids walk the n-tiles of one m-tile
-  const int tm = gfirst + gl / p.nbn, tn = gl % p.nbn;
+    tm_ = gfirst + gl / p.nbn; tn_ = gl % p.nbn;
 #else
-  const int tm = gfirst + gl % grows, tn = gl / grows;
+    tm_ = gfirst + gl % grows; tn_ = gl / grows;
 #endif
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const half_t* A = p.A + (long)batch * p.sA;
-  const half_t* W = p.W + (long)batch * p.sW;
+  };
+  int vb = blockIdx.x;
+  int batch, tm, tn;
+  decode(vb, batch, tm, tn);
+  int m0 = tm * BM, n0 = tn * BN;
 
   // DMA sources: piece pc covers LDS rows [16*pc, 16*pc+16); lane -> row (lane>>2), phys chunk lane&3.
   // LDS row order: A hi [BM] (A lo [BM]) W hi [BN] (W lo [BN]).  A piece never straddles two row sets, so its source is a
@@ -159,37 +176,48 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const half_t* gbase[NP];
   unsigned goff[NP];
   int lds_piece[NP];
+  auto setup_dma = [&](int b_, int m0_, int n0_, int lane) {   // the tile's operand rows -> gbase / goff (`lane`: see lane_e in the epilogue)
+    const half_t* A = p.A + (long)b_ * p.sA;
+    const half_t* W = p.W + (long)b_ * p.sW;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    int pc = wave + i * NW;
-    pc = pc < PIECES ? pc : PIECES - 1;
-    lds_piece[i] = pc * RPP * KB;
-    const int R0 = pc * RPP;                      // uniform
-    const int rl = lane / LPR;
-    // 64-B rows: chunk ^ (-(row >> 2) & 3), (R0 + rl) >> 2 == R0/4 + (rl >> 2), R0/4 % 4 == 0.  128-B rows (K64): chunk ^ ((row >> 1) & 7)
-    // — with it the sixteen lanes ds_read_b128 services together (rows 0-3, 12-15 of one k-chunk and 4-11 of its neighbour) fall into
-    // sixteen different 16-byte bank groups: even rows take 0-7, odd rows 8-15, and (c ^ s) is a bijection over the eight rows of a parity
-    const int c = K64 ? ((lane & 7) ^ (((R0 + rl) >> 1) & 7)) : ((lane & 3) ^ ((-(rl >> 2)) & 3));
-    if (R0 < NPL * BM) {
-      const int pl = SPLIT ? (R0 >= BM) : 0;
-      int row = m0 + (R0 - pl * BM) + rl;
-      row = row < p.M ? row : p.M - 1;
-      gbase[i] = A + pl * p.planeA;
-      goff[i] = (unsigned)row * (unsigned)p.lda + c * 8;
-    } else {
-      const int Rw = R0 - NPL * BM;
-      const int pl = SPLIT == 1 ? (Rw >= BN) : 0;
-      int row = n0 + (Rw - pl * BN) + rl;
-      row = row < p.N ? row : p.N - 1;
-      gbase[i] = W + pl * p.planeW;
-      goff[i] = (unsigned)row * (unsigned)p.ldw + c * 8;
+    for (int i = 0; i < NP; ++i) {
+      int pc = wave + i * NW;
+      pc = pc < PIECES ? pc : PIECES - 1;
+      lds_piece[i] = pc * RPP * KB;
+      const int R0 = pc * RPP;                      // uniform
+      const int rl = lane / LPR;
+      // 64-B rows: chunk ^ (-(row >> 2) & 3), (R0 + rl) >> 2 == R0/4 + (rl >> 2), R0/4 % 4 == 0.  128-B rows (K64): chunk ^ ((row >> 1) & 7)
+      // — with it the sixteen lanes ds_read_b128 services together (rows 0-3, 12-15 of one k-chunk and 4-11 of its neighbour) fall into
+      // sixteen different 16-byte bank groups: even rows take 0-7, odd rows 8-15, and (c ^ s) is a bijection over the eight rows of a parity
+      const int c = K64 ? ((lane & 7) ^ (((R0 + rl) >> 1) & 7)) : ((lane & 3) ^ ((-(rl >> 2)) & 3));
+      if (R0 < NPL * BM) {
+        const int pl = SPLIT ? (R0 >= BM) : 0;
+        int row = m0_ + (R0 - pl * BM) + rl;
+        row = row < p.M ? row : p.M - 1;
+        gbase[i] = A + pl * p.planeA;
+        goff[i] = (unsigned)row * (unsigned)p.lda + c * 8;
+        if constexpr (PERS) gbase[i] += goff[i];
+      } else {
+        const int Rw = R0 - NPL * BM;
+        const int pl = SPLIT == 1 ? (Rw >= BN) : 0;
+        int row = n0_ + (Rw - pl * BN) + rl;
+        row = row < p.N ? row : p.N - 1;
+        gbase[i] = W + pl * p.planeW;
+        goff[i] = (unsigned)row * (unsigned)p.ldw + c * 8;
+        if constexpr (PERS) gbase[i] += goff[i];
+      }
     }
-  }
+  };
+  setup_dma(batch, m0, n0, lane);
+  // PERS: ONE per-lane 64-bit source pointer per piece (base + lane offset folded at tile setup, advanced by a 64-bit add per issue)
+  // instead of a uniform base + a 32-bit lane offset: hipcc forms 64-bit per-lane addresses for the builtin anyway and kept BOTH forms
+  // alive across the K loop (the offsets for the tail loops) — 8 registers the tile loop does not have
   auto issue_stage = [&](int slot) {
     half_t* sb = smem + slot * STAGE_HALVES;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase[i] + goff[i]), (lds_ptr_t)(sb + lds_piece[i]), 16, 0, 0);
+      if constexpr (PERS) __builtin_amdgcn_global_load_lds((glb_ptr_t)gbase[i], (lds_ptr_t)(sb + lds_piece[i]), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase[i] + goff[i]), (lds_ptr_t)(sb + lds_piece[i]), 16, 0, 0);
       gbase[i] += KB;
     }
   };
@@ -215,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   // (SPLIT = 2: at most 2 passes — more register sets spilled in the 256 x 256 tiles; larger slices take the direct path.  No
   //  x2 GEMM of the model carries pos tables: the composed K / V weights that do are never fp16-valued.)
   constexpr int POS_MAXIT_FULL = (POS_SLOT_BYTES / 16 + POS_NT - 1) / POS_NT;
-  constexpr int POS_MAXIT = SPLIT == 2 && POS_MAXIT_FULL > 2 ? 2 : POS_MAXIT_FULL;
+  constexpr int POS_MAXIT = SPLIT == 2 && POS_MAXIT_FULL > 2 ? (TN >= 8 ? 1 : 2) : POS_MAXIT_FULL;   // (TN = 8: one pass — a second register set spilled once the tile loop of round 5 wrapped the kernel)
   constexpr int POS_CAP_BYTES = POS_MAXIT * POS_NT * 16 < POS_SLOT_BYTES ? POS_MAXIT * POS_NT * 16 : POS_SLOT_BYTES;
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t pos_v[POS_MAXIT];
@@ -324,6 +352,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const int foff = K64 ? frow * KB : frow * BK + ((fk ^ ((-(frow >> 2)) & 3)) * 8);   // per-lane offset inside a 16-row subtile (K64: + the k-step's chunk)
   const half_t* rdA = smem + (wr * TM * 16) * KB + foff;
   const half_t* rdW = smem + (NPL * BM + wc * TN * 16) * KB + foff;
+
+  if constexpr (PERS) {                       // the first tile's prologue, in FRONT of the tile loop: with the pos-table code inside it, everything
+    pos_before_prologue();                    // in there that depends on the lane alone was hoisted out and kept alive through the K loop (spills)
+#pragma unroll
+    for (int s = 0; s < DIST; ++s)
+      if (s < nk) issue_stage(s % STAGES);
+    pos_after_prologue();
+  }
+  for (;;) {                                  // tiles of this workgroup: one, or (PERS) vb, vb + gridDim.x, ...
+  const int vb_next = vb + (int)gridDim.x;
+  const bool more = PERS && vb_next < p.total;
 
   constexpr bool BIGT = SPLIT && BM * BN >= 192 * 256;    // the two-slot (SPLIT = 2: three-slot) big tiles
   static_assert(!SPLIT || K64 || BIGT == (STAGES == 2 || (SPLIT == 2 && STAGES == 3 && BM * BN >= 192 * 256)), "big split-pair tiles: 2 slots (x2: 2 or 3)");
@@ -619,11 +658,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       advance();
     }
   } else {
-  pos_before_prologue();
+  if constexpr (!PERS) {                      // (PERS: requested in front of the tile loop / under the previous tile's epilogue)
+    pos_before_prologue();
 #pragma unroll
-  for (int s = 0; s < DIST; ++s)
-    if (s < nk) issue_stage(s % STAGES);
-  pos_after_prologue();
+    for (int s = 0; s < DIST; ++s)
+      if (s < nk) issue_stage(s % STAGES);
+    pos_after_prologue();
+  }
 
   // Register double-buffered fragments: while the MFMAs of slice kt run, the ds_read_b128 of slice kt+1 are in
   // flight (the LDS latency at the head of every slice was exposed on all 8 waves at once behind the barrier).
@@ -699,8 +740,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   }
 
   ZH_PROBE(2);
-  // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4).  ACT / VEC are template
+  // ---- epilogue: lane_e owns rows m = ..+(lane_e&15), 4 consecutive n at 4*(lane_e>>4).  ACT / VEC are template
   // parameters: a runtime switch unrolled 32x blew the instruction cache (fc GEMM 1.4x slower in the model).
+  // PERS: the epilogue sits inside the tile loop, and everything in it that depends on the lane alone is loop-invariant — hoisted in
+  // front of the loop it would stay live through the K loop, which has no register to spare (the build spilled 300+ bytes).  An opaque
+  // copy of the lane id pins those computations here.
+  int lane_e = lane;
+  if (PERS) asm volatile("" : "+v"(lane_e));
+  const int frow_e = PERS ? (lane_e & 15) : frow, fk_e = PERS ? (lane_e >> 4) : fk;
   const long cb = (long)batch * p.sC;
   const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
   const float osc = SPLIT ? p.out_scale : 1.0f;
@@ -708,26 +755,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   if (VEC == 2) {
     // LDS-staged epilogue: the direct form stores 32-byte runs (4 lanes x 8 B) into 16 different 128-B lines per
     // instruction and measured 2.4 TB/s, fully exposed (34 % of a K=768 tile).  Here each wave transposes its tile through
-    // a private, conflict-free LDS slab (row stride +16 B) and writes whole rows with 16 B per lane (split pairs: the
-    // slab holds fp32 and each lane writes 8 B to the hi plane and 8 B to the lo plane).
+    // a private, conflict-free LDS slab (row stride +16 B) and writes whole rows with 16 B per lane_e (split pairs: the
+    // slab holds fp32 and each lane_e writes 8 B to the hi plane and 8 B to the lo plane).
     constexpr int ESZ = OUT_F16 ? 2 : 4;
     constexpr int RS = TN * 16 * ESZ + 16;                  // slab row stride (bytes)
     constexpr int PRW = (OUT_F16 ? 64 : 32) / (TN >= 8 ? 2 : 1);   // wide wave tiles: half the rows per pass (the pass's residual / slab registers)
     constexpr int PR0 = PRW < TM * 16 ? PRW : TM * 16;
-    constexpr int PR = (TM * 16) % PR0 == 0 ? PR0 : (TM * 16 <= 48 ? TM * 16 : 16);       // rows per pass (divides the wave tile)
+    constexpr int PR1 = (TM * 16) % PR0 == 0 ? PR0 : (TM * 16 <= 48 ? TM * 16 : 16);      // rows per pass (divides the wave tile)
+    // PERS: the slabs share what the next tile's prologue leaves of the LDS — halve the pass until they fit
+    constexpr int PR = !PERS ? PR1 : (NW * PR1 * RS <= SLAB_CAP ? PR1 : (NW * (PR1 / 2) * RS <= SLAB_CAP ? PR1 / 2 : PR1 / 4));
+    static_assert(PR >= 8 && (TM * 16) % PR == 0 && NW * PR * RS <= SLAB_CAP, "epilogue slabs do not fit beside the next tile's prologue");
     constexpr int MTP = PR / 16;
     constexpr int CPRW = TN * 16 * ESZ / 16;                // 16-B chunks per row
     constexpr int NIT = PR * CPRW / 64;
     static_assert((PR * CPRW) % 64 == 0, "epilogue slab must divide into full wave reads");
-    static_assert(NW * PR * RS <= (int)sizeof(smem), "epilogue slabs exceed the ring");
-    // the TN bias vectors of this lane's columns, requested together and ONCE (they used to be loaded per pass and sub-tile
+    static_assert(SLAB_OFF + NW * PR * RS <= (int)sizeof(smem), "epilogue slabs exceed the LDS");
+    // the TN bias vectors of this lane_e's columns, requested together and ONCE (they used to be loaded per pass and sub-tile
     // column behind a branch, each followed by a full wait: 16 exposed load latencies in the epilogue of a 256 x 256 tile)
+    // (plain fp16 kernel, fp32 output, no activation — the residual GEMMs: the bias joins at store time instead, where a lane's
+    //  chunk column never changes: ONE vector per lane for the whole epilogue instead of TN — (acc + bias) + residual either way)
+    constexpr bool BIAS_LATE = !SPLIT && OUT == 0 && ACT == ZH_ACT_NONE && (64 % CPRW) == 0;
     f32x4 bvs[TN];
+    f32x4 bias_late = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS_LATE) {
+#pragma clang loop unroll(full)
+      for (int nt = 0; nt < TN; ++nt) bvs[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        int n = n0 + wc * TN * 16 + (lane_e % CPRW) * (16 / ESZ);
+        n = n < p.N ? n : 0;
+        bias_late = *(const f32x4*)(p.bias + n);
+      }
+    } else
     if (p.bias) {                                           // wave-uniform
       const __attribute__((address_space(1))) float* gb = (const __attribute__((address_space(1))) float*)p.bias;
 #pragma clang loop unroll(full)
       for (int nt = 0; nt < TN; ++nt) {
-        int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+        int n = n0 + (wc * TN + nt) * 16 + fk_e * 4;
         n = n < p.N ? n : 0;                                // columns >= N are never stored
         bvs[nt] = *(const __attribute__((address_space(1))) f32x4*)(gb + n);
       }
@@ -736,7 +799,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       for (int nt = 0; nt < TN; ++nt) bvs[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();                                        // ring no longer read; every LDS-DMA has landed
-    char* slab = (char*)smem + wave * (PR * RS);
+    if (more) {                                             // PERS: the next tile's first slices fly under this epilogue
+      int nb_, ntm_, ntn_;
+      decode(vb_next, nb_, ntm_, ntn_);
+      setup_dma(nb_, ntm_ * BM, ntn_ * BN, lane_e);
+#pragma unroll
+      for (int s = 0; s < DIST; ++s)
+        if (s < nk) issue_stage(s % STAGES);
+    }
+    char* slab = (char*)smem + SLAB_OFF + wave * (PR * RS);
 #pragma clang loop unroll(full)
     for (int pass = 0; pass < TM / MTP; ++pass) {
 #pragma clang loop unroll(full)
@@ -744,11 +815,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         const f32x4 bv = bvs[nt];
 #pragma clang loop unroll(full)
         for (int ml = 0; ml < MTP; ++ml) {
-          f32x4 v = SPLIT ? acc[nt][pass * MTP + ml] * osc + bv : acc[nt][pass * MTP + ml] + bv;
+          f32x4 v = SPLIT ? acc[nt][pass * MTP + ml] * osc + bv : (BIAS_LATE ? acc[nt][pass * MTP + ml] : acc[nt][pass * MTP + ml] + bv);
           if (ACT != ZH_ACT_NONE) {
             v[0] = zh_act(v[0], ACT); v[1] = zh_act(v[1], ACT); v[2] = zh_act(v[2], ACT); v[3] = zh_act(v[3], ACT);
           }
-          char* dst = slab + (ml * 16 + frow) * RS + (nt * 16 + fk * 4) * ESZ;
+          char* dst = slab + (ml * 16 + frow_e) * RS + (nt * 16 + fk_e * 4) * ESZ;
           if (OUT_F16) {
             half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             *(half4_t*)dst = h;
@@ -758,7 +829,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         }
       }
       if constexpr (OUT == 2) {
-        // split pair: a lane takes 8 consecutive columns — one 16-byte store per plane instead of two 8-byte ones (the epilogue
+        // split pair: a lane_e takes 8 consecutive columns — one 16-byte store per plane instead of two 8-byte ones (the epilogue
         // of a 256 x 256 tile was 7.9 us of a 29.6-us K = 256 block, store-issue bound: tools/gemm_x3_stamp.py)
         constexpr int UPR = CPRW / 2, NIT2 = PR * UPR / 64;
         static_assert(CPRW % 2 == 0 && (PR * UPR) % 64 == 0, "split-pair epilogue: 8-column units must tile the pass");
@@ -768,7 +839,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         if (R) {
 #pragma clang loop unroll(full)
           for (int it = 0; it < NIT2; ++it) {
-            const int c = it * 64 + lane;
+            const int c = it * 64 + lane_e;
             const int row = c / UPR, un = c - row * UPR;
             const int m = min(m0 + wr * TM * 16 + pass * PR + row, p.M - 1);
             int n = n0 + wc * TN * 16 + un * 8;
@@ -779,7 +850,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         }
 #pragma clang loop unroll(full)
         for (int it = 0; it < NIT2; ++it) {
-          const int c = it * 64 + lane;
+          const int c = it * 64 + lane_e;
           const int row = c / UPR, un = c - row * UPR;
           const int m = m0 + wr * TM * 16 + pass * PR + row;
           const int n = n0 + wc * TN * 16 + un * 8;
@@ -792,7 +863,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       } else {
         // fp32 output + residual (out_proj, c_proj, the decoder's output projections): the loop used to load each residual
         // chunk right where it is added — read slab, ~30 address instructions (an integer modulo among them), ONE load, wait, add,
-        // store — 24 exposed memory latencies per lane in a row: that, not bandwidth, was the 13-us epilogue of a 54-us out_proj
+        // store — 24 exposed memory latencies per lane_e in a row: that, not bandwidth, was the 13-us epilogue of a 54-us out_proj
         // block (tools/gemm_x3_stamp.py).  Now the pass's residual chunks are requested together, branch-free, before the slab is
         // read, and `m % res_rows` is skipped when the residual has a row of its own for every output row.
         f32x4 rv[NIT];
@@ -800,7 +871,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
           auto request = [&](auto nowrap) {
 #pragma clang loop unroll(full)
             for (int it = 0; it < NIT; ++it) {
-              const int c = it * 64 + lane;
+              const int c = it * 64 + lane_e;
               const int row = c / CPRW, ch = c - row * CPRW;
               const int m = min(m0 + wr * TM * 16 + pass * PR + row, p.M - 1);
               int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
@@ -813,13 +884,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         }
 #pragma clang loop unroll(full)
         for (int it = 0; it < NIT; ++it) {
-          const int c = it * 64 + lane;
+          const int c = it * 64 + lane_e;
           const int row = c / CPRW, ch = c - row * CPRW;
           const int m = m0 + wr * TM * 16 + pass * PR + row;
           const int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
           f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
           if (m < p.M && n < p.N) {
             // f32 output: the slab holds fp32, the residual joins before the store
+            if (BIAS_LATE) d += bias_late;
             if (OUT == 0 && R) d += rv[it];
             if (OUT == 1) *(f32x4*)((half_t*)p.C + cb + (long)m * p.ldc + n) = d;
             else *(f32x4*)((float*)p.C + cb + (long)m * p.ldc + n) = d;
@@ -830,13 +902,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   } else if (VEC) {
 #pragma clang loop unroll(full)
     for (int nt = 0; nt < TN; ++nt) {
-      const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+      const int n = n0 + (wc * TN + nt) * 16 + fk_e * 4;
       const bool nok = n < p.N;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (p.bias && nok) bv = *(const f32x4*)(p.bias + n);
 #pragma clang loop unroll(full)
       for (int mt = 0; mt < TM; ++mt) {
-        const int m = m0 + (wr * TM + mt) * 16 + frow;
+        const int m = m0 + (wr * TM + mt) * 16 + frow_e;
         if (nok && m < p.M) {
           f32x4 v = acc[nt][mt] * osc + bv;
           if (ACT != ZH_ACT_NONE) {
@@ -857,11 +929,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   } else {   // unaligned / odd-N fallback: scalar stores (rare: odd pixel counts)
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < TM; ++mt) {
-      const int m = m0 + (wr * TM + mt) * 16 + frow;
+      const int m = m0 + (wr * TM + mt) * 16 + frow_e;
       const long rrow = R ? (long)(m % p.res_rows) * p.ldr : 0;
 #pragma clang loop unroll(full)
       for (int nt = 0; nt < TN; ++nt) {
-        const int n = n0 + (wc * TN + nt) * 16 + fk * 4;
+        const int n = n0 + (wc * TN + nt) * 16 + fk_e * 4;
 #pragma clang loop unroll(full)
         for (int e = 0; e < 4; ++e) {
           if (m < p.M && n + e < p.N) {
@@ -880,6 +952,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       }
     }
   }
+  if (!more) break;
+  vb = vb_next;                               // PERS: on to the workgroup's next tile (its operands are already in flight)
+  decode(vb, batch, tm, tn);
+  m0 = tm * BM; n0 = tn * BN;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 #ifdef ZH_GEMM_PROBE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   ZH_PROBE(3);
@@ -888,12 +969,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 
 
 
+int gemm_persist_cus();      // capi.hip: 256, or the developer override (zh_dev_set_gemm_persist)
+
 template <int WM, int WN, int TM, int TN, int STAGES, int OUT, int ACT, int VEC, int SPLIT>
 static void launch_one(GemmArgs p, int batch, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   p.nbm = zh_cdiv(p.M, BM);
   p.nbn = zh_cdiv(p.N, BN);
-  const unsigned nblk = (unsigned)((long)p.nbm * p.nbn * batch);
+  unsigned nblk = (unsigned)((long)p.nbm * p.nbn * batch);
+  p.total = (int)nblk;
+  // persistent big plain-fp16 tiles (see PERS in the kernel): one workgroup per CU walks the tiles when there is more than one round of
+  // them; never with pos tables (their slice is staged through the ring slot the next tile's prologue would use)
+  constexpr bool PERS = !SPLIT && WM * WN == 8 && STAGES == 4 && VEC == 2 && (OUT == 1 || TN == 3);
+  if (PERS) {
+    const int cus = gemm_persist_cus();                    // 256; developer override: 0 = off, n = a grid of n workgroups (multiple of 8)
+    if (cus > 0 && !p.pos_y && nblk > (unsigned)cus) nblk = (unsigned)cus;
+  }
   hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, STAGES, OUT, ACT, VEC, SPLIT>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
 }
 
