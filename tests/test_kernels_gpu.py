@@ -762,3 +762,41 @@ def test_thresholded_mask_upsample_rows_kernel_is_bitwise_the_flat_kernel(dev, h
     assert torch.equal(m_rows.bool(), out > thr)
     ref = F.interpolate(x[None].cpu(), size=(H, W), mode="bilinear")[0]
     assert torch.equal(out.cpu(), ref)                                                               # ATen-exact arithmetic
+
+
+def test_attention_x3_two_query_tiles_per_wave_is_bitwise_the_product_kernel(dev, tmp_path):
+    """Developer variant ZH_ATTN_QT=2 (round 5: a wave owns two 32-query tiles and every K / V fragment read feeds both; measured a tie
+    with the product kernel at the headline's shape, profiles/NOTES.md): the same arithmetic per query, so the outputs agree bit for bit —
+    ragged T (tile B of the last wave beyond Tq), several heads and images.  The switch is read once per process: the variant runs in a
+    child process on the tensors this one wrote."""
+    import os, subprocess, sys
+    from zutis_amd import ops
+    from zutis_amd.ops import Act
+    B, H, dh, T = 3, 4, 64, 333
+    D = H * dh
+    x = [_randn((B * T, D), 900 + i, 1.0).to(dev) for i in range(3)]
+    torch.save([t.cpu() for t in x], tmp_path / "qkv.pt")
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})\n"
+        "from zutis_amd import ops\nfrom zutis_amd.ops import Act\n"
+        f"B, H, dh, T, D = {B}, {H}, {dh}, {T}, {D}\n"
+        "dev = torch.device('cuda:0')\n"
+        f"x = [t.to(dev) for t in torch.load({repr(str(tmp_path / 'qkv.pt'))})]\n"
+        "def pair(t):\n    a = Act.empty(tuple(t.shape), True, dev); ops.cast_f16(t, a, t.shape[0], t.shape[1]); return a\n"
+        "q, k, v = (pair(t) for t in x)\no = Act.empty((B * T, D), True, dev)\n"
+        "ops.attention(q, k, v, o, batch=B, heads=H, Tq=T, Tk=T, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=T * D, strideK=T * D, strideV=T * D, strideO=T * D, x3=True)\n"
+        f"torch.save(o.t.cpu(), {repr(str(tmp_path / 'o.pt'))})\n")
+
+    def pair(t):
+        a = Act.empty(tuple(t.shape), True, dev)
+        ops.cast_f16(t, a, t.shape[0], t.shape[1])
+        return a
+    q, k, v = (pair(t) for t in x)
+    o = Act.empty((B * T, D), True, dev)
+    ops.attention(q, k, v, o, batch=B, heads=H, Tq=T, Tk=T, head_dim=dh, ldq=D, ldk=D, ldv=D, ldo=D, strideQ=T * D, strideK=T * D, strideV=T * D,
+                  strideO=T * D, x3=True)
+    r = subprocess.run([sys.executable, str(script)], env={**os.environ, "ZH_ATTN_QT": "2"}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert torch.equal(torch.load(tmp_path / "o.pt"), o.t.cpu())

@@ -17,8 +17,9 @@ EXTRA_FLAGS = {"bilateral.hip": ["-ffp-contract=off"]}
 NO_SCRATCH = {"gemm.hip", "gemm_x3.hip", "attention.hip"}
 MAX_SCRATCH = int(os.environ.get("ZH_BUILD_MAX_SCRATCH", "0"))    # bytes per lane tolerated: the MFMA loops must not spill (developer builds may raise it)
 # waves per SIMD the design of a kernel relies on (mangled-name substring -> minimum), checked against the compiler's remarks
-MIN_OCCUPANCY = {"attn_f16_kernelILi64ELi4ELi1ELi0E": 3, "attn_f16_kernelILi64ELi4ELi0ELi0E": 3, "attn_f16_kernelILi64ELi4ELi1ELi1E": 2,
-                 "attn_f16_kernelILi96ELi4ELi1ELi0E": 2, "attn_f16_kernelILi96ELi4ELi0ELi0E": 2, "attn_f16_kernelILi96ELi4ELi1ELi1E": 2}
+MIN_OCCUPANCY = {"attn_f16_kernelILi64ELi4ELi1ELi0ELi1E": 3, "attn_f16_kernelILi64ELi4ELi0ELi0ELi1E": 3, "attn_f16_kernelILi64ELi4ELi1ELi1ELi1E": 2,
+                 "attn_f16_kernelILi96ELi4ELi1ELi0ELi1E": 2, "attn_f16_kernelILi96ELi4ELi0ELi0ELi1E": 2, "attn_f16_kernelILi96ELi4ELi1ELi1ELi1E": 2,
+                 "attn_f16_kernelILi64ELi4ELi1ELi0ELi2E": 2}
 SOURCES = ["capi.hip", "gemm.hip", "gemm_x3.hip", "attention.hip", "norm.hip", "resample.hip", "metrics.hip", "instance.hip", "bilateral.hip", "retrieval.hip", "text.hip", "plan.hip"]
 
 

@@ -16,6 +16,7 @@
 // LDS strides: K rows dh+8 halves (conflict-free ds_read_b128), V rows 96 halves (4 consecutive rows cover
 // disjoint 16-dword bank ranges for the transposed read).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 struct AttnArgs {
@@ -92,9 +93,13 @@ __device__ __forceinline__ float zh_xor32_sum(float x) {
 #ifndef ZH_ATTN_ABL
 #define ZH_ATTN_ABL 0      // developer ablations (tools/attn_ablate.py): 1 no exp, 2 no P.V, 4 no K.Q^T, 8 no tile traffic and no
 #endif                     // barriers, 16 no barriers, 32 barriers only, 64 no LDS stores.  0 in the product build.
-template <int DH, int NWAVE, int X3, int PIPE>
+// QT = 2 (round 5, developer A/B behind ZH_ATTN_QT=2; split-pair dh = 64 only): a wave owns TWO 32-query tiles.  Every K / V fragment
+// read from LDS feeds both tiles' MFMAs and a key tile's loads / stores / barrier serve 256 queries per workgroup: the kernel is
+// bound by the SIMD's instruction issue (profiles/NOTES.md round 3), and those are the instructions that do not scale with the scores.
+template <int DH, int NWAVE, int X3, int PIPE, int QT = 1>
 __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_f16_kernel(AttnArgs p) {
   static_assert(!PIPE || X3, "the pipelined loop exists for the split-pair kernels");
+  static_assert(QT == 1 || (QT == 2 && X3 && !PIPE && DH == 64), "two query tiles per wave: split-pair dh = 64, plain loop");
   constexpr int NT = 64 * NWAVE;
   constexpr int KS = DH + 8;          // K row stride (halves)
   constexpr int NKS = DH / 16;        // k-steps of QK^T
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   const int qbs = item - group * per_group;
   const int qb = qbs / p.ksplit, ks = qbs - qb * p.ksplit;
   const int head = group % p.H, img = group / p.H;
-  const int q0 = qb * (32 * NWAVE) + wave * 32;
+  const int q0 = qb * (32 * NWAVE * QT) + wave * (32 * QT);     // first query of this wave (its tile a starts at q0 + 32 a)
   const int ql = lane & 31, hh = lane >> 5;
   const long hoff = (long)head * DH;
 
@@ -149,25 +154,30 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   const half_t* V = p.V + (long)img * p.sV + hoff;
 
   // Q fragments (B operand: col = query, k = d)
-  half8_t qf[NKS], qfl[X3 ? NKS : 1];
-  {
-    int qr = q0 + ql;
+  half8_t qf[QT][NKS], qfl[QT][X3 ? NKS : 1];
+#pragma unroll
+  for (int a = 0; a < QT; ++a) {
+    int qr = q0 + 32 * a + ql;
     qr = qr < p.Tq ? qr : p.Tq - 1;
     const half_t* qp = Q + (long)qr * p.ldq + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const half8_t*)(qp + 16 * ks);
+    for (int ks = 0; ks < NKS; ++ks) qf[a][ks] = *(const half8_t*)(qp + 16 * ks);
     if (X3) {
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) qfl[ks] = *(const half8_t*)(qp + p.planeQ + 16 * ks);
+      for (int ks = 0; ks < NKS; ++ks) qfl[a][ks] = *(const half8_t*)(qp + p.planeQ + 16 * ks);
     }
   }
 
-  f32x16 oacc[NDT];
+  f32x16 oacc[QT][NDT];
 #pragma unroll
-  for (int d = 0; d < NDT; ++d)
+  for (int a = 0; a < QT; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-  float m_run = -INFINITY;
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[a][d][r] = 0.f;
+  float m_run[QT];
+#pragma unroll
+  for (int a = 0; a < QT; ++a) m_run[a] = -INFINITY;
   // Row sums of P ride the MFMA pipe: one extra "d tile" whose V^T operand is all ones accumulates sum_k P[k][q] in every row
   // of lacc (32 v_add_f32 per key tile leave the VALU, which is the bound; the sum is of the SAME rounded P the numerator uses).
   // Split-pair kernels (X3) keep the row sum on the VALU instead: they are MFMA-bound (three products per score and per P.V
@@ -177,7 +187,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   f32x16 lacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
-  float l_run = 0.f;
+  float l_run[QT];
+#pragma unroll
+  for (int a = 0; a < QT; ++a) l_run[a] = 0.f;
   half8_t ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (half_t)1.0f;
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
 
   int ntiles = (max(key_end - key0, 0) + KTT - 1) / KTT;
   if (p.causal) {                                           // key tiles entirely above this block's last query are skipped
-    const int qlast = min(p.Tq, (qb + 1) * (32 * NWAVE)) - 1;
+    const int qlast = min(p.Tq, (qb + 1) * (32 * NWAVE * QT)) - 1;
     ntiles = min(ntiles, qlast / KTT + 1);
   }
   const int qidx = q0 + ql;
@@ -269,25 +281,31 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
 #endif
 
   // ---- S^T(t) = K(t) Q^T from K buffer t & 1 (NU 32-key slot tiles)
-  auto qk = [&](int t, f32x16 (&s)[NU]) {
+  auto qk = [&](int t, f32x16 (&s)[QT][NU]) {
     const half_t* sK = sKb[t & 1];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+      for (int a = 0; a < QT; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[a][u][r] = 0.f;
       const half_t* kp = sK + (32 * u + krow) * KS + 8 * hh;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         half8_t kf = *(const half8_t*)(kp + 16 * ks);
+        half8_t kl;
+        if (X3) kl = *(const half8_t*)(sKl[t & 1] + (32 * u + krow) * KS + 8 * hh + 16 * ks);
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {                   // (QT = 2: the K fragments just read serve both query tiles)
 #if ZH_ATTN_ABL & 4
-        s[u][ks] += (float)kf[0] * (float)qf[ks][0];
+          s[a][u][ks] += (float)kf[0] * (float)qf[a][ks][0];
 #else
-        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[u], 0, 0, 0);
+          s[a][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[a][ks], s[a][u], 0, 0, 0);
 #endif
-        if (X3) {
-          half8_t kl = *(const half8_t*)(sKl[t & 1] + (32 * u + krow) * KS + 8 * hh + 16 * ks);
-          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf[ks], s[u], 0, 0, 0);
-          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qfl[ks], s[u], 0, 0, 0);
+          if (X3) {
+            s[a][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf[a][ks], s[a][u], 0, 0, 0);
+            s[a][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qfl[a][ks], s[a][u], 0, 0, 0);
+          }
         }
       }
     }
@@ -298,7 +316,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   // ---- online softmax of tile t: scores -> P (fp16, or a split pair), accumulators rescaled when the reference point moves
   // (MASKED = false: the caller knows the tile is full and the attention not causal — no branch splits the block, so the
   //  pipelined loop's K.Q^T MFMAs of the next tile can be scheduled in among these instructions)
-  auto softmax = [&](int t, f32x16 (&s)[NU], PFrag& P, auto masked) {
+  auto softmax = [&](int t, f32x16 (&s)[NU], PFrag& P, auto masked, int a = 0) {
     constexpr bool MASKED = decltype(masked)::value;
     const int kbase = key0 + t * KTT;
     // register r of slot tile u holds key kbase + 32u + 16(r>>3) + 8*hh + (r&7)
@@ -331,9 +349,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     // Lazy: the reference point only moves when the tile's max exceeds it by more than 2^8 (any fixed reference gives the same
     // softmax; both key halves of a query see the same mx and m_run, so they decide alike)
     const float m_cand = mx * p.scale_log2;
-    const float m_new = m_cand > m_run + ZH_ATTN_LAZY_LOG2 ? m_cand : m_run;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    const float m_new = m_cand > m_run[a] + ZH_ATTN_LAZY_LOG2 ? m_cand : m_run[a];
+    const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
+    m_run[a] = m_new;
     float lsum2[2] = {0.f, 0.f};                             // scalar adds: packed fp32 VALU is an anti-lever beside MFMAs (v_pk_add_f32 ~ +13 issue cycles)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
@@ -364,28 +382,27 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[a][d][r] *= alpha;
       if (!X3) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
       }
     }
-    if (X3) l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
+    if (X3) l_run[a] = l_run[a] * alpha + (lsum2[0] + lsum2[1]);
     ZH_STAMP(3);
   };
   // ---- O^T += V(t)^T P^T from V buffer t & 1
-  auto pv = [&](int t, const PFrag& P) {
+  auto pv = [&](int t, const PFrag (&P)[QT]) {
     const half_t* sV = sVb[t & 1];
 #if ZH_ATTN_ABL & 2
-    oacc[0][0] += (float)__builtin_bit_cast(half8_t, P.hi[0][0])[0] + (float)__builtin_bit_cast(half8_t, P.hi[NU - 1][1])[7];
-    lacc[0] += 1.0f; l_run += 1.0f;
+    oacc[0][0][0] += (float)__builtin_bit_cast(half8_t, P[0].hi[0][0])[0] + (float)__builtin_bit_cast(half8_t, P[0].hi[NU - 1][1])[7];
+    lacc[0] += 1.0f; l_run[0] += 1.0f;
 #else
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const half8_t pf = __builtin_bit_cast(half8_t, P.hi[u][ks]);
-        if (!X3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
+        if (!X3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, __builtin_bit_cast(half8_t, P[0].hi[u][ks]), lacc, 0, 0, 0);
         const half_t* vp = sV + (32 * u + 16 * ks + tr_row) * VS + tr_col;
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
@@ -394,16 +411,22 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
           half8_t vf;
           __builtin_memcpy(&vf, &lo, 8);
           __builtin_memcpy(((char*)&vf) + 8, &hi, 8);
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+          half8_t vl;
           if (X3) {
             const half_t* vq = sVl[t & 1] + (32 * u + 16 * ks + tr_row) * VS + tr_col;
             fp16x4 llo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(vq + 32 * d));
             fp16x4 lhi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(vq + 32 * d + 4 * VS));
-            half8_t vl;
             __builtin_memcpy(&vl, &llo, 8);
             __builtin_memcpy(((char*)&vl) + 8, &lhi, 8);
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf, oacc[d], 0, 0, 0);
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, __builtin_bit_cast(half8_t, P.lo[u][ks]), oacc[d], 0, 0, 0);
+          }
+#pragma unroll
+          for (int a = 0; a < QT; ++a) {                 // (QT = 2: the V fragments just read serve both query tiles)
+            const half8_t pf = __builtin_bit_cast(half8_t, P[a].hi[u][ks]);
+            oacc[a][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[a][d], 0, 0, 0);
+            if (X3) {
+              oacc[a][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf, oacc[a][d], 0, 0, 0);
+              oacc[a][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, __builtin_bit_cast(half8_t, P[a].lo[u][ks]), oacc[a][d], 0, 0, 0);
+            }
           }
         }
       }
@@ -426,19 +449,19 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     store_v(0, ra);
     if (ntiles > 1) { load_k(key0 + KTT, ra); store_k(1, ra); }
     __syncthreads();
-    f32x16 sA[NU], sB[NU];
-    PFrag P;
+    f32x16 sA[QT][NU], sB[QT][NU];
+    PFrag P[QT];
     if (active) qk(0, sA);
     __syncthreads();                               // step 0 stores K(2) over K(0): every wave's reads of K(0) come first
     // one step: tile t has a successor; par = t & 1 as a compile-time constant
-    auto step = [&](int t, auto par, f32x16 (&cur)[NU], f32x16 (&nxt)[NU]) {
+    auto step = [&](int t, auto par, f32x16 (&cur)[QT][NU], f32x16 (&nxt)[QT][NU]) {
       constexpr int PAR = decltype(par)::value;
       if (t + 2 < ntiles) load_k(key0 + (t + 2) * KTT, ra);
       load_v(key0 + (t + 1) * KTT, ra);
       ZH_STAMP(0);
       if (active) {
         qk(PAR ^ 1, nxt);
-        softmax(t, cur, P, std::false_type{});
+        softmax(t, cur[0], P[0], std::false_type{});
         pv(PAR, P);
       }
       if (t + 2 < ntiles) store_k(PAR, ra);
@@ -454,9 +477,9 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     }
     if (t + 1 < ntiles) {                         // two tiles left
       step(t, std::integral_constant<int, 0>{}, sA, sB);
-      if (active) { softmax(t + 1, sB, P, std::true_type{}); pv(1, P); }
+      if (active) { softmax(t + 1, sB[0], P[0], std::true_type{}); pv(1, P); }
     } else if (active) {                          // one tile left
-      softmax(t, sA, P, std::true_type{});
+      softmax(t, sA[0], P[0], std::true_type{});
       pv(0, P);
     }
   } else
@@ -469,11 +492,12 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   __syncthreads();
   auto compute = [&](int t) {
     if (active) {
-      f32x16 s[NU];
-      PFrag P;
+      f32x16 s[QT][NU];
+      PFrag P[QT];
       qk(t, s);
       ZH_STAMP(1);
-      softmax(t, s, P, std::true_type{});
+#pragma unroll
+      for (int a = 0; a < QT; ++a) softmax(t, s[a], P[a], std::true_type{}, a);   // (a tile beyond Tq computes on a clamped query row and stores nothing)
       pv(t, P);
     }
   };
@@ -497,7 +521,7 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) load_tile((t + 1) * KTT, ra);
     compute(t & 1);
-    if (t + 1 < ntiles) m_run += 1e-30f * (float)ra.k[0][0] * (float)ra.v[NLD - 1][7];
+    if (t + 1 < ntiles) m_run[0] += 1e-30f * (float)ra.k[0][0] * (float)ra.v[NLD - 1][7];
     __syncthreads();
   }
 #else
@@ -533,8 +557,10 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
 
   // f16: every row of lacc holds the full row sum of this lane's query (the MFMA already summed both key halves);
   // split pairs: this lane's half of the keys + the other half's (lane ^ 32)
-  const float l_row = X3 ? zh_xor32_sum(l_run) : lacc[0];
-  const int qr = q0 + ql;
+#pragma unroll
+  for (int a = 0; a < QT; ++a) {
+  const float l_row = X3 ? zh_xor32_sum(l_run[a]) : lacc[0];
+  const int qr = q0 + 32 * a + ql;
   if (p.ksplit > 1) {                                   // partial result of this key chunk: unnormalised O, running max, row sum
     if (qr < p.Tq) {
       float* po = p.part_o + (((long)ks * (p.groups / p.H) + img) * p.Tq + qr) * ((long)p.H * DH) + hoff + 4 * hh;
@@ -542,14 +568,14 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
       for (int d = 0; d < NDT; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          *(f32x4*)(po + 32 * d + 8 * g) = (f32x4){oacc[d][4 * g], oacc[d][4 * g + 1], oacc[d][4 * g + 2], oacc[d][4 * g + 3]};
+          *(f32x4*)(po + 32 * d + 8 * g) = (f32x4){oacc[a][d][4 * g], oacc[a][d][4 * g + 1], oacc[a][d][4 * g + 2], oacc[a][d][4 * g + 3]};
       if (hh == 0) {
         const long mi = ((long)ks * p.groups + group) * p.Tq + qr;
-        p.part_m[mi] = m_run;
+        p.part_m[mi] = m_run[a];
         p.part_l[mi] = l_row;
       }
     }
-    return;
+    continue;
   }
   const float inv = 1.0f / l_row;
   if (qr < p.Tq) {
@@ -558,9 +584,10 @@ __global__ __launch_bounds__(64 * NWAVE, X3 ? 2 : (DH == 64 ? 3 : 2)) void attn_
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 o = {oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
+        const f32x4 o = {oacc[a][d][4 * g] * inv, oacc[a][d][4 * g + 1] * inv, oacc[a][d][4 * g + 2] * inv, oacc[a][d][4 * g + 3] * inv};
         zh_store_h4(op + 32 * d + 8 * g, p.planeO, o);
       }
+  }
   }
 #ifdef ZH_ATTN_STAMP
   if (p.stamp && lane == 0) {
@@ -623,9 +650,12 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   p.planeQ = planeQ; p.planeK = planeK; p.planeV = planeV; p.planeO = planeO;
   // 128-query (4-wave) blocks: each K/V tile is shared four ways.  A 64-query (2-wave) variant was measured slower on
   // every shape of the model (encoder 301 vs 423 TF, cross-attention 230 vs 397 TF) and was dropped.
-  p.nqb = zh_cdiv(Tq, 128);
-  p.groups = heads * batch;
   const bool x3 = planeQ != 0;
+  // developer A/B (round 5): ZH_ATTN_QT=2 gives the split-pair dh = 64 kernel two 32-query tiles per wave (256 queries per workgroup)
+  static const int qt_env = [] { const char* e = getenv("ZH_ATTN_QT"); return e ? atoi(e) : 1; }();
+  const bool qt2 = qt_env == 2 && x3 && head_dim == 64 && !causal && ksplit <= 1;
+  p.nqb = zh_cdiv(Tq, qt2 ? 256 : 128);
+  p.groups = heads * batch;
   p.ksplit = 1; p.kchunk = 0; p.part_o = p.part_m = p.part_l = nullptr;
 #ifdef ZH_ATTN_STAMP
   p.stamp = g_attn_stamp;
@@ -653,7 +683,8 @@ static int attention_launch(const void* Q, long ldq, long strideQ, const void* K
   // dh = 64 when the grid needs no more rounds of the chip at two workgroups per CU than at three.
   bool pipe = x3 && (head_dim == 96 || zh_cdiv(nblk, 512L) <= zh_cdiv(nblk, 768L));
   if (ZH_ATTN_PIPE >= 0) pipe = x3 && ZH_ATTN_PIPE;
-  if (head_dim == 64) {
+  if (qt2) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1, 0, 2>), grid, dim3(256), 0, stream, p);
+  else if (head_dim == 64) {
     if (x3 && pipe) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1, 1>), grid, dim3(256), 0, stream, p);
     else if (x3) hipLaunchKernelGGL((attn_f16_kernel<64, 4, 1, 0>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_f16_kernel<64, 4, 0, 0>), grid, dim3(256), 0, stream, p);
