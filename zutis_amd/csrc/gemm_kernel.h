@@ -764,7 +764,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     constexpr int PR1 = (TM * 16) % PR0 == 0 ? PR0 : (TM * 16 <= 48 ? TM * 16 : 16);      // rows per pass (divides the wave tile)
     // PERS: the slabs share what the next tile's prologue leaves of the LDS — halve the pass until they fit
     constexpr int PR = !PERS ? PR1 : (NW * PR1 * RS <= SLAB_CAP ? PR1 : (NW * (PR1 / 2) * RS <= SLAB_CAP ? PR1 / 2 : PR1 / 4));
-    static_assert(PR >= 8 && (TM * 16) % PR == 0 && NW * PR * RS <= SLAB_CAP, "epilogue slabs do not fit beside the next tile's prologue");
+    static_assert(PR >= 16 && PR % 16 == 0 && (TM * 16) % PR == 0 && NW * PR * RS <= SLAB_CAP, "epilogue slabs do not fit beside the next tile's prologue (a pass is whole 16-row sub-tiles)");
     constexpr int MTP = PR / 16;
     constexpr int CPRW = TN * 16 * ESZ / 16;                // 16-B chunks per row
     constexpr int NIT = PR * CPRW / 64;
