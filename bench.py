@@ -668,6 +668,30 @@ def solver_object(dev, reps=20):
     return solver
 
 
+def pseudo_label_object(dev, precision="exact", B=4, reps=5):
+    """The pseudo-label path north_star names (SelfMask, networks/selfmask + utils/bilateral_solver.py, as datasets/*.py
+    generate_pseudo_masks drives them): DINO ViT-S/8 SelfMask at its working shape 512x683 (T = 5505 tokens) -> query selection ->
+    bilateral solver -> > 0.5 -> nearest resize to 480x640, `B` images per call, device side (the RLE JSON files are host work).
+    Parity of this path is held by tests/test_e2e_gpu.py::test_selfmask_* (reference goldens + the oracle at 512x683) and
+    tests/test_bilateral_gpu.py; synthetic noise images give the solver one lattice vertex per pixel (17x a natural image's)."""
+    from zutis_amd import detgen, pseudo_masks
+    from zutis_amd.engine import SelfMaskEngine
+    H, W = 512, 683
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()}, precision=precision)
+    x = torch.from_numpy(detgen.images(B, H, W, seed=7)).to(dev)
+    for _ in range(2):
+        pseudo_masks.pseudo_masks_batch(eng, x, [(480, 640)] * B, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pseudo_masks.pseudo_masks_batch(eng, x, [(480, 640)] * B, True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    eng._bufs.clear()
+    return {"what": f"SelfMask (DINO ViT-S/8 @{H}x{W}, T = 5505) + bilateral solver + threshold + nearest resize, {B} images per call, device side",
+            "value": round(B / dt, 1), "unit": "images/s", "ms_per_call": round(dt * 1e3, 2), "batch": B, "precision": precision, "calls": reps}
+
+
 def c4_object(P, cfg, dev, precision, steps=12, warmup=4, n_lanes=3, cpu_images=1, cpu_threads=16):
     """BASELINE config 4 on one GPU, bounded: ViT-B/16 @518 px, 920 classes, 8 images per step (the reference's own batch for this
     config, configs/imagenet_s919_*.yaml), three launch plans in flight exactly as the headline — value, roofline fraction of the
@@ -1094,7 +1118,7 @@ def main():
         batch1 = batch1_object(args.precision, dev)
     # ---- the other BASELINE configs, bounded, in the driver-run line (N = 1, default workload only): c4 (518 px / 920 classes / 8 per step),
     # c5 (ViT-L/14@336 embedding extraction, one 256-image step, at the reference's fp16 arithmetic class) and the bilateral solver
-    c4o = c5o = solvero = None
+    c4o = c5o = solvero = pseudoo = None
     if rank == 0 and world == 1 and not args.no_configs and args.workload == "c2" and (S, n) == (336, 81):
         for e in engines.values():
             e._bufs.clear()
@@ -1106,6 +1130,7 @@ def main():
         c5o = c5_object(dev, "fast", cpu_images=ncpu, cpu_threads=args.cpu_threads)
         torch.cuda.empty_cache()
         solvero = solver_object(dev)
+        pseudoo = pseudo_label_object(dev, args.precision)
     if rank == 0:
         total_images = world * B * args.steps
         line = {
@@ -1134,6 +1159,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             **({"batch1": batch1} if batch1 else {}),
             **({"c4": c4o} if c4o else {}), **({"c5": c5o} if c5o else {}), **({"bilateral_solver": solvero} if solvero else {}),
+            **({"pseudo_labels": pseudoo} if pseudoo else {}),
             **({"torch_gpu_baseline": torch_gpu} if torch_gpu else {}),
             **({"io_inclusive": io_rates} if io_rates else {}),
         }
@@ -1171,6 +1197,8 @@ def main():
         if solvero:
             sm["solver_ms"] = [solvero["batch1"]["ms_per_image"], solvero["batch8"]["ms_per_image"]]
             sm["solver_frac"] = [solvero["batch1"]["frac"], solvero["batch8"]["frac"]]
+        if pseudoo:
+            sm["selfmask_solver_ips"] = pseudoo["value"]
         if io_rates:
             sm["io"] = [io_rates["d2h"]["value"], io_rates["h2d_d2h"]["value"]]
         line["summary"] = sm
