@@ -810,6 +810,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     char* slab = (char*)smem + SLAB_OFF + wave * (PR * RS);
 #pragma clang loop unroll(full)
     for (int pass = 0; pass < TM / MTP; ++pass) {
+#ifdef ZH_ABL_SKIP_EPI        // developer ablation (timing only, results are garbage): a persistent tile that has a successor skips its slab passes and stores
+      if (more) break;
+#endif
 #pragma clang loop unroll(full)
       for (int nt = 0; nt < TN; ++nt) {
         const f32x4 bv = bvs[nt];
