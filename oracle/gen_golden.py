@@ -216,6 +216,13 @@ def gen_bilateral():
         d[f"{tag}_soft"], d[f"{tag}_binary"] = soft, binary
         d[f"{tag}_cg_iters"] = its[-1]
         print("bilateral", tag, "V", grid.nvertices, "nnz", d[f"{tag}_nnz"], "cg iters", its[-1], "fg", (soft > 0.5).mean())
+    # EMPTY target (no foreground found by the pseudo-labeller): b = splat(0) = 0, and scipy's cg returns zeros without iterating
+    # (`if bnrm2 == 0: return postprocess(b), 0`); the post-processing then finds no component and falls back to the all-True mask
+    # (bilateral_solver.py:188-193)
+    rgb = detgen.selfmask_like_rgb(96, 128, seed=3)
+    soft, binary = rb.bilateral_solver_output(Image.fromarray(rgb), np.zeros((96, 128), np.uint8))
+    d["z_soft"], d["z_binary"], d["z_cg_iters"] = soft, binary, its[-1]
+    print("bilateral empty target: soft max", float(np.abs(soft).max()), "finite", bool(np.isfinite(soft).all()), "binary all-True", bool(binary.all()), "cg iters", its[-1])
     # de-normalise step (utils/utils.py:261-273) on values engineered to land on integer boundaries
     from utils.utils import convert_tensor_to_pil_image
     x = torch.from_numpy(detgen.det_normal("denorm", (3, 40, 56)))

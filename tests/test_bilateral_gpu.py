@@ -62,6 +62,30 @@ def test_dropin_bilateral_solver_output(dev, golden_dir):
     assert np.array_equal(binary, g["c_binary"])
 
 
+def test_solver_empty_target_is_zeros_like_the_reference(dev, golden_dir):
+    """An all-zero target (no foreground from the pseudo-labeller): b = 0, the reference's scipy cg returns zeros without iterating and its
+    post-processing falls back to the all-True mask (golden `z_*`, generated from the real reference).  The device loop must not form
+    0 / 0: soft output exactly zero, 0 iterations, alone and as one image of a batch whose other images solve normally (bitwise)."""
+    from zutis_amd import ops, detgen
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zutis_amd", "dropin")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    from PIL import Image
+    from utils.bilateral_solver import bilateral_solver_output
+    g = np.load(f"{golden_dir}/bilateral.npz")
+    rgb = detgen.selfmask_like_rgb(96, 128, seed=3)
+    zero = np.zeros((96, 128), np.uint8)
+    soft, stats = ops.bilateral_solve(torch.from_numpy(rgb).to(dev), torch.from_numpy(zero).to(dev))
+    assert int(stats.cpu().numpy().reshape(-1)[1]) == 0 and np.array_equal(soft.cpu().numpy(), g["z_soft"])
+    s2, b2 = bilateral_solver_output(Image.fromarray(rgb), zero)
+    assert np.array_equal(s2, g["z_soft"]) and np.array_equal(b2, g["z_binary"]) and b2.all()
+    # in a batch: image 0 empty, image 1 the golden "a" case (same picture)
+    tg = np.stack([zero, g["a_target"]])
+    sb, st = ops.bilateral_solve(torch.from_numpy(np.stack([rgb, rgb])).to(dev), torch.from_numpy(tg).to(dev))
+    sb = sb.cpu().numpy()
+    assert not sb[0].any() and np.abs(sb[1] - g["a_soft"]).max() < 1e-9 and [int(v) for v in st.cpu().numpy()[:, 1]] == [0, 25]
+
+
 def test_solver_vs_oracle_selfmask_size(dev):
     """Full SelfMask-style size (512x683, V ~ 10^4-10^5): round trip against the oracle + float target path."""
     from zutis_amd import ops, detgen

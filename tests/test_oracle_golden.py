@@ -136,6 +136,10 @@ def test_bilateral_oracle_matches_reference(golden_dir):
         soft = xhat.reshape(h, w)
         assert np.abs(soft - g[f"{tag}_soft"]).max() < 1e-12
         assert np.array_equal(B.postprocess(soft), g[f"{tag}_binary"])
+    # the EMPTY target (the pseudo-labeller found nothing): the reference's scipy cg returns zeros without iterating (`bnrm2 == 0`) and
+    # the post-processing falls back to the all-True mask (bilateral_solver.py:188-193) — not 0 / 0
+    soft0, bin0 = B.bilateral_solver_output(detgen.selfmask_like_rgb(96, 128, seed=3), np.zeros((96, 128), np.uint8))
+    assert int(g["z_cg_iters"]) == 0 and np.array_equal(soft0, g["z_soft"]) and not soft0.any() and np.array_equal(bin0, g["z_binary"]) and bin0.all()
     x = detgen.det_normal("denorm", (3, 40, 56))
     x[0, 0, :16] = ((np.arange(16) * 16 / 255.0 - 0.485) / 0.229).astype(np.float32)
     assert np.array_equal(B.denormalize_to_u8(x), g["denorm_u8"])

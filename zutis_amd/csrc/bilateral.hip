@@ -501,7 +501,9 @@ __global__ __launch_bounds__(256) void cg_step_kernel(CgPtrs c0, int it, int las
     double gamma = 0.0, delta = 0.0, rr = 0.0;
     for (int i = threadIdx.x; i < nb; i += 256) { gamma += pin[i]; delta += pin[c.nblocks + i]; rr += pin[2 * c.nblocks + i]; }
     block_sum3(gamma, delta, rr, red);
-    if (sqrt(rr) < atol) {                                                  // SciPy's test at the top of iteration `it`
+    // SciPy's test at the top of iteration `it`; and its `if bnrm2 == 0: return b` (atol = rtol ||b|| = 0: an EMPTY target — the
+    // pseudo-labeller found nothing — solves to zeros without iterating; x0 = b / w is already 0 there, where the loop would form 0 / 0)
+    if (sqrt(rr) < atol || atol == 0.0) {
       if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
       return;
     }
