@@ -71,7 +71,7 @@ def live_pmc_traffic(extra_args, split: int, timeout_s=240):
         return None, "rocprofv3 not found"
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this run is itself being profiled: no nested rocprofv3 passes"
-    tot, cnt = {}, {}
+    tot, cnt, seq = {}, {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="zh_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
@@ -80,23 +80,31 @@ def live_pmc_traffic(extra_args, split: int, timeout_s=240):
         try:
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=timeout_s, check=True)
+            rows = []
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
                     k = r["Kernel_Name"]
                     if "gemm_f16_kernel" in k and k.rstrip().endswith(", %d>(GemmArgs)" % split) and r["Counter_Name"] == counter:
-                        tot[counter] = tot.get(counter, 0.0) + float(r["Counter_Value"])
-                        cnt[counter] = cnt.get(counter, 0) + 1
+                        rows.append((int(r.get("Dispatch_Id", len(rows))), float(r["Counter_Value"])))
+            rows.sort()
+            seq[counter] = [v for _, v in rows]
+            tot[counter] = sum(seq[counter])
+            cnt[counter] = len(rows)
         except Exception as e:                                   # profiler unavailable / refused: report, never fail the bench
             shutil.rmtree(d, ignore_errors=True)
-            return None, f"live rocprofv3 pass failed ({type(e).__name__})"
+            return None, f"live rocprofv3 pass failed ({type(e).__name__})", None
         shutil.rmtree(d, ignore_errors=True)
     if not cnt.get("FETCH_SIZE") or not cnt.get("WRITE_SIZE"):
-        return None, "no GEMM dispatches in the counter output"
+        return None, "no GEMM dispatches in the counter output", None
     fetch = tot["FETCH_SIZE"] / cnt["FETCH_SIZE"] * 1024.0
     write = tot["WRITE_SIZE"] / cnt["WRITE_SIZE"] * 1024.0
+    # per dispatch, in dispatch order (both passes run the same launch sequence): bytes = 2 * FETCH_SIZE + WRITE_SIZE
+    per = None
+    if cnt["FETCH_SIZE"] == cnt["WRITE_SIZE"]:
+        per = [(2.0 * a + b) * 1024.0 for a, b in zip(seq["FETCH_SIZE"], seq["WRITE_SIZE"])]
     return round(2.0 * fetch + write), (f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --inflight 1 --steps 2` run by this "
                                         f"bench ({cnt['FETCH_SIZE']} launches of gemm_f16_kernel<..., SPLIT={split}>): 2*FETCH_SIZE ({2 * fetch / 1e6:.1f} MB) + WRITE_SIZE "
-                                        f"({write / 1e6:.1f} MB) per launch, gfx950 correction")
+                                        f"({write / 1e6:.1f} MB) per launch, gfx950 correction"), per
 
 
 def gemm_roofline(ops, run_once, step_seconds):
@@ -148,6 +156,7 @@ def gemm_roofline(ops, run_once, step_seconds):
         if isinstance(w, tuple) and len(w) > 2:
             e = by.setdefault(w[2], [0, 0.0, 0.0])
             e[0] += 1; e[1] += w[0]; e[2] += a.elapsed_time(b) * 1e-3
+    gemm_roofline.last_launch_shapes = [(w[2], w[1]) for w, _, _ in prof[dom] if isinstance(w, tuple) and len(w) > 2]   # (shape, algorithmic bytes), launch order
     roof["by_shape"] = [{"MxNxK": "x".join(str(d) for d in (k[:3] if k[3] == 1 else k)), "launches": v[0], "avg_us": round(v[2] / v[0] * 1e6, 1),
                          "tflops": round(v[1] / v[2] / 1e12, 1), "frac": round(v[1] / v[2] / 1e12 / peak, 3),
                          "share_of_kernel_time": round(v[2] / tt, 3)}
@@ -1000,7 +1009,24 @@ def main():
         roof = gemm_roofline(ops, one_eager_step, elapsed / args.steps)
         if world == 1 and not args.no_live_traffic:
             extra = ["--precision", args.precision, "--batch", str(B), "--size", str(S), "--classes", str(n), "--no-io-rates"]
-            roof["traffic"], roof["traffic_source"] = live_pmc_traffic(extra, 1 if "SPLIT=1" in roof["kernel"] else (2 if "SPLIT=2" in roof["kernel"] else 0))
+            roof["traffic"], roof["traffic_source"], per = live_pmc_traffic(extra, 1 if "SPLIT=1" in roof["kernel"] else (2 if "SPLIT=2" in roof["kernel"] else 0))
+            shapes = getattr(gemm_roofline, "last_launch_shapes", None) or []
+            nls = len(shapes)
+            whole = (len(per) // nls - 1) if (per and nls) else 0
+            if whole >= 1:
+                # the counter passes ran whole steps of the same launch sequence and END with one: the last `whole` x n dispatches are
+                # aligned steps (the first forward also launches the once-per-weights decoder prefix: it is dropped with the remainder)
+                per = per[-whole * nls:]
+                acc = {}
+                for i, b in enumerate(per):
+                    k, algo = shapes[i % len(shapes)]
+                    e = acc.setdefault(k, [0, 0.0, algo])
+                    e[0] += 1; e[1] += b
+                for row in roof["by_shape"]:
+                    for k, (c, b, algo) in acc.items():
+                        if row["MxNxK"] == "x".join(str(d) for d in (k[:3] if k[3] == 1 else k)):
+                            row["traffic"] = round(b / c)
+                            row["traffic_over_algorithmic"] = round(b / c / algo, 2) if algo else None
         if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 2)
         roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r05_bench_%s_kernel_stats.csv"
