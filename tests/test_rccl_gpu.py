@@ -41,3 +41,23 @@ def test_rccl_one_rank_bench_c5_sharded_retrieval(dev):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["retrieval"]["equals_unsharded_on_rank0"] is True and d["retrieval"]["k"] == 16 and d["retrieval"]["categories"] == 919
     assert d["value"] > 0 and "NOT CONFIG 5" in d["config"]["workload"]
+
+
+def test_rccl_one_rank_bench_headline_force_dist(dev):
+    """The headline workload of `bench.py` on its N > 1 path with ONE rank (--force-dist): RCCL group, three lanes, the asynchronous
+    all-gather of the low-res logits per step on each lane's stream — the line carries the collective, and the timed lanes' outputs are
+    still bitwise an eager step."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**os.environ, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "6", "--warmup", "3", "--no-cpu-baseline",
+                        "--no-torch-gpu-baseline", "--no-second-precision", "--no-io-rates", "--no-batch1", "--no-configs", "--no-live-traffic"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["timed_outputs_checked"] is True and "all_gather" in d["config"]["collective"] and d["n_gpus"] == 1 and d["value"] > 0
