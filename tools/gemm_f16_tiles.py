@@ -2,7 +2,8 @@
 [variant A, variant B, ...] per shape, median and min), model-shaped operands (A ~ N(0,1), W ~ N(0, 0.03^2)), next to the vendor
 library (torch.mm -> hipBLASLt) on the same data; results checked against the auto tile bit for bit (same K order).
 
-    python tools/gemm_f16_tiles.py [rounds] [tile codes ...]      # default codes: 0 (auto) 6256
+    python tools/gemm_f16_tiles.py [rounds] [tile codes ...]      # default codes: 0 (auto) 256 192
+(profiles/r05_gemm_f16_tiles.txt was taken with codes 0 6256 6192: the 64-k two-slot loop of the round-5 experiment tree, since removed)
 """
 import os
 import sys
@@ -15,7 +16,7 @@ from zutis_amd import _lib, ops
 
 dev = torch.device("cuda:0")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
-codes = [int(a) for a in sys.argv[2:]] or [0, 6256]
+codes = [int(a) for a in sys.argv[2:]] or [0, 256, 192]
 L = _lib.load()
 shapes = [("qkv", 14144, 2304, 768, "f16", 0), ("out", 14144, 768, 768, "f32r", 0), ("fc", 14144, 3072, 768, "f16", 1),
           ("proj", 14144, 768, 3072, "f32r", 0), ("kv", 56448, 4608, 256, "f16", 0),
