@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   }
 
   ZH_PROBE(2);
-  // ---- epilogue: lane_e owns rows m = ..+(lane_e&15), 4 consecutive n at 4*(lane_e>>4).  ACT / VEC are template
+  // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4).  ACT / VEC are template
   // parameters: a runtime switch unrolled 32x blew the instruction cache (fc GEMM 1.4x slower in the model).
   // PERS: the epilogue sits inside the tile loop, and everything in it that depends on the lane alone is loop-invariant — hoisted in
   // front of the loop it would stay live through the K loop, which has no register to spare (the build spilled 300+ bytes).  An opaque
@@ -755,8 +755,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   if (VEC == 2) {
     // LDS-staged epilogue: the direct form stores 32-byte runs (4 lanes x 8 B) into 16 different 128-B lines per
     // instruction and measured 2.4 TB/s, fully exposed (34 % of a K=768 tile).  Here each wave transposes its tile through
-    // a private, conflict-free LDS slab (row stride +16 B) and writes whole rows with 16 B per lane_e (split pairs: the
-    // slab holds fp32 and each lane_e writes 8 B to the hi plane and 8 B to the lo plane).
+    // a private, conflict-free LDS slab (row stride +16 B) and writes whole rows with 16 B per lane (split pairs: the
+    // slab holds fp32 and each lane writes 8 B to the hi plane and 8 B to the lo plane).
     constexpr int ESZ = OUT_F16 ? 2 : 4;
     constexpr int RS = TN * 16 * ESZ + 16;                  // slab row stride (bytes)
     constexpr int PRW = (OUT_F16 ? 64 : 32) / (TN >= 8 ? 2 : 1);   // wide wave tiles: half the rows per pass (the pass's residual / slab registers)
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
     constexpr int NIT = PR * CPRW / 64;
     static_assert((PR * CPRW) % 64 == 0, "epilogue slab must divide into full wave reads");
     static_assert(SLAB_OFF + NW * PR * RS <= (int)sizeof(smem), "epilogue slabs exceed the LDS");
-    // the TN bias vectors of this lane_e's columns, requested together and ONCE (they used to be loaded per pass and sub-tile
+    // the TN bias vectors of this lane's columns, requested together and ONCE (they used to be loaded per pass and sub-tile
     // column behind a branch, each followed by a full wait: 16 exposed load latencies in the epilogue of a 256 x 256 tile)
     // (plain fp16 kernel, fp32 output, no activation — the residual GEMMs: the bias joins at store time instead, where a lane's
     //  chunk column never changes: ONE vector per lane for the whole epilogue instead of TN — (acc + bias) + residual either way)
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
         }
       }
       if constexpr (OUT == 2) {
-        // split pair: a lane_e takes 8 consecutive columns — one 16-byte store per plane instead of two 8-byte ones (the epilogue
+        // split pair: a lane takes 8 consecutive columns — one 16-byte store per plane instead of two 8-byte ones (the epilogue
         // of a 256 x 256 tile was 7.9 us of a 29.6-us K = 256 block, store-issue bound: tools/gemm_x3_stamp.py)
         constexpr int UPR = CPRW / 2, NIT2 = PR * UPR / 64;
         static_assert(CPRW % 2 == 0 && (PR * UPR) % 64 == 0, "split-pair epilogue: 8-column units must tile the pass");
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       } else {
         // fp32 output + residual (out_proj, c_proj, the decoder's output projections): the loop used to load each residual
         // chunk right where it is added — read slab, ~30 address instructions (an integer modulo among them), ONE load, wait, add,
-        // store — 24 exposed memory latencies per lane_e in a row: that, not bandwidth, was the 13-us epilogue of a 54-us out_proj
+        // store — 24 exposed memory latencies per lane in a row: that, not bandwidth, was the 13-us epilogue of a 54-us out_proj
         // block (tools/gemm_x3_stamp.py).  Now the pass's residual chunks are requested together, branch-free, before the slab is
         // read, and `m % res_rows` is skipped when the residual has a row of its own for every output row.
         f32x4 rv[NIT];
