@@ -204,7 +204,7 @@ def test_gemm_x3_row_periodic_table_before_rounding(dev, kind):
     assert float((got - ref).abs().max()) < tol, float((got - ref).abs().max())
 
 
-@pytest.mark.parametrize("tile", [64, 96, 192, 256, 512, 448, 3064, 32, 1288, 6496])
+@pytest.mark.parametrize("tile", [64, 96, 192, 256, 512, 448, 3064, 3066, 32, 1288, 6496, 6464, 7096, 7128])
 def test_gemm_x3_every_tile_variant(dev, tile):
     """Every x3 tile (128x64, 192x128, 256x128 on the 3-slot ring; 256x256 on the two-slot ring with the SGPR-base LDS-DMA and
     the in-place A lo fragments), forced through zh_dev_set_gemm_overrides, over K = 64 .. 1024 (every prologue / steady / tail
@@ -499,7 +499,7 @@ def test_split_weight_packs_fp16_valued_weights_as_one_plane(dev):
         ops.gemm_x3(_split_act(_randn((64, 128), 1), dev), ops.Act(W16.to(f16).unsqueeze(0).contiguous()), torch.empty((64, 96), dtype=f32, device=dev))
 
 
-@pytest.mark.parametrize("tile", [0, 64, 96, 192, 256, 512, 448, 3064, 5122, 5124, 4484, 1288, 32, 6496])
+@pytest.mark.parametrize("tile", [0, 64, 96, 192, 256, 512, 448, 3064, 5122, 5124, 4484, 1288, 32, 6496, 3066, 6464])
 def test_gemm_x2_is_bitwise_the_x3_kernel_on_fp16_valued_weights(dev, tile):
     """Every tile of the two-product kernel (incl. the three-slot big tiles and their two-slot A/B form) over every K phase,
     ragged M / N, bias + residual (f32 out), ReLU / QuickGELU split-pair out, fp16 out: bit-identical to the three-product

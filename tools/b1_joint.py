@@ -42,8 +42,8 @@ wrap(eng, "instance_candidates"); wrap(eng, "instance_nms_encode"); wrap(rle, "r
 import zutis_amd.engine as E
 marks = {}
 _th = E._to_host
-def to_host(t):
-    r = _th(t); marks["sync"] = time.perf_counter(); return r
+def to_host(t, *a):
+    r = _th(t, *a); marks["sync"] = time.perf_counter(); return r
 E._to_host = to_host
 _rp = torch.cuda.CUDAGraph.replay
 def replay(self):

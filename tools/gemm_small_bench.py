@@ -105,6 +105,20 @@ if __name__ == "__main__":
         bench(3200, 768, 2048, "dec l2/S", (0, 96, 1288), splits=(2, 4), out="f32")
         bench(19200, 256, 768, "ffn2.0", (0, 96, 1288, 192, 256), act=ops.ACT_RELU)
         bench(19200, 768, 256, "ffn2.2", (0, 96, 1288, 192, 256), out="f32")
+    if which == "k64":        # round 5: 64-k slices on a ring that keeps two or more slices in flight (3064 = 64 x 64 / four slots, 6464 = 128 x 64 / three)
+        bench(T, 2304, 768, "qkv", (96, 6496, 7096, 1288, 7128))
+        bench(T, 3072, 768, "fc", (1288, 7128, 7096), act=ops.ACT_QUICKGELU)
+        bench(T, 768, 3072, "proj/S4", (1288, 7128, 7096), splits=(4,), out="f32")
+        bench(3200, 768, 768, "dec o", (0, 96, 7096), out="f32", resid=True)
+        bench(3200, 2304, 768, "dec qkv", (0, 7096, 7128))
+        bench(3200, 768, 768, "dec q", (0, 96, 7096))
+        if len(sys.argv) > 2: sys.exit(0)
+        bench(T, 1536, 768, "n1536", (64, 6464, 96, 6496, 1288))          # beside their 32-k forms (3066 = 64 x 64 / six slots, 64 = 128 x 64 / three) and the two-slot 64-k tile (6496)
+        bench(T, 768, 768, "out", (3066, 3064), out="f32", resid=True)
+        bench(T, 768, 768, "out pair", (3066, 3064))
+        bench(442, 2304, 768, "qkv336", (3066, 3064, 6496))
+        bench(442, 3072, 768, "fc336", (3066, 3064, 6496), act=ops.ACT_QUICKGELU)
+        bench(T, 768, 3072, "proj/S4", (1288, 6464, 6496), splits=(4,), out="f32")
     if which == "pmc64":      # counters of the 32-k (96) and 64-k (6496) forms of the one-image QKV tile
         def t(fn, n=12):
             for i in range(n): fn(i)

@@ -95,6 +95,25 @@ __device__ __forceinline__ void wait_stages_barrier(int c) {
   }
 }
 
+// Split-pair tiles that take 64-k slices on MORE than two slots (every other (tile, ring depth) pair below the big tiles is on 32-k
+// slices; two slots always mean 64-k).  Round 5: with ONE slice of prefetch every slice pays the whole load latency (the K loop of the
+// two-slot form ran 1.5 us per slice against 0.66 us of stream time); these keep two or more slices in flight.
+// ... and the tiles whose 64-k slice is more than a third of the LDS: a CIRCULAR ring of 1-KiB pieces instead of whole slots (the value
+// is its size in pieces; 0 = whole slots).  A 128 x 96 tile stages 56 KiB per slice — two slots, ONE slice in flight; as a 160-piece
+// circle the stream runs 48 .. 104 KiB ahead of the slice being read: the space of slice kt - 1 is refilled, behind barrier kt, with the
+// last pieces of slice kt + 1 and the first of slice kt + 2.  (`stages` only tells these instantiations from the whole-slot ones.)
+constexpr int gemm_k64_ring_pieces(int wm, int wn, int tm, int tn, int stages, int split) {
+  return split != 1 ? 0                                                                   // (the two-plane-W form only: x2 slices are a quarter smaller and fit three whole slots)
+       : (wm == 4 && wn == 2 && tm == 2 && tn == 3 && stages == 4) ? 160                  // 128 x 96, 8 waves of 32 x 48: 2.86 slices
+       : (wm == 4 && wn == 2 && tm == 2 && tn == 4 && stages == 3) ? 160                  // 128 x 128, 8 waves of 32 x 64: 2.5 slices
+       : 0;
+}
+constexpr bool gemm_k64_deep(int wm, int wn, int tm, int tn, int stages, int split) {
+  return (wm == 4 && wn == 2 && tm == 2 && tn == 2 && stages == 3)                        // 128 x 64, 8 waves of 32 x 32, 3 x 48 KiB
+      || (wm == 2 && wn == 2 && tm == 2 && tn == 2 && (stages == 4 || stages == 5))       // 64 x 64, 4 waves, 4 - 5 x 32 KiB
+      || gemm_k64_ring_pieces(wm, wn, tm, tn, stages, split) != 0;
+}
+
 // WM x WN waves; each wave owns TM x TN subtiles of 16x16.  Block tile = (WM*TM*16) x (WN*TN*16).
 // STAGES = depth of the LDS ring: 4 for the big tiles; 8 for the small-tile variants used when a GEMM has fewer tiles than
 // the chip has CUs — those are bound by bytes in flight per CU (3 x 16 KiB per 128x128 block = 24 GB/s per CU at ~2 us of
@@ -111,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   // of 32: a CU's LDS-DMA stream moves 85 GB/s in 128-B pieces against 52 - 57 in 64-B pieces whatever the ring depth or the number of
   // issuing waves (tools/micro/dma_stream.hip, the batch-1 QKV pattern), and with one image's ~1200 token rows the K loop IS that
   // stream (ablations: profiles/NOTES.md round 4).
-  constexpr bool K64 = SPLIT && STAGES == 2 && BM * BN < 192 * 256;
+  constexpr bool K64 = SPLIT && BM * BN < 192 * 256 && (STAGES == 2 || gemm_k64_deep(WM, WN, TM, TN, STAGES, SPLIT));
   constexpr int KB = K64 ? 64 : BK;         // k per staged slice
   constexpr int RPP = 512 / KB;             // rows per 1-KiB DMA piece (16 at 64-B rows, 8 at 128-B rows)
   constexpr int LPR = 64 / RPP;             // lanes (16-byte chunks) per row
@@ -133,7 +152,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   // (the fp32-output 256 x 256 form stays one workgroup per tile: with the tile loop around it hipcc spills 36 bytes in its epilogue)
   constexpr bool PERS = !SPLIT && NW == 8 && STAGES == 4 && VEC == 2 && (OUT == 1 || TN == 3);
   constexpr int SLAB_OFF = PERS ? (STAGES - 1) * STAGE_HALVES * 2 : 0;                       // bytes: slot STAGES - 1 and what follows
-  constexpr int LDS_BYTES = PERS ? 160 * 1024 : STAGES * STAGE_HALVES * 2;
+  constexpr int RINGP = K64 ? gemm_k64_ring_pieces(WM, WN, TM, TN, STAGES, SPLIT) : 0;            // circular ring of pieces (K64 tiles too large for three slots)
+  constexpr bool FRAC = RINGP != 0;
+  constexpr int LDS_BYTES = PERS ? 160 * 1024 : (FRAC ? RINGP * 1024 : STAGES * STAGE_HALVES * 2);
   constexpr int SLAB_CAP = LDS_BYTES - SLAB_OFF;
   __shared__ __attribute__((aligned(16))) half_t smem[LDS_BYTES / 2];
 
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   const unsigned pos_y0 = p.pos_y ? pos_q0 / (unsigned)p.pos_w : 0u, pos_x0 = pos_q0 - pos_y0 * (unsigned)p.pos_w;
   const int pos_rsb = BN * (p.pos_f16 ? 2 : 4) + 16;                          // LDS row stride of the slice (bytes)
   const int pos_rows = p.pos_y ? p.pos_w + (int)((pos_x0 + BM - 1) / (unsigned)p.pos_w) + 1 : 0;
-  const bool pos_lds = p.pos_y && pos_rows * pos_rsb <= POS_CAP_BYTES;
+  const bool pos_lds = !FRAC && p.pos_y && pos_rows * pos_rsb <= POS_CAP_BYTES;   // (the circular ring leaves no slot free under its prologue: direct path)
   char* const pos_slot = (char*)(smem + (STAGES - 1) * STAGE_HALVES);
   auto pos_fetch_t = [&](auto tag) {                            // global -> registers, one 16-byte chunk per thread and pass
     typedef decltype(tag) T;
@@ -367,19 +388,93 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   constexpr bool BIGT = SPLIT && BM * BN >= 192 * 256;    // the two-slot (SPLIT = 2: three-slot) big tiles
   static_assert(!SPLIT || K64 || BIGT == (STAGES == 2 || (SPLIT == 2 && STAGES == 3 && BM * BN >= 192 * 256)), "big split-pair tiles: 2 slots (x2: 2 or 3)");
   if constexpr (K64) {
-    // ---- f16x3 loop on 64-k slices, two slots: barrier (slice kt landed everywhere, every read of the other slot has returned) ->
-    // fragments of both k-steps -> DMA of slice kt + 1 into the other slot -> 2 x three sweeps.  One slice of prefetch: a slice carries
-    // 6 TM TN MFMAs per wave, as long as the DMA stream needs to land the next one at its 128-B-piece rate.
+    // ---- f16x3 loop on 64-k slices.  Per slice: counted wait + barrier (slice kt landed everywhere, every read of the slot about to be
+    // refilled has returned) -> fragments of both k-steps -> DMA of slice kt + STAGES - 1 into the slot slice kt - 1 left -> 2 x three sweeps.
+    // Two slots: one slice of prefetch (the round-4 form).  Three and more: STAGES - 2 slices stay in flight across the barrier.
+    constexpr int KD = STAGES - 1;
+    const int sz = (frow >> 1) & 7;
+    if constexpr (FRAC) {
+    // ---- circular ring.  Stream position of piece pc of slice s: s * PIECES + pc; ring position: that modulo RINGP (both multiples of 8
+    // pieces = 64 rows: a 16-row fragment read never straddles the wrap, and wave w always owns the ring positions = w mod NW).  A slice
+    // goes out in two parts: its first H issues per wave two steps ahead, the other NP - H one step ahead, so that behind barrier kt exactly
+    // one slice's worth of pieces — the rest of slice kt + 1, then the head of slice kt + 2 — refills the space slice kt - 1 left.
+    // At barrier kt slice kt must have landed: the only issues younger than its last piece are the H of slice kt + 1's head.
+    static_assert(PIECES % NW == 0 && RINGP % 8 == 0 && PIECES % 8 == 0 && RPP == 8, "circular ring: whole issues per wave, wrap on 64-row boundaries");
+    constexpr int H = (RINGP - 2 * PIECES) / NW;
+    static_assert((RINGP - 2 * PIECES) % NW == 0 && H >= 1 && H < NP && NP + H < 64, "circular ring: between two and three slices");
+    auto wrap = [](int r) { return r >= RINGP ? r - RINGP : r; };
+    auto issue_part = [&](int st, auto LO, auto HI) {          // issues [LO, HI) of the slice whose ring start is piece st
+#pragma unroll
+      for (int i = decltype(LO)::value; i < decltype(HI)::value; ++i) {
+        const int r = wrap(st + wave + i * NW);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase[i] + goff[i]), (lds_ptr_t)(smem + r * 512), 16, 0, 0);
+        gbase[i] += KB;
+      }
+    };
+    typedef std::integral_constant<int, 0> i0_t;
+    typedef std::integral_constant<int, H> iH_t;
+    typedef std::integral_constant<int, NP> iN_t;
     pos_before_prologue();
-    issue_stage(0);
+    if (nk > 0) issue_part(0, i0_t{}, iN_t{});
+    if (nk > 1) issue_part(PIECES, i0_t{}, iN_t{});
+    if (nk > 2) issue_part(2 * PIECES, i0_t{}, iH_t{});
     pos_after_prologue();
     ZH_PROBE(1);
-    const int sz = (frow >> 1) & 7;
     half8_t fa[2][2 * TM], fw[2][NPLW * TN];
+    const int lofs0 = foff + ((fk ^ sz) * 8), lofs1 = foff + (((4 | fk) ^ sz) * 8);   // lane offsets (halves) inside a subtile's two pieces, k-steps 0 / 1
+    int st = 0;                                                // ring start (piece) of slice kt
     for (int kt = 0; kt < nk; ++kt) {
-      const int slot = kt & 1;
+      if (kt == 0) {
+        if (nk > 2) wait_vmcnt_barrier<NP + H>();
+        else if (nk > 1) wait_vmcnt_barrier<NP>();
+        else wait_vmcnt_barrier<0>();
+      } else if (kt + 1 < nk) wait_vmcnt_barrier<H>();
+      else wait_vmcnt_barrier<0>();
+      // the refill goes out FIRST: the tail of slice kt + 1 is needed one step from now, and a step (fragment reads + 6 TM TN MFMAs) is about
+      // one load latency long
+      const int st1 = wrap(st + PIECES);
+      if (kt >= 1) {
+        if (kt + 1 < nk) issue_part(st1, iH_t{}, iN_t{});
+        if (kt + 2 < nk) issue_part(wrap(st1 + PIECES), i0_t{}, iH_t{});
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int lo = j ? lofs1 : lofs0;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int t = 0; t < TM; ++t) fa[j][pl * TM + t] = *(const half8_t*)(smem + wrap(st + pl * (BM / 8) + (wr * TM + t) * 2) * 512 + lo);
+          if (pl < NPLW) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) fw[j][pl * TN + t] = *(const half8_t*)(smem + wrap(st + (NPL * BM + pl * BN) / 8 + (wc * TN + t) * 2) * 512 + lo);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int sw = 0; sw < 3; ++sw) {
+          if (SPLIT == 2 && sw == 1) continue;           // W has no lo plane
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][(sw == 1 ? TN : 0) + nt], fa[j][(sw == 2 ? TM : 0) + mt], acc[nt][mt], 0, 0, 0);
+        }
+      st = st1;
+    }
+    } else {
+    static_assert((KD - 1) * NP < 64, "vmcnt overflow");
+    pos_before_prologue();
+#pragma unroll
+    for (int s = 0; s < KD; ++s)
+      if (s < nk) issue_stage(s);
+    pos_after_prologue();
+    ZH_PROBE(1);
+    half8_t fa[2][2 * TM], fw[2][NPLW * TN];
+    int slot = 0, wslot = KD % STAGES;
+    auto read_frags = [&]() {
       const int so = slot * STAGE_HALVES;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int ko = (((j << 2) | fk) ^ sz) * 8;
@@ -393,7 +488,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
           }
         }
       }
-      if (kt + 1 < nk) issue_stage(slot ^ 1);
+    };
+    auto sweeps = [&]() {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -405,6 +501,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
             for (int mt = 0; mt < TM; ++mt)
               acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][(sw == 1 ? TN : 0) + nt], fa[j][(sw == 2 ? TM : 0) + mt], acc[nt][mt], 0, 0, 0);
         }
+    };
+    auto advance = [&]() {
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+      wslot = wslot + 1 == STAGES ? 0 : wslot + 1;
+    };
+    int kt = 0;
+    for (; kt + KD < nk; ++kt) {
+      wait_vmcnt_barrier<(KD - 1) * NP>();
+      read_frags();
+      issue_stage(wslot);
+      sweeps();
+      advance();
+    }
+    for (; kt < nk; ++kt) {              // tail: slices kt .. nk-1 are in flight, slice kt must have landed
+      wait_stages_barrier<NP, KD - 1>(nk - 1 - kt);
+      read_frags();
+      sweeps();
+      advance();
+    }
     }
   } else if constexpr (BIGT) {
     // ---- f16x3 loop, big tile (256 x 256, 8 waves of 128 x 64), TWO 64-KiB slots.  Ablations of the 3-slot 256 x 128 loop

@@ -152,6 +152,14 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // (only while the 64 x 64 tiles still fit ONE round of the chip, one block per CU: c_fc at M = 442 is 336 such tiles and ran
   //  18.3 -> 23.6 us with them)
   if (pick == 64 && (long)zh_cdiv(M, 64) * zh_cdiv(N, 64) * batch <= 256) pick = 3064;
+  // Round 5: these one-round tiles move their operands at (bytes in flight per CU) / (load latency) — 64-k slices (128-B row pieces: 85
+  // instead of 52 - 57 GB/s of request rate) on a ring deep enough to keep TWO or more of them in flight: the 64 x 64 tile on four slots
+  // of 32 KiB (was six 32-k slots: out_proj at one image 12.3 -> 11.1 us, QKV / c_fc at 442 tokens 13.6 -> 12.2 / 24.2 -> 21.2), and a
+  // 128 x 64 tile on three slots of 48 KiB where ITS tiles are one round and the 64 x 64 ones are not (1201 x 1536 x 768: 18.8 -> 15.1 us).
+  // The 128 x 96 / 128 x 128 tiles of the one-image QKV / c_fc stage 56 / 64 KiB per 64-k slice: two slots, one slice in flight — a tie
+  // with their 32-k forms (6496); fetching their A lo fragments straight into registers to make room (40 / 48 KiB slots) was slower
+  // (QKV 24.4 -> 26.4 us: the duplicate requests of the waves that share rows cost the request rate more than the deeper ring returns).
+  if (pick == 64 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch <= 256) pick = 6464;
   const int forced = gemm_dev_overrides().tile;
   if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448 || forced == 3064) pick = forced;
   // M ~ 1200 rows (one image at native resolution: c_fc 1201 x 3072, the split-K planes of c_proj / out_proj): 128 x 64 tiles are 480
@@ -163,7 +171,16 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   //  stream runs 85 GB/s in 128-B pieces against 52 - 57 in 64-B pieces (tools/micro/dma_stream.hip), but inside the GEMM the form with
   //  ONE slice in flight ties with the 3-slot 32-k form: QKV at one image 21.9 - 22.8 us against 22.4 - 23.5 over four runs, K loop
   //  18.2 against 13.8 us on a cold weight (profiles/NOTES.md round 4): measured, tested, not selected.)
-  if (forced == 1288 || forced == 6496) pick = forced;
+  if (forced == 1288 || forced == 6496 || forced == 6464 || forced == 3066 || ((forced == 7096 || forced == 7128) && !x2 && !pos_y)) pick = forced;
+  // The one-image tiles above 48 KiB per 64-k slice (QKV's 128 x 96: 56 KiB, c_fc's and the split-K planes' 128 x 128: 64 KiB) on a CIRCULAR ring
+  // of 160 one-KiB pieces (gemm_kernel.h FRAC): behind every barrier one slice's worth of pieces — the tail of slice kt + 1, then the head
+  // of slice kt + 2 — refills what slice kt - 1 left, 48 .. 104 KiB ahead of the reads instead of the 56 of two slots.  QKV at one image
+  // 23.5 -> 21.8 us, c_fc 28.9 -> 27.5, c_proj planes 27.6 -> 26.5, the decoder's 3200 x 768 x 768 21.1 -> 20.8 (r05_gemm_k64_deep.txt):
+  // the pieces that go out ONE step ahead (an eighth of a 128 x 96 slice, half of a 128 x 128 one) still wait out their latency.
+  if (!forced && !x2 && !pos_y) {
+    if (pick == 96) pick = 7096;
+    else if (pick == 1288) pick = 7128;
+  }
   if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
   if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124 || pick == 4484) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
@@ -207,7 +224,9 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
     else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 4, 2, 2>(p, batch, out_kind, stream);   // 4 slots: the epilogue slabs need 102 KiB
     else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2, 2>(p, batch, out_kind, stream);
-    else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, 4, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 3066) ok = launch_x3<2, 2, 2, 2, RING64, 2, 2>(p, batch, out_kind, stream);
+    else if (pick == 6464) ok = launch_x3<4, 2, 2, 2, 3, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 1288) ok = launch_x3<4, 2, 2, 4, 4, 2, 2>(p, batch, out_kind, stream);
     else if (pick == 6496) ok = launch_x3<4, 2, 2, 3, 2, 2, 2>(p, batch, out_kind, stream);
     else ok = launch_x3<2, 2, 4, 2, 3, 2, 2>(p, batch, out_kind, stream);
@@ -219,9 +238,13 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   else if (pick == 256) ok = launch_x3<4, 2, 4, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 192) ok = launch_x3<4, 2, 3, 4, 3, 2>(p, batch, out_kind, stream);
   else if (pick == 96) ok = launch_x3<4, 2, 2, 3, 3, 2>(p, batch, out_kind, stream);   // 8 waves of 32 x 48
-  else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, RING64, 2>(p, batch, out_kind, stream);   // 64 x 64, deep ring
+  else if (pick == 3064) ok = launch_x3<2, 2, 2, 2, 4, 2>(p, batch, out_kind, stream);   // 64 x 64 on 64-k slices, four slots (three slices in flight)
+  else if (pick == 3066) ok = launch_x3<2, 2, 2, 2, RING64, 2>(p, batch, out_kind, stream);   // developer A/B: 64 x 64 on 32-k slices, six slots (the form until round 5)
   else if (pick == 1288) ok = launch_x3<4, 2, 2, 4, 4, 2>(p, batch, out_kind, stream);   // 128 x 128, 8 waves of 32 x 64, 4 slots
   else if (pick == 6496) ok = launch_x3<4, 2, 2, 3, 2, 2>(p, batch, out_kind, stream);   // K64 (64-k slices, two slots): 128 x 96, 8 waves of 32 x 48
+  else if (pick == 6464) ok = launch_x3<4, 2, 2, 2, 3, 2>(p, batch, out_kind, stream);   // K64 on THREE slots: 128 x 64, 8 waves of 32 x 32
+  else if (pick == 7096) ok = launch_x3<4, 2, 2, 3, 4, 2>(p, batch, out_kind, stream);   // K64 on a circular ring of 160 pieces: 128 x 96
+  else if (pick == 7128) ok = launch_x3<4, 2, 2, 4, 3, 2>(p, batch, out_kind, stream);   // ... 128 x 128
   else ok = launch_x3<2, 2, 4, 2, 3, 2>(p, batch, out_kind, stream);
   ZH_CHECK_ARG(ok, "zh_gemm_f16x3: (out_kind=%d, act=%d) is not an instantiated epilogue", out_kind, act);
   ZH_CHECK_LAUNCH("zh_gemm_f16x3");
