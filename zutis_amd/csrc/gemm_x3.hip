@@ -159,7 +159,11 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // The 128 x 96 / 128 x 128 tiles of the one-image QKV / c_fc stage 56 / 64 KiB per 64-k slice: two slots, one slice in flight — a tie
   // with their 32-k forms (6496); fetching their A lo fragments straight into registers to make room (40 / 48 KiB slots) was slower
   // (QKV 24.4 -> 26.4 us: the duplicate requests of the waves that share rows cost the request rate more than the deeper ring returns).
+#ifndef ZH_X3_ROUND4_SMALL_TILES   // developer A/B (tools/build_variant_lib.sh): the one-round tiles as selected until round 5
   if (pick == 64 && (long)zh_cdiv(M, 128) * zh_cdiv(N, 64) * batch <= 256) pick = 6464;
+#else
+  if (pick == 3064) pick = 3066;
+#endif
   const int forced = gemm_dev_overrides().tile;
   if (forced == 64 || forced == 96 || forced == 192 || forced == 256 || forced == 512 || forced == 448 || forced == 3064) pick = forced;
   // M ~ 1200 rows (one image at native resolution: c_fc 1201 x 3072, the split-K planes of c_proj / out_proj): 128 x 64 tiles are 480
@@ -177,10 +181,12 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // of slice kt + 2 — refills what slice kt - 1 left, 48 .. 104 KiB ahead of the reads instead of the 56 of two slots.  QKV at one image
   // 23.5 -> 21.8 us, c_fc 28.9 -> 27.5, c_proj planes 27.6 -> 26.5, the decoder's 3200 x 768 x 768 21.1 -> 20.8 (r05_gemm_k64_deep.txt):
   // the pieces that go out ONE step ahead (an eighth of a 128 x 96 slice, half of a 128 x 128 one) still wait out their latency.
+#ifndef ZH_X3_ROUND4_SMALL_TILES
   if (!forced && !x2 && !pos_y) {
     if (pick == 96) pick = 7096;
     else if (pick == 1288) pick = 7128;
   }
+#endif
   if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
   // the two-slot tiles address operand rows as SGPR base + 32-bit per-lane BYTE offset
   if ((pick == 512 || pick == 448 || pick == 5122 || pick == 5124 || pick == 4484) && ((long)(M - 1) * lda + K > 0x7FFFFFFFL || (long)(N - 1) * ldw + K > 0x7FFFFFFFL)) pick = 256;
