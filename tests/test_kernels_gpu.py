@@ -121,19 +121,24 @@ def test_gemm_race_screen_bitwise_repeatable(dev):
                 assert torch.equal(out, first), f"non-repeatable GEMM result at launch {it} for {(M, N, K)}"
 
 
-@pytest.mark.parametrize("tile", ["256", "192", "128", "64", "2128", "2064", "3064"])
+@pytest.mark.parametrize("tile", ["256", "192", "128", "64", "2128", "2064", "3064", "7032", "7096", "7128"])
 def test_gemm_every_tile_variant_every_ring_phase(dev, tile):
     """Each tile / ring-depth variant (forced through the developer entry zh_dev_set_gemm_overrides: the environment is read
-    once per process) over K = 64 .. 1024: every prologue / steady / tail combination of the 4- and 8-deep LDS-DMA rings,
-    ragged M and N, repeated launches bitwise identical."""
+    once per process) over K = 64 .. 1024: every prologue / steady / tail combination of the 4- and 8-deep LDS-DMA rings and of the
+    64-k-slice rings of round 5 (7032 / 7096 / 7128: five and seven slots), ragged M and N, repeated launches bitwise identical — and
+    bitwise the 128 x 128 tile's result (the K order inside a tile does not depend on the tile: what the tail peel and the
+    batch-invariance of the engine rest on)."""
     from zutis_amd import ops, _lib
     L = _lib.load(raw=True)
-    _lib.check(L.zh_dev_set_gemm_overrides(0, int(tile), 0), "zh_dev_set_gemm_overrides")
     try:
         M, N = 333, 328
         for K in (64, 128, 192, 256, 320, 448, 512, 576, 640, 1024):
             A, W = _randn((M, K), 300 + K, 0.5).to(f16).to(dev), _randn((N, K), 400 + K, 0.5).to(f16).to(dev)
             ref = A.float() @ W.float().t()
+            _lib.check(L.zh_dev_set_gemm_overrides(0, 128, 0), "zh_dev_set_gemm_overrides")
+            base = torch.empty((M, N), dtype=f32, device=dev)
+            ops.gemm(A, W, base)
+            _lib.check(L.zh_dev_set_gemm_overrides(0, int(tile), 0), "zh_dev_set_gemm_overrides")
             outs = []
             for _ in range(3):
                 out = torch.empty((M, N), dtype=f32, device=dev)
@@ -141,6 +146,7 @@ def test_gemm_every_tile_variant_every_ring_phase(dev, tile):
                 outs.append(out)
             assert torch.allclose(outs[0], ref, atol=1e-3 * math.sqrt(K / 64), rtol=1e-3), (tile, K)
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (tile, K)
+            assert torch.equal(outs[0], base), (tile, K)
     finally:
         L.zh_dev_set_gemm_overrides(0, 0, 0)
 

@@ -119,6 +119,40 @@ if __name__ == "__main__":
         bench(442, 2304, 768, "qkv336", (3066, 3064, 6496))
         bench(442, 3072, 768, "fc336", (3066, 3064, 6496), act=ops.ACT_QUICKGELU)
         bench(T, 768, 3072, "proj/S4", (1288, 6464, 6496), splits=(4,), out="f32")
+    if which == "k64f":       # round 5, the plain-fp16 kernel (`fast`): one-round tiles on 64-k slices (7032 / 7096 / 7128) beside the 32-k tiles (3064 / 64 / 128)
+        def benchf(M, N, K, name, tiles, f16out=True, act=ops.ACT_NONE, resid=False):
+            A = torch.randn(M, K, device=dev).half()
+            Ws = [(torch.randn(N, K, device=dev) * 0.03).half() for _ in range(NW)]
+            b = torch.randn(N, device=dev)
+            R = torch.randn(M, N, device=dev) if resid else None
+            ref = ops_act(A.float() @ Ws[0].float().t() + b, act) + (R if resid else 0)
+            line = f"{name:8s} {M}x{N}x{K}"
+            for tile in tiles:
+                _lib.check(L.zh_dev_set_gemm_overrides(0, tile, 0))
+                try:
+                    o = torch.empty(M, N, device=dev, dtype=torch.float16 if f16out else torch.float32)
+                    fn = lambda i: ops.gemm(A, Ws[i % NW], o, bias=b, residual=R, act=act)
+                    fn(0); torch.cuda.synchronize()
+                    err = float((o.float() - ref).abs().max())
+                    line += f" | t{tile}: {t(fn):5.1f}us e{err:.0e}"
+                except Exception as e:
+                    line += f" | t{tile}: ERR {str(e)[:40]}"
+                finally:
+                    L.zh_dev_set_gemm_overrides(0, 0, 0)
+            print(line, flush=True)
+        DT = (64, 128, 7096, 7128)
+        benchf(3200, 768, 768, "dec o", DT, f16out=False, resid=True)
+        benchf(3200, 768, 768, "dec q", DT)
+        benchf(3200, 2304, 768, "dec qkv", DT)
+        benchf(3200, 2048, 768, "dec l1", DT, act=ops.ACT_RELU)
+        benchf(3200, 768, 2048, "dec l2", DT, f16out=False, resid=True)
+        ET = (128, 7096, 7128)
+        benchf(T, 2304, 768, "qkv", ET)
+        benchf(T, 3072, 768, "fc", ET, act=ops.ACT_QUICKGELU)
+        benchf(T, 768, 768, "out", (64, 3064, 7032), f16out=False, resid=True)
+        benchf(T, 768, 3072, "proj", (64, 3064, 7032), f16out=False, resid=True)
+        benchf(442, 2304, 768, "qkv336", (3064, 7032))
+        benchf(442, 768, 3072, "proj336", (3064, 7032), f16out=False, resid=True)
     if which == "pmc64":      # counters of the 32-k (96) and 64-k (6496) forms of the one-image QKV tile
         def t(fn, n=12):
             for i in range(n): fn(i)

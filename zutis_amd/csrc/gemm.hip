@@ -70,12 +70,22 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   // blocks to work; measured 19.6 -> 16.5 us (K = 768) and 32.7 -> 28.8 us (K = 2048) with the residual epilogue, while
   // N = 1536 / 2048 keep 128 x 128 (tools/gemm_dec_tiles.py)
   else if (pick == 128 && t128 <= 256 && N <= 768) pick = 64;
+#ifndef ZH_F16_ROUND4_SMALL_TILES   // developer A/B (tools/build_variant_lib.sh): the one-round tiles as selected until round 5
+  // Round 5: one-round tiles on 64-k slices (128-B row pieces) with several slices in flight (gemm_kernel.h K64 / gemm_k64_plain; the
+  // finding of the split-pair tiles, tools/gemm_small_bench.py k64f): 64 x 64 on seven slots instead of eight 32-k ones (c_proj at one
+  // image 18.6 -> 15.1 us, at 442 tokens 17.4 -> 13.7); 128 x 96 on five where it makes ONE round (the decoder's 3200 x 768 x 768
+  // 14.7 -> 13.1 / 12.3 -> 10.4 us, linear2 (K = 2048) 26.7 -> 22.1, QKV at one image 11.7 -> 10.7); 128 x 128 on five where that is one
+  // round (c_fc at one image 14.2 -> 13.7).  (128 x 64 on six slots: slower than every form it was compared with — not kept.)
+  if (pick == 3064) pick = 7032;
+  else if ((pick == 64 || pick == 128) && N % 96 == 0 && (long)zh_cdiv(M, 128) * (N / 96) * batch <= 256) pick = 7096;
+  else if (pick == 128 && t128 <= 256) pick = 7128;
+#endif
   const int forced = dev.tile ? dev.tile : (M <= 4096 ? dev.tile_small : 0);
   if (forced) {
-    static const int known[] = {64, 128, 192, 256, 2064, 2128, 3064};
+    static const int known[] = {64, 128, 192, 256, 2064, 2128, 3064, 7032, 7096, 7128};
     bool okc = false;
     for (int k : known) okc |= (k == forced);
-    ZH_CHECK_ARG(okc, "zh_gemm_f16: ZH_GEMM_TILE(_SMALL)=%d is not a tile code (64|128|192|256|2064|2128|3064)", forced);
+    ZH_CHECK_ARG(okc, "zh_gemm_f16: ZH_GEMM_TILE(_SMALL)=%d is not a tile code (64|128|192|256|2064|2128|3064|7032|7096|7128)", forced);
     pick = forced;
   }
   // 16-byte row stores need 16-B aligned rows; an f16 residual is not supported (none on the hot path)
@@ -108,6 +118,9 @@ extern "C" int zh_gemm_f16(const void* A, long lda, long strideA, const void* W,
   else if (pick == 2128) ok = launch_gemm<2, 2, 4, 4, 8, 2>(p, batch, out_f16, stream);   // 128 x 128, 8-deep ring
   else if (pick == 2064) ok = launch_gemm<2, 2, 4, 2, 8, 2>(p, batch, out_f16, stream);   // 128 x 64, 8-deep ring
   else if (pick == 3064) ok = launch_gemm<2, 2, 2, 2, 8, 2>(p, batch, out_f16, stream);   // 64 x 64, 8-deep ring
+  else if (pick == 7032) ok = launch_gemm<2, 2, 2, 2, 7, 2>(p, batch, out_f16, stream);   // 64-k slices (gemm_k64_plain): 64 x 64, seven slots
+  else if (pick == 7096) ok = launch_gemm<2, 2, 4, 3, 5, 2>(p, batch, out_f16, stream);   // ... 128 x 96, five
+  else if (pick == 7128) ok = launch_gemm<2, 2, 4, 4, 5, 2>(p, batch, out_f16, stream);   // ... 128 x 128, five
   else if (pick == 64) ok = launch_gemm<2, 2, 4, 2, 4, 2>(p, batch, out_f16, stream);   // 128 x 64
   else if (pick == 128) ok = launch_gemm<2, 2, 4, 4, 4, 2>(p, batch, out_f16, stream);
   else if (pick == 192) ok = launch_gemm<2, 4, 8, 3, 4, 2>(p, batch, out_f16, stream);

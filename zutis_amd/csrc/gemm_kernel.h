@@ -114,6 +114,14 @@ constexpr bool gemm_k64_deep(int wm, int wn, int tm, int tn, int stages, int spl
       || gemm_k64_ring_pieces(wm, wn, tm, tn, stages, split) != 0;
 }
 
+// Plain-fp16 tiles on 64-k slices (round 5: the same finding for the one-round GEMMs of the `fast` precision — the decoder's 3200-row
+// projections at the headline batch, everything at one image): 28 / 32 / 16 KiB per slice: five, five and seven whole slots.
+constexpr bool gemm_k64_plain(int wm, int wn, int tm, int tn, int stages) {
+  return (wm == 2 && wn == 2 && tm == 4 && tn == 3 && stages == 5)                        // 128 x 96, 4 waves of 64 x 48, 5 x 28 KiB
+      || (wm == 2 && wn == 2 && tm == 4 && tn == 4 && stages == 5)                        // 128 x 128, 4 waves of 64 x 64, 5 x 32 KiB
+      || (wm == 2 && wn == 2 && tm == 2 && tn == 2 && stages == 7);                       // 64 x 64, 4 waves of 32 x 32, 7 x 16 KiB
+}
+
 // WM x WN waves; each wave owns TM x TN subtiles of 16x16.  Block tile = (WM*TM*16) x (WN*TN*16).
 // STAGES = depth of the LDS ring: 4 for the big tiles; 8 for the small-tile variants used when a GEMM has fewer tiles than
 // the chip has CUs — those are bound by bytes in flight per CU (3 x 16 KiB per 128x128 block = 24 GB/s per CU at ~2 us of
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   // of 32: a CU's LDS-DMA stream moves 85 GB/s in 128-B pieces against 52 - 57 in 64-B pieces whatever the ring depth or the number of
   // issuing waves (tools/micro/dma_stream.hip, the batch-1 QKV pattern), and with one image's ~1200 token rows the K loop IS that
   // stream (ablations: profiles/NOTES.md round 4).
-  constexpr bool K64 = SPLIT && BM * BN < 192 * 256 && (STAGES == 2 || gemm_k64_deep(WM, WN, TM, TN, STAGES, SPLIT));
+  constexpr bool K64 = BM * BN < 192 * 256 && (SPLIT ? (STAGES == 2 || gemm_k64_deep(WM, WN, TM, TN, STAGES, SPLIT)) : gemm_k64_plain(WM, WN, TM, TN, STAGES));
   constexpr int KB = K64 ? 64 : BK;         // k per staged slice
   constexpr int RPP = 512 / KB;             // rows per 1-KiB DMA piece (16 at 64-B rows, 8 at 128-B rows)
   constexpr int LPR = 64 / RPP;             // lanes (16-byte chunks) per row
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       if (s < nk) issue_stage(s);
     pos_after_prologue();
     ZH_PROBE(1);
-    half8_t fa[2][2 * TM], fw[2][NPLW * TN];
+    half8_t fa[2][NPL * TM], fw[2][NPLW * TN];
     int slot = 0, wslot = KD % STAGES;
     auto read_frags = [&]() {
       const int so = slot * STAGE_HALVES;
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
       for (int j = 0; j < 2; ++j) {
         const int ko = (((j << 2) | fk) ^ sz) * 8;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
           for (int t = 0; t < TM; ++t) fa[j][pl * TM + t] = *(const half8_t*)(rdA + so + (pl * BM + t * 16) * KB + ko);
           if (pl < NPLW) {
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int sw = 0; sw < 3; ++sw) {
+        for (int sw = 0; sw < (SPLIT ? 3 : 1); ++sw) {   // (plain fp16 operands: the one product)
           if (SPLIT == 2 && sw == 1) continue;           // W has no lo plane
 #pragma unroll
           for (int nt = 0; nt < TN; ++nt)
