@@ -179,12 +179,13 @@ extern "C" int zh_gemm_f16x3(const void* A, long lda, long strideA, long planeA,
   // The one-image tiles above 48 KiB per 64-k slice (QKV's 128 x 96: 56 KiB, c_fc's and the split-K planes' 128 x 128: 64 KiB) on a CIRCULAR ring
   // of 160 one-KiB pieces (gemm_kernel.h FRAC): behind every barrier one slice's worth of pieces — the tail of slice kt + 1, then the head
   // of slice kt + 2 — refills what slice kt - 1 left, 48 .. 104 KiB ahead of the reads instead of the 56 of two slots.  QKV at one image
-  // 23.5 -> 21.8 us, c_fc 28.9 -> 27.5, c_proj planes 27.6 -> 26.5, the decoder's 3200 x 768 x 768 21.1 -> 20.8 (r05_gemm_k64_deep.txt):
+  // 23.5 -> 21.8 us, the decoder's 3200 x 768 x 768 21.1 -> 20.8 (r05_gemm_k64_deep.txt; 128 x 128: c_fc 28.9 -> 27.5, c_proj planes 27.6 -> 26.5):
   // the pieces that go out ONE step ahead (an eighth of a 128 x 96 slice, half of a 128 x 128 one) still wait out their latency.
 #ifndef ZH_X3_ROUND4_SMALL_TILES
   if (!forced && !x2 && !pos_y) {
     if (pick == 96) pick = 7096;
-    else if (pick == 1288) pick = 7128;
+    // (7128, the 128 x 128 tile on the same circle: half of every slice still goes out one step ahead — c_fc 28.9 -> 27.5 us back to
+    //  back, but 26.5 -> 26.4 per launch inside one image's dependent chain (r05_c3_launch_list.txt): developer code, not selected)
   }
 #endif
   if ((forced == 5122 || forced == 5124 || forced == 4484) && x2) pick = forced;   // developer A/B: the x2 256 x 256 tile on TWO slots (2 x 4 waves of 128 x 64) / on three as 2 x 4 waves of 128 x 64
