@@ -50,8 +50,10 @@ const char* zh_arch(void);
 const char* zh_last_error(void);
 
 /* DEVELOPER entry (tests / tools, not part of the reference's surface): force the GEMM tile variant for the calls that follow.
- * group_m = super-tile height (0 = default 4); tile = tile code for zh_gemm_f16 (64|128|192|256|2064|2128|3064) and
- * zh_gemm_f16x3 (64|96|192|256|448|512|3064; 5122 / 5124 = the planeW = 0 form of 512 on two slots / as 2 x 4 waves of 128 x 64, 4484 = of 448 as 4 x 2 waves of 48 x 128), 0 = the cost model's choice; tile_small = the same, applied to M <= 4096 only.  Process-wide;
+ * group_m = super-tile height (0 = default 4); tile = tile code for zh_gemm_f16 (64|128|192|256|2064|2128|3064; 7032 / 7096 / 7128 = the
+ * 64 x 64 / 128 x 96 / 128 x 128 tiles on 64-k slices) and zh_gemm_f16x3 (64|96|192|256|448|512|3064|1288; 3066 = 64 x 64 on 32-k slices,
+ * 6464 / 6496 = 128 x 64 / 128 x 96 on 64-k slices in three / two whole slots, 7096 / 7128 = 128 x 96 / 128 x 128 on the circular piece ring;
+ * 5122 / 5124 = the planeW = 0 form of 512 on two slots / as 2 x 4 waves of 128 x 64, 4484 = of 448 as 4 x 2 waves of 48 x 128), 0 = the cost model's choice; tile_small = the same, applied to M <= 4096 only.  Process-wide;
  * the initial values come from ZH_GEMM_GROUP_M / ZH_GEMM_TILE / ZH_GEMM_TILE_SMALL, read once. */
 int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small);
 
