@@ -95,10 +95,7 @@ __device__ __forceinline__ void wait_stages_barrier(int c) {
   }
 }
 
-// Split-pair tiles that take 64-k slices on MORE than two slots (every other (tile, ring depth) pair below the big tiles is on 32-k
-// slices; two slots always mean 64-k).  Round 5: with ONE slice of prefetch every slice pays the whole load latency (the K loop of the
-// two-slot form ran 1.5 us per slice against 0.66 us of stream time); these keep two or more slices in flight.
-// ... and the tiles whose 64-k slice is more than a third of the LDS: a CIRCULAR ring of 1-KiB pieces instead of whole slots (the value
+// Split-pair tiles whose 64-k slice is more than a third of the LDS: a CIRCULAR ring of 1-KiB pieces instead of whole slots (the value
 // is its size in pieces; 0 = whole slots).  A 128 x 96 tile stages 56 KiB per slice — two slots, ONE slice in flight; as a 160-piece
 // circle the stream runs 48 .. 104 KiB ahead of the slice being read: the space of slice kt - 1 is refilled, behind barrier kt, with the
 // last pieces of slice kt + 1 and the first of slice kt + 2.  (`stages` only tells these instantiations from the whole-slot ones.)
@@ -108,6 +105,10 @@ constexpr int gemm_k64_ring_pieces(int wm, int wn, int tm, int tn, int stages, i
        : (wm == 4 && wn == 2 && tm == 2 && tn == 4 && stages == 3) ? 160                  // 128 x 128, 8 waves of 32 x 64: 2.5 slices
        : 0;
 }
+// Split-pair tiles that take 64-k slices on MORE than two slots (every other (tile, ring depth) pair below the big tiles is on 32-k
+// slices; two slots always mean 64-k).  Round 5: with ONE slice of prefetch every slice pays the whole load latency (the K loop of the
+// two-slot form ran 1.5 us per slice against 0.66 us of stream time); these keep two or more slices in flight —
+// whole slots, or the circular ring above.
 constexpr bool gemm_k64_deep(int wm, int wn, int tm, int tn, int stages, int split) {
   return (wm == 4 && wn == 2 && tm == 2 && tn == 2 && stages == 3)                        // 128 x 64, 8 waves of 32 x 32, 3 x 48 KiB
       || (wm == 2 && wn == 2 && tm == 2 && tn == 2 && (stages == 4 || stages == 5))       // 64 x 64, 4 waves, 4 - 5 x 32 KiB
