@@ -1,0 +1,184 @@
+"""Bounded objects of the default line: the other BASELINE configs (c4, c5), the bilateral solver and the pseudo-label path."""
+from __future__ import annotations
+
+import contextlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .common import PRECISION_DTYPE
+from .lanes import build_lanes, make_launch, check_timed_outputs
+from .roofline import gemm_roofline
+
+
+def solver_object(dev, reps=20):
+    """Bilateral-solver refinement (utils/bilateral_solver.py; BASELINE config 3's second half) at the pseudo-label size 512x683, natural-image
+    colour statistics: ms per image at 1 and 8 images per call, HBM roofline on SURVEY 8d's algorithmic bytes."""
+    from zutis_amd import detgen, ops
+    Hs, Ws = 512, 683
+    yy, xx = np.mgrid[:Hs, :Ws]
+    solver = {"size": [Hs, Ws], "unit": "ms per image", "bound": "hbm", "peak_TBps": 8.0,
+              "algorithmic_bytes_note": "N*(3+1+8+16) + V*250*(25 CG + 11 bistochastisation iterations) per image (SURVEY 8d)"}
+    for Bs in (1, 8):
+        rgb = torch.from_numpy(np.stack([detgen.selfmask_like_rgb(Hs, Ws, seed=3 + i) for i in range(Bs)])).to(dev)
+        tg = torch.from_numpy(np.stack([(((yy - 250) ** 2 + (xx - 300 - 3 * i) ** 2) < 150 ** 2).astype(np.uint8) for i in range(Bs)])).to(dev)
+        soft, stats = ops.bilateral_solve(rgb, tg)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ops.bilateral_solve(rgb, tg)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        V = float(stats[:, 0].float().mean().item())
+        byts = Hs * Ws * (3 + 1 + 8 + 16) + V * 250 * 36
+        solver[f"batch{Bs}"] = {"ms_per_image": round(dt / Bs * 1e3, 4), "vertices": round(V), "achieved_TBps": round(byts * Bs / dt / 1e12, 3),
+                                "frac": round(byts * Bs / dt / 8e12, 3), "cg_iterations": [int(v) for v in stats[:, 1].tolist()[:2]]}
+    return solver
+
+
+def pseudo_label_object(dev, precision="exact", B=4, reps=5):
+    """The pseudo-label path north_star names (SelfMask, networks/selfmask + utils/bilateral_solver.py, as datasets/*.py
+    generate_pseudo_masks drives them): DINO ViT-S/8 SelfMask at its working shape 512x683 (T = 5505 tokens) -> query selection ->
+    bilateral solver -> > 0.5 -> nearest resize to 480x640, `B` images per call, device side (the RLE JSON files are host work).
+    Parity of this path is held by tests/test_e2e_gpu.py::test_selfmask_* (reference goldens + the oracle at 512x683) and
+    tests/test_bilateral_gpu.py; synthetic noise images give the solver one lattice vertex per pixel (17x a natural image's)."""
+    from zutis_amd import detgen, pseudo_masks
+    from zutis_amd.engine import SelfMaskEngine
+    H, W = 512, 683
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()}, precision=precision)
+    x = torch.from_numpy(detgen.images(B, H, W, seed=7)).to(dev)
+    for _ in range(2):
+        pseudo_masks.pseudo_masks_batch(eng, x, [(480, 640)] * B, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pseudo_masks.pseudo_masks_batch(eng, x, [(480, 640)] * B, True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    eng._bufs.clear()
+    return {"what": f"SelfMask (DINO ViT-S/8 @{H}x{W}, T = 5505) + bilateral solver + threshold + nearest resize, {B} images per call, device side",
+            "value": round(B / dt, 1), "unit": "images/s", "ms_per_call": round(dt * 1e3, 2), "batch": B, "precision": precision, "calls": reps}
+
+
+def c4_object(P, cfg, dev, precision, steps=12, warmup=4, n_lanes=3, cpu_images=1, cpu_threads=16):
+    """BASELINE config 4 on one GPU, bounded: ViT-B/16 @518 px, 920 classes, 8 images per step (the reference's own batch for this
+    config, configs/imagenet_s919_*.yaml), three launch plans in flight exactly as the headline — value, roofline fraction of the
+    dominant GEMM, timed outputs bitwise an eager step, parity of the TIMED outputs against the oracle on `cpu_images` image(s)."""
+    from zutis_amd import detgen, ops
+    from zutis_amd import distributed as zd
+    from zutis_amd.engine import ZutisEngine
+    B, S, n = 8, 518, 920
+    text = torch.from_numpy(detgen.text_embeddings(n, cfg.embed_dim)).to(dev)
+    x = torch.randn((B, 3, S, S), generator=torch.Generator(device="cpu").manual_seed(4000)).to(dev)
+    eng = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
+    lanes = build_lanes(eng, x, text, S, n, n_lanes)
+    torch.cuda.synchronize()
+    pipe = zd.StepPipeline(lanes, make_launch(n_lanes), gather=False)
+    pipe.run(max(warmup, n_lanes))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok, lo_t, lab_t = check_timed_outputs(lanes)
+
+    def one_eager_step():
+        out = eng.forward(x)
+        eng.predict_semantic(out["patch_tokens"], text, (S, S))
+    roof = gemm_roofline(ops, one_eager_step, dt / steps)
+    obj = {"what": f"C4: ViT-B/16 @{S}px, {n} classes, {B} images per step, {n_lanes} launch plans in flight (`bench.py --workload c4` is the full line)",
+           "value": round(B * steps / dt, 1), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "precision": precision,
+           "dtype": PRECISION_DTYPE[precision], "timed_outputs_bitwise_equal_eager": bool(ok),
+           "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step", "gemm_share_of_step")}}
+    for an in ("attention_f16x3_tflops", "attention_f16x3_share_of_step", "attention_f16_tflops", "attention_f16_share_of_step"):
+        if an in roof:
+            obj["roofline"][an] = roof[an]
+    if cpu_images:
+        from oracle import zutis_ref as O
+        from oracle.parity import unexplained_label_mismatches
+        from oracle import resample as R
+        torch.set_num_threads(max(1, min(cpu_threads, os.cpu_count() or 1)))
+        Pc = O.to_torch_params(detgen.zutis_state_dict(cfg))
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            o = O.zutis_forward(Pc, x[:cpu_images].cpu(), cfg.patch, cfg.dec_heads)
+            lo_ref = O.semantic_logits_lowres(o["patch_tokens"], text.cpu()).numpy()
+            lab_ref = R.bilinear_argmax_nchw(lo_ref, S, S)
+            dtc = time.perf_counter() - t1
+        lo = lo_t[:cpu_images].cpu().numpy()
+        lab = lab_t[:cpu_images].cpu().numpy()
+        err = float(np.abs(lo - lo_ref).max())
+        n_mis, n_bad, worst = unexplained_label_mismatches(lab, lab_ref, lo_ref, err, (S, S))
+        obj["parity"] = {"logit_max_abs_err": err, "label_mismatches": n_mis, "unexplained_label_mismatches": n_bad, "tolerance": 1e-3,
+                         "against": f"fp32 oracle on the first {cpu_images} image(s) of the timed batch, outputs of the timed plans (lane 0)"}
+        obj["cpu_baseline"] = {"value": round(cpu_images / dtc, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{cpu_images} image(s), one pass (oracle forward + 920-class semantic predict)"}
+    for ln in lanes:
+        ln.state["eng"]._bufs.clear()
+    return obj
+
+
+def c5_object(dev, precision="fast", steps=3, cpu_images=1, cpu_threads=16):
+    """BASELINE config 5 on one GPU, bounded: CLIP ViT-L/14@336 `encode_image`, ONE 256-image batch per step, at the reference's own
+    arithmetic class for this config (fp16 on a GPU: utils/extract_image_embeddings.py:43,72-76 -> `fast`).  Weights are random values of
+    the architecture drawn on the device (fp16-valued conv / Linear / attention / proj tensors as convert_weights leaves them); the full
+    line with the deterministic host-generated weights is `bench.py --workload c5`."""
+    from zutis_amd import ops
+    from zutis_amd.engine import ClipImageEncoder
+    D, L, p, g, E, B = 1024, 24, 14, 24, 768, 256
+    gen = torch.Generator(device=dev).manual_seed(5005)
+
+    def w(shape, std, mean=0.0, f16v=True):
+        t = torch.randn(shape, generator=gen, device=dev, dtype=torch.float32) * std + mean
+        return t.half().float() if f16v else t
+    P = {"visual.class_embedding": w((D,), D ** -0.5, f16v=False), "visual.positional_embedding": w((g * g + 1, D), D ** -0.5, f16v=False),
+         "visual.proj": w((D, E), D ** -0.5), "visual.conv1.weight": w((D, 3, p, p), (3 * p * p) ** -0.5)}
+    for ln in ("ln_pre", "ln_post"):
+        P[f"visual.{ln}.weight"], P[f"visual.{ln}.bias"] = w((D,), 0.1, 1.0, False), w((D,), 0.1, 0.0, False)
+    for i in range(L):
+        q = f"visual.transformer.resblocks.{i}."
+        P[q + "attn.in_proj_weight"], P[q + "attn.in_proj_bias"] = w((3 * D, D), D ** -0.5), w((3 * D,), 0.02)
+        P[q + "attn.out_proj.weight"], P[q + "attn.out_proj.bias"] = w((D, D), D ** -0.5 * (2 * L) ** -0.5), w((D,), 0.02)
+        P[q + "mlp.c_fc.weight"], P[q + "mlp.c_fc.bias"] = w((4 * D, D), (2 * D) ** -0.5), w((4 * D,), 0.02)
+        P[q + "mlp.c_proj.weight"], P[q + "mlp.c_proj.bias"] = w((D, 4 * D), D ** -0.5 * (2 * L) ** -0.5), w((D,), 0.02)
+        for ln in ("ln_1", "ln_2"):
+            P[q + ln + ".weight"], P[q + ln + ".bias"] = w((D,), 0.1, 1.0, False), w((D,), 0.1, 0.0, False)
+    enc = ClipImageEncoder(P, p, prefix="visual.", precision=precision)
+    x = torch.randn((B, 3, 336, 336), generator=gen, device=dev, dtype=torch.float32)
+    emb = enc.encode_image(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        emb = enc.encode_image(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    roof = gemm_roofline(ops, lambda: enc.encode_image(x), dt)
+    T = g * g + 1
+    flop = L * (2 * T * (D * 3 * D + D * D + 2 * D * 4 * D) + 4 * T * T * D) + 2 * g * g * 3 * p * p * D + 2 * D * E
+    obj = {"what": f"C5: CLIP ViT-L/14@336 encode_image, one {B}-image batch per step, one stream (`bench.py --workload c5` is the full line)",
+           "value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps, "precision": precision,
+           "dtype": PRECISION_DTYPE[precision], "model_tflops": round(B * flop / dt / 1e12, 1),
+           "precision_note": "the reference runs this config in fp16 on a GPU (clip.load; extract_image_embeddings.py:43,72-76): `fast` is its arithmetic class",
+           "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step", "gemm_share_of_step")}}
+    for an in ("attention_f16x3_tflops", "attention_f16_tflops"):
+        if an in roof:
+            obj["roofline"][an] = roof[an]
+    if cpu_images:
+        from oracle import zutis_ref as O
+        torch.set_num_threads(max(1, min(cpu_threads, os.cpu_count() or 1)))
+        Pc = {k.replace("visual.", "encoder."): v.cpu() for k, v in P.items()}
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            ref = O.clip_encode_image(Pc, x[:cpu_images].cpu(), p)
+            dtc = time.perf_counter() - t1
+        got = emb[:cpu_images].cpu()             # rows of the TIMED step's output (the last of the timed encode_image calls)
+        obj["parity"] = {"embedding_max_abs_err": float((got - ref).abs().max()), "tolerance": 1e-3,
+                         "against": f"fp32 oracle on the first {cpu_images} image(s) of the timed batch (unit-norm embeddings); the compared rows are the timed step's output"}
+        obj["cpu_baseline"] = {"value": round(cpu_images / dtc, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{cpu_images} image(s), one pass (oracle encode_image, 24-layer ViT-L/14@336)"}
+    enc._bufs.clear()
+    return obj

@@ -77,7 +77,28 @@ def _worker(rank, world, port, n_images, q):
         pipe.run(3)                                                      # warm-up group
         pipe.run(7)
         pipe.drain()
-        assert sorted(seen) == list(range(10)) and pipe.next_step == 10
+        assert sorted(seen) == list(range(10)) and pipe.next_step == 10 and pipe.retired == 10
+        # bench.py's proof that the timed gathers saw N ranks (benchlib/headline.py runs exactly this after pipe.drain()): every rank's
+        # payload checksum, all-gathered on its own, against the checksums of the slices of lane 0's gathered buffer
+        v = zd.verify_gather(lanes[0])
+        assert v["verified"] and v["slices_distinct"] and v["ranks_in_gather"] == world and v["bytes_per_rank"] == 24 and v["step"] == lanes[0].step, v
+        keep = lanes[0].gathered.clone()
+        lanes[0].gathered[2 * (1 - rank)] += 1.0                        # the OTHER rank's slice is damaged (on both ranks): caught
+        v = zd.verify_gather(lanes[0])
+        assert not v["verified"] and v["mismatching_slices_on_this_rank"] == [1 - rank], v
+        lanes[0].gathered.copy_(keep)
+        if rank == 1:                                                    # damage on ONE rank only: the verdict is min-reduced, rank 0 sees it too
+            lanes[0].gathered[0, 0] = 7.0
+        v = zd.verify_gather(lanes[0])
+        assert not v["verified"] and v["mismatching_slices_on_this_rank"] == ([0] if rank == 1 else []), v
+        lanes[0].gathered.copy_(torch.cat([lanes[0].payload] * world))   # a "gather" that only ever saw this rank's buffer
+        v = zd.verify_gather(lanes[0])
+        assert not v["verified"] and v["mismatching_slices_on_this_rank"] == [1 - rank], v
+        lanes[0].gathered.copy_(keep)
+        same = zd.Lane(torch.ones((2, 3)), gathered=torch.ones((2 * world, 3)))       # identical data on every rank: verified, but flagged
+        same.step = 0
+        v = zd.verify_gather(same)
+        assert v["verified"] and not v["slices_distinct"], v
         nog = zd.StepPipeline([zd.Lane(torch.zeros(1)) for _ in range(2)], lambda g_, ids: seen.extend(-i - 1 for i in ids), gather=False)
         nog.run(5); nog.drain()
         assert [s for s in seen if s < 0] == [-1, -2, -3, -4, -5]

@@ -47,6 +47,36 @@ def all_reduce_confusion(hist: torch.Tensor, group=None) -> torch.Tensor:
     return hist
 
 
+def payload_checksum(t: torch.Tensor) -> torch.Tensor:
+    """Two wrapping int64 sums over the BITS of `t` (4-byte elements): the plain sum and a position-weighted one (a permutation of
+    rows, a stale or a zeroed slice all change it).  [2] int64 on t's device."""
+    v = t.contiguous().view(torch.int32).to(torch.int64).flatten()
+    w = torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 65521 + 1
+    return torch.stack([v.sum(), (v * w).sum()])
+
+
+def verify_gather(lane: "Lane", group=None) -> dict:
+    """Did the all-gather of `lane` (retired: call after StepPipeline.drain) really see every rank?  Every rank checksums its own
+    payload of the lane's last step; the [world, 2] checksums are all-gathered on their own; slice r of `lane.gathered` must
+    checksum to rank r's entry — on EVERY rank (the verdict is min-reduced) — and, when the ranks ran different data, the entries
+    differ from one another (a gather that only ever saw this rank's buffer would pass a self-comparison).  New code: the
+    reference evaluates on a single device (main.py:54) and has no collective to compare with."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b = lane.payload.shape[0]
+    assert lane.pending is None and lane.gathered is not None and lane.gathered.shape[0] == world * b, "verify_gather: drain the pipeline first"
+    mine = payload_checksum(lane.payload)
+    flat = torch.empty((world * 2,), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    sums = flat.view(world, 2)
+    got = torch.stack([payload_checksum(lane.gathered[r * b:(r + 1) * b]) for r in range(world)])
+    ok = torch.tensor([int(torch.equal(got, sums))], dtype=torch.int64, device=mine.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    rows = [tuple(r) for r in sums.tolist()]
+    return {"ranks_in_gather": world, "verified": bool(ok.item() == 1), "slices_distinct": len(set(rows)) == world,
+            "bytes_per_rank": int(lane.payload.numel() * lane.payload.element_size()), "step": int(lane.step),
+            "mismatching_slices_on_this_rank": [r for r in range(world) if not torch.equal(got[r], sums[r])]}
+
+
 class Lane:
     """One evaluation step in flight: `payload` is the tensor the step's kernels write and the collective reads (low-res class
     logits), `gathered` the all-gather destination, `stream` the HIP stream its work is enqueued on (None on CPU), `state`
@@ -71,6 +101,7 @@ class StepPipeline:
     def __init__(self, lanes, launch, gather: bool, group=None, consume=None):
         self.lanes, self.launch, self.gather, self.group, self.consume = list(lanes), launch, gather, group, consume
         self.next_step = 0
+        self.retired = 0                      # gathers waited for (== steps run once drained)
 
     def _on_stream(self, lane):
         import contextlib
@@ -81,6 +112,7 @@ class StepPipeline:
             with self._on_stream(lane):
                 lane.pending.wait()
             lane.pending = None
+            self.retired += 1
             if self.consume is not None:
                 self.consume(lane, lane.step)
 
