@@ -42,7 +42,7 @@ from benchlib.lanes import build_lanes, check_timed_outputs, make_launch        
 from benchlib.launch import launch_ranks, rank_launch_command                                                  # noqa: E402,F401
 from benchlib.roofline import gemm_roofline, live_pmc_traffic                                                  # noqa: E402,F401
 from benchlib.c3 import batch1_object, c3_model, c3_parity                                                     # noqa: E402,F401
-from benchlib.objects import c4_object, c5_object, pseudo_label_object, solver_object                          # noqa: E402,F401
+from benchlib.objects import c4_object, c5_object, natural_images, pseudo_label_object, solver_object                          # noqa: E402,F401
 
 
 def main():

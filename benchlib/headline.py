@@ -185,7 +185,7 @@ def run(args):
         c5o = c5_object(dev, "fast", cpu_images=ncpu, cpu_threads=args.cpu_threads)
         torch.cuda.empty_cache()
         solvero = solver_object(dev)
-        pseudoo = pseudo_label_object(dev, args.precision)
+        pseudoo = pseudo_label_object(dev, args.precision, cpu=not args.no_cpu_baseline, cpu_threads=args.cpu_threads)
     if rank == 0:
         total_images = world * B * args.steps
         line = {
@@ -255,6 +255,8 @@ def run(args):
             sm["solver_frac"] = [solvero["batch1"]["frac"], solvero["batch8"]["frac"]]
         if pseudoo:
             sm["selfmask_solver_ips"] = pseudoo["value"]
+            sm["pseudo"] = {"frac": pseudoo["roofline"]["frac"], **({"bad_px": pseudoo["parity"]["differing_pixels_off_the_oracle_contour"],
+                                                                    "diff_px": pseudoo["parity"]["differing_pixels"]} if "parity" in pseudoo else {})}
         if io_rates:
             sm["io"] = [io_rates["d2h"]["value"], io_rates["h2d_d2h"]["value"]]
         line["summary"] = sm

@@ -40,28 +40,76 @@ def solver_object(dev, reps=20):
     return solver
 
 
-def pseudo_label_object(dev, precision="exact", B=4, reps=5):
-    """The pseudo-label path north_star names (SelfMask, networks/selfmask + utils/bilateral_solver.py, as datasets/*.py
+def natural_images(B, H, W, dev, seed=7):
+    """B normalised images [B,3,H,W] with natural-image colour statistics (detgen.selfmask_like_rgb: gradients, blobs, 5 % noise —
+    the bilateral solver's lattice then has ~20 k vertices as on photographs; pure noise images give it one vertex per pixel)."""
+    from zutis_amd import detgen
+    mean = np.array([0.485, 0.456, 0.406], np.float32)
+    std = np.array([0.229, 0.224, 0.225], np.float32)
+    xs = [((detgen.selfmask_like_rgb(H, W, seed=seed + i).astype(np.float32) / 255.0 - mean) / std).transpose(2, 0, 1) for i in range(B)]
+    return torch.from_numpy(np.ascontiguousarray(np.stack(xs))).to(dev)
+
+
+SELFMASK_FLOPS_PER_IMAGE = 792e9     # SURVEY.md §8(d): DINO ViT-S/8 @512x683 (T = 5505) + 6-layer decoder
+
+
+def pseudo_label_object(dev, precision="exact", B=4, reps=5, cpu=True, cpu_threads=16):
+    """The pseudo-label path north_star names (SelfMask, networks/selfmask + utils/bilateral_solver.py, as datasets/index_dataset.py:177-226
     generate_pseudo_masks drives them): DINO ViT-S/8 SelfMask at its working shape 512x683 (T = 5505 tokens) -> query selection ->
     bilateral solver -> > 0.5 -> nearest resize to 480x640, `B` images per call, device side (the RLE JSON files are host work).
-    Parity of this path is held by tests/test_e2e_gpu.py::test_selfmask_* (reference goldens + the oracle at 512x683) and
-    tests/test_bilateral_gpu.py; synthetic noise images give the solver one lattice vertex per pixel (17x a natural image's)."""
-    from zutis_amd import detgen, pseudo_masks
+    Measured like the headline: value on images with natural colour statistics, `roofline` with the flash-attention kernel as the
+    dominant kernel, `parity` of image 0's final mask against the oracle chain, a bounded `cpu_baseline` (the oracle chain, one image)."""
+    from zutis_amd import detgen, ops, pseudo_masks
     from zutis_amd.engine import SelfMaskEngine
-    H, W = 512, 683
-    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()}, precision=precision)
-    x = torch.from_numpy(detgen.images(B, H, W, seed=7)).to(dev)
-    for _ in range(2):
-        pseudo_masks.pseudo_masks_batch(eng, x, [(480, 640)] * B, True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pseudo_masks.pseudo_masks_batch(eng, x, [(480, 640)] * B, True)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    from .roofline import attention_roofline
+    H, W, out_size = 512, 683, (480, 640)
+    sd = detgen.selfmask_state_dict()
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, precision=precision)
+
+    def timed(x):
+        for _ in range(2):
+            pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * B, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            masks = pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * B, True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, masks
+    x = natural_images(B, H, W, dev)
+    dt, masks = timed(x)
+    roof = attention_roofline(ops, lambda: pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * B, True), dt)
+    dt_noise, _ = timed(torch.from_numpy(detgen.images(B, H, W, seed=7)).to(dev))
+    obj = {"what": f"SelfMask (DINO ViT-S/8 @{H}x{W}, T = 5505) + bilateral solver + threshold + nearest resize to {out_size[0]}x{out_size[1]}, "
+                   f"{B} images per call, device side (datasets/index_dataset.py:177-226)",
+           "value": round(B / dt, 1), "unit": "images/s", "ms_per_call": round(dt * 1e3, 2), "batch": B, "precision": precision, "calls": reps,
+           "images": "natural colour statistics (detgen.selfmask_like_rgb, normalised): ~20 k lattice vertices per image",
+           "value_noise_images": round(B / dt_noise, 1),
+           "value_noise_images_note": "the workload rounds 2-5 quoted: N(0,1) images give the solver one lattice vertex per pixel (17x a photograph's)",
+           "model_tflops": round(B * SELFMASK_FLOPS_PER_IMAGE / dt / 1e12, 1), "flops_per_image": SELFMASK_FLOPS_PER_IMAGE, "roofline": roof}
+    if cpu:
+        from oracle import zutis_ref as O
+        from oracle.parity import contour_mismatches, pseudo_mask_chain
+        torch.set_num_threads(max(1, min(cpu_threads, os.cpu_count() or 1)))
+        Pc = O.to_torch_params(sd)
+        t1 = time.perf_counter()
+        ref = pseudo_mask_chain(Pc, x[:1].cpu(), out_size)
+        dtc = time.perf_counter() - t1
+        got = masks[0].cpu().numpy().astype(bool)                 # image 0 of the LAST timed call
+        inf = eng.forward(x[:1].contiguous(), inference=True)
+        n_sm, bad_sm = contour_mismatches(inf["dts"][0].cpu().numpy(), ref["selfmask"])
+        n_diff, n_bad = contour_mismatches(got, ref["mask"], native=ref["mask_native"])
+        obj["parity"] = {"mask_pixels": int(got.size), "differing_pixels": n_diff, "differing_pixels_off_the_oracle_contour": n_bad,
+                         "selfmask_differing_pixels": n_sm, "selfmask_differing_pixels_off_the_oracle_contour": bad_sm,
+                         "selected_query_identical": bool(int(inf["index"][0]) == ref["query"]) if "index" in inf else None,
+                         "oracle_objectness_margin": round(ref["objectness_margin"], 5),
+                         "against": "the oracle chain on image 0 of the timed batch (oracle/parity.py::pseudo_mask_chain: SelfMask inference -> "
+                                    "scipy bilateral solver -> > 0.5 -> nearest resize); a differing pixel is explained when it lies within one "
+                                    "pixel of the oracle's own mask contour"}
+        obj["cpu_baseline"] = {"value": round(1.0 / dtc, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "ONE 512x683 image, one pass of the oracle chain (torch fp32 SelfMask on %d threads + numpy / scipy.sparse "
+                                         "bilateral solver on one)" % torch.get_num_threads()}
     eng._bufs.clear()
-    return {"what": f"SelfMask (DINO ViT-S/8 @{H}x{W}, T = 5505) + bilateral solver + threshold + nearest resize, {B} images per call, device side",
-            "value": round(B / dt, 1), "unit": "images/s", "ms_per_call": round(dt * 1e3, 2), "batch": B, "precision": precision, "calls": reps}
+    return obj
 
 
 def c4_object(P, cfg, dev, precision, steps=12, warmup=4, n_lanes=3, cpu_images=1, cpu_threads=16):

@@ -138,3 +138,48 @@ def gemm_roofline(ops, run_once, step_seconds):
             roof[an + "_tflops"] = round(fa / ta / 1e12, 1)
             roof[an + "_share_of_step"] = round(ta / step_seconds, 3)
     return roof
+
+
+def launch_profile(ops, run_once, passes=2):
+    """HIP events around every profiled launch (ops.PROFILER) of `run_once()`, eager on torch's current stream (== the launch stream).
+    Returns {family: (launches, algorithmic flops, seconds)} of the last pass."""
+    prof = {}
+
+    def profiler(name, work, launch):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = launch()
+        e1.record()
+        prof.setdefault(name, []).append((work, e0, e1))
+        return r
+    ops.PROFILER = profiler
+    try:
+        for _ in range(passes):
+            prof.clear()
+            run_once()
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    fl = lambda w: w[0] if isinstance(w, tuple) else w
+    return {k: (len(v), sum(fl(w) for w, _, _ in v), sum(a.elapsed_time(b) for _, a, b in v) * 1e-3) for k, v in prof.items()}
+
+
+def attention_roofline(ops, run_once, step_seconds):
+    """Roofline object with the flash-attention kernel as the dominant kernel (the SelfMask pseudo-label path at T = 5505: attention is
+    half of its GPU time).  Algorithmic flops = 4 * Tq * Tk * dh per (image, head); the split-pair form issues three MFMA products per
+    algorithmic product in QK^T and in P.V, so its ceiling is a third of the dense fp16 MFMA peak."""
+    stats = launch_profile(ops, run_once)
+    fam = max((k for k in stats if k.startswith("attention")), key=lambda k: stats[k][2])
+    nl, fl, tt = stats[fam]
+    npr = 3 if fam.endswith("x3") else 1
+    peak = MFMA_F16_DENSE_PEAK_TFLOPS / npr
+    ach = fl / tt / 1e12
+    gem = {k: v for k, v in stats.items() if k.startswith("gemm")}
+    gt = sum(v[2] for v in gem.values())
+    return {"bound": "mfma", "kernel": "attn_f16_kernel (zh_attention_f16" + (", split-pair operands: three MFMA products per product)" if npr == 3 else ")"),
+            "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "flops_per_launch": round(fl / nl), "launches_per_step": nl, "avg_launch_us": round(tt / nl * 1e6, 1),
+            "attention_share_of_step": round(tt / step_seconds, 3), "gemm_share_of_step": round(gt / step_seconds, 3),
+            "gemm_algorithmic_tflops": round(sum(v[1] for v in gem.values()) / gt / 1e12, 1) if gt else None,
+            "executed_algorithmic_flops_per_step": round(sum(v[1] for k, v in stats.items() if k.startswith(("gemm", "attention")))),
+            "measured_on": "HIP events around every attention / GEMM launch of an instrumented eager call on one stream"}

@@ -59,8 +59,10 @@ int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small);
 
 /* DEVELOPER entry: the big plain-fp16 GEMM tiles (256 x 256 / 256 x 192) are persistent — `workgroups` of them walk a launch's tiles and
  * request the next tile's first K slices under the current tile's epilogue (csrc/gemm_kernel.h PERS; bitwise the one-workgroup-per-
- * tile results).  Default 256 (one per CU; ZH_GEMM_PERSIST read once); 0 = one workgroup per tile; any multiple of 8 forces that many
- * (tests use 8 to make small problems walk several tiles per workgroup).  Process-wide. */
+ * tile results).  Default (-1): the current device's CU count rounded down to a multiple of 8, resolved at the first launch (256 on an
+ * MI355X in SPX mode; ZH_GEMM_PERSIST, validated the same way, read once); 0 = one workgroup per tile; any multiple of 8 forces that
+ * many (tests use 8 to make small problems walk several tiles per workgroup).  Process-wide: the library's one mutable word that
+ * steers product launches, written only here. */
 int zh_dev_set_gemm_persist(int workgroups);
 
 /* C[b][m][n] = act(sum_k A[b][m][k]*W[b][n][k] + bias[n] + pos[m][n]) + residual[b][m % res_rows][n]

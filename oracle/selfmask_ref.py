@@ -74,10 +74,12 @@ def selfmask_forward(P: Dict[str, Tensor], x: Tensor, patch: int = 8, heads: int
     return {"objectness": torch.sigmoid(o)[:, None], "mask_pred": mask, "objectness_logits": o[..., 0]}
 
 
-def selfmask_inference(P: Dict[str, Tensor], x: Tensor, patch: int = 8, heads: int = 6):
-    """selfmask.py:204-224: x4 bilinear, crop to the input size, pick the argmax-objectness query, > 0.5 -> uint8."""
+def selfmask_inference(P: Dict[str, Tensor], x: Tensor, patch: int = 8, heads: int = 6, out=None):
+    """selfmask.py:204-224: x4 bilinear, crop to the input size, pick the argmax-objectness query, > 0.5 -> uint8.
+    (`out`: a selfmask_forward result for the same x, to save the second forward.)"""
     B, _, H, W = x.shape
-    out = selfmask_forward(P, x, patch, heads)
+    if out is None:
+        out = selfmask_forward(P, x, patch, heads)
     mp = out["mask_pred"][:, 0].numpy()
     up = R.bilinear_nchw(mp, 4 * mp.shape[2], 4 * mp.shape[3])[..., :H, :W]
     idx = out["objectness_logits"].argmax(dim=1).numpy()

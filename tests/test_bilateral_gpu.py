@@ -86,6 +86,24 @@ def test_solver_empty_target_is_zeros_like_the_reference(dev, golden_dir):
     assert not sb[0].any() and np.abs(sb[1] - g["a_soft"]).max() < 1e-9 and [int(v) for v in st.cpu().numpy()[:, 1]] == [0, 25]
 
 
+def test_solver_cg_tol_zero_iterates_to_maxiter_like_scipy(dev):
+    """cg_tol = 0 makes atol = rtol * ||b|| zero although b is not: scipy (and the oracle's restated loop) then run all `cg_maxiter`
+    iterations — only ||b|| == 0 itself returns early (round-5 advisor: the device loop used atol == 0 as that flag and stopped at x0)."""
+    from zutis_amd import ops, detgen
+    from oracle import bilateral_ref as B
+    rgb = detgen.selfmask_like_rgb(96, 128, seed=3)
+    yy, xx = np.mgrid[:96, :128]
+    target = (((yy - 50) ** 2 + (xx - 60) ** 2) < 30 ** 2).astype(np.uint8)
+    grid = B.Grid(rgb)
+    ref, its, _, _ = B.solve(grid, target.reshape(-1).astype(np.float64), np.full(target.size, 0.999), cg_tol=0.0, cg_maxiter=9)
+    soft, stats = ops.bilateral_solve(torch.from_numpy(rgb).to(dev), torch.from_numpy(target).to(dev), cg_tol=0.0, cg_maxiter=9)
+    assert its == 9 and int(stats.cpu().numpy().reshape(-1)[1]) == 9
+    assert np.abs(soft.cpu().numpy().reshape(-1) - ref).max() < 1e-9
+    # and the empty target still returns at iteration 0 with cg_tol = 0
+    soft0, st0 = ops.bilateral_solve(torch.from_numpy(rgb).to(dev), torch.from_numpy(np.zeros_like(target)).to(dev), cg_tol=0.0, cg_maxiter=9)
+    assert int(st0.cpu().numpy().reshape(-1)[1]) == 0 and not soft0.cpu().numpy().any()
+
+
 def test_solver_vs_oracle_selfmask_size(dev):
     """Full SelfMask-style size (512x683, V ~ 10^4-10^5): round trip against the oracle + float target path."""
     from zutis_amd import ops, detgen
@@ -114,23 +132,52 @@ def test_resize_nearest_bit_exact(dev):
 
 
 def test_pseudo_mask_driver_end_to_end(dev, tmp_path):
-    """SelfMask -> device bilateral solver -> nearest resize -> RLE JSON, against the oracle chain on the same inputs."""
+    """SelfMask -> device bilateral solver -> nearest resize -> RLE JSON, against the oracle chain on the same inputs, at the engine's
+    default precision (`exact`: fp32-class contractions).  The masks may differ only where a soft value sits within rounding of a 0.5
+    threshold: every differing pixel lies within one (source) pixel of the oracle's own mask contour, and there are few of them."""
     from zutis_amd import detgen, pseudo_masks, rle
     from zutis_amd.engine import SelfMaskEngine
-    from oracle import selfmask_ref as S, bilateral_ref as B, zutis_ref as O
+    from oracle import zutis_ref as O
+    from oracle.parity import contour_mismatches, pseudo_mask_chain
     import json
     eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in detgen.selfmask_state_dict().items()})
+    assert eng.precision == "exact"
     x = torch.from_numpy(detgen.images(1, 72, 100, seed=11))[0]
     p = str(tmp_path / "m" / "a.json")
     pseudo_masks.generate_pseudo_masks(eng, [x.to(dev)], [(144, 200)], [p])
     got = rle.decode(json.load(open(p))).astype(bool)
     assert got.shape == (144, 200)
-    with torch.no_grad():
-        dts, _, _ = S.selfmask_inference(O.to_torch_params(detgen.selfmask_state_dict()), x[None])
-    soft, _ = B.bilateral_solver_output(B.denormalize_to_u8(x.numpy()), dts[0])
-    ref = (soft > 0.5)
-    ref = ref[(np.arange(144) * np.float32(72 / 144)).astype(int)][:, (np.arange(200) * np.float32(100 / 200)).astype(int)]
-    assert (got != ref).mean() < 1e-2          # the SelfMask mask itself comes from fp16-MFMA logits
+    ref = pseudo_mask_chain(O.to_torch_params(detgen.selfmask_state_dict()), x[None], (144, 200))
+    n_diff, n_bad = contour_mismatches(got, ref["mask"], native=ref["mask_native"])
+    print(f"pseudo-mask chain 72x100 -> 144x200 [exact]: {n_diff} of {got.size} pixels differ, {n_bad} off the oracle's contour")
+    assert n_bad == 0 and n_diff <= 64, (n_diff, n_bad)          # <= 16 source pixels (each is a 2 x 2 block after the resize)
+
+
+def test_pseudo_mask_chain_at_the_working_shape_512x683(dev, tmp_path):
+    """The whole pseudo-label chain at the shape the pipeline runs it (datasets/index_dataset.py:177-226: 512 on the short side, T = 5505
+    tokens; natural colour statistics so the solver's lattice is photograph-sized): SelfMask -> solver -> > 0.5 -> nearest resize to the
+    file's 480x640 -> RLE JSON -> decode, against the oracle chain; and the batched driver writes the same file."""
+    from zutis_amd import detgen, pseudo_masks, rle
+    from zutis_amd.engine import SelfMaskEngine
+    from oracle import zutis_ref as O
+    from oracle.parity import contour_mismatches, pseudo_mask_chain
+    import json
+    import bench
+    H, W, out = 512, 683, (480, 640)
+    sd = detgen.selfmask_state_dict()
+    eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in sd.items()})
+    x = bench.natural_images(2, H, W, dev, seed=7)
+    pa, pb = str(tmp_path / "one" / "a.json"), [str(tmp_path / "batch" / f"{i}.json") for i in range(2)]
+    pseudo_masks.generate_pseudo_masks(eng, [x[0]], [out], [pa], n_streams=1)
+    pseudo_masks.generate_pseudo_masks_batched(eng, [x[0], x[1]], [out, out], pb, batch_size=2)
+    assert open(pa).read() == open(pb[0]).read()
+    got = rle.decode(json.load(open(pa))).astype(bool)
+    ref = pseudo_mask_chain(O.to_torch_params(sd), x[:1].cpu(), out)
+    assert ref["objectness_margin"] > 1e-3                       # the selected query is unambiguous for this image
+    n_diff, n_bad = contour_mismatches(got, ref["mask"], native=ref["mask_native"])
+    print(f"pseudo-mask chain 512x683 -> 480x640 [exact]: {n_diff} of {got.size} pixels differ, {n_bad} off the oracle's contour; "
+          f"mask covers {got.mean():.3f}")
+    assert 0.02 < ref["mask"].mean() < 0.98 and n_bad == 0 and n_diff <= 200, (n_diff, n_bad)
 
 
 def test_pseudo_mask_pipeline_matches_sequential(dev, tmp_path):

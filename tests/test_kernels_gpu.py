@@ -213,7 +213,7 @@ def test_gemm_persistent_tiles_are_bitwise_one_workgroup_per_tile(dev, tile, N):
                     assert torch.equal(h1, h0) and torch.equal(o1, o0), (tile, K, batch, g)
     finally:
         L.zh_dev_set_gemm_overrides(0, 0, 0)
-        L.zh_dev_set_gemm_persist(256)
+        L.zh_dev_set_gemm_persist(-1)            # back to the default: the device's CU count
 
 
 def test_gemm_forced_tile_is_really_forced(dev):
@@ -394,6 +394,18 @@ def test_upsample_argmax_bit_exact(dev, golden_dir):
     ops.upsample_argmax(torch.from_numpy(x).to(dev), lab, 1, 150, 32, 32, 518, 518)
     ref = R.bilinear_argmax_nchw(x, 518, 518)
     assert np.array_equal(lab.cpu().numpy(), ref) and not (ref == 140).any()
+    # ties INSIDE a group of four classes (the round-6 kernel resolves the index from the group's maximum: the first equal value), across
+    # groups of one chunk, and between -0.0 and +0.0 (equal: the first index wins); class counts that are not multiples of four
+    for n in (6, 37, 81):
+        x = -np.abs(_randn((2, n, 12, 12), 74 + n).numpy()) - 0.5
+        x[0, 1] = x[0, 3] = np.abs(x[0, 3])                      # same group, first and third member
+        x[1, 2] = -0.0; x[1, 5] = 0.0                            # -0.0 (class 2) before +0.0 (class 5): equal, class 2 wins
+        if n > 36:
+            x[0, 33] = x[0, 1]                                   # and again in the next chunk: never replaces
+        lab = torch.empty((2, 96, 100), dtype=torch.int64, device=dev)
+        ops.upsample_argmax(torch.from_numpy(x).to(dev), lab, 2, n, 12, 12, 96, 100)
+        ref = R.bilinear_argmax_nchw(x, 96, 100)
+        assert np.array_equal(lab.cpu().numpy(), ref) and (ref[0] == 1).all() and (ref[1] == 2).all()
     # NaN logits: torch.argmax / np.argmax take the FIRST NaN as the maximum; -inf everywhere -> index 0
     x = _randn((2, 40, 6, 6), 73).numpy()
     x[0, 35, 2, 3] = np.nan; x[0, 3, 2, 3] = np.nan; x[1, :, 4:, 4:] = -np.inf; x[1, 20, 0, 0] = np.inf

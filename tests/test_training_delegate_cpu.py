@@ -179,3 +179,68 @@ def test_delegate_is_the_real_reference(monkeypatch):
                   or k in ("clip", "torchvision", "torchvision.ops", "pycocotools", "pycocotools.mask", "zutis_reference_networks_zutis")]:
             del sys.modules[m]
         sys.modules.update(saved)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "networks")), reason="needs the reference checkout (authoring container only)")
+def test_keep_reference_helper_leaves_the_overlay_canonical(monkeypatch):
+    """`keep_reference_for_training(<reference>/networks/zutis.py)` (round-5 advisor: the hand-written alias left the reference's
+    `networks` / `utils` cached and the overlay was silently never loaded): the reference's class becomes the delegate, and afterwards
+    `networks.zutis`, `utils.running_score`, ... are still the overlay's modules — a later `from networks.zutis import ZUTIS`
+    (utils/utils.py:166-174) gets the HIP module."""
+    sys.path.insert(0, REPO)
+    from oracle import gen_golden as G
+    cfg = detgen.TINY
+    keep = ("clip", "torchvision", "torchvision.ops", "pycocotools", "pycocotools.mask")
+    saved = {k: v for k, v in sys.modules.items() if k == "networks" or k.startswith("networks.") or k == "utils" or k.startswith("utils.") or k in keep}
+    path0 = list(sys.path)
+    try:
+        G.install_stubs(cfg)
+        for m in [k for k in sys.modules if k == "networks" or k.startswith("networks.") or k == "utils" or k.startswith("utils.")]:
+            del sys.modules[m]
+        sys.modules.pop("zutis_reference_networks_zutis", None)
+        sys.path.insert(0, DROPIN)
+        import networks.zutis as NZ
+        import utils.running_score as RS
+        assert NZ.__file__.startswith(DROPIN) and RS.__file__.startswith(DROPIN) and NZ.reference_zutis_class() is None
+        cls = NZ.keep_reference_for_training(os.path.join(REF, "networks", "zutis.py"))
+        assert cls.__module__ == "zutis_reference_networks_zutis" and NZ.reference_zutis_class() is cls and cls is not NZ.ZUTIS
+        import importlib
+        assert importlib.import_module("networks.zutis") is NZ and sys.modules["networks"].__file__.startswith(DROPIN)
+        assert importlib.import_module("utils.running_score") is RS and sys.modules["utils"].__file__.startswith(DROPIN)
+        from networks.zutis import ZUTIS as again
+        assert again is NZ.ZUTIS
+        with pytest.raises(ImportError):
+            NZ.keep_reference_for_training(NZ.__file__)            # the overlay's own file is not a reference
+        assert NZ.reference_zutis_class() is None or NZ.reference_zutis_class() is not NZ.ZUTIS
+    finally:
+        sys.path[:] = path0
+        for m in [k for k in sys.modules if k == "networks" or k.startswith("networks.") or k == "utils" or k.startswith("utils.")
+                  or k in keep + ("zutis_reference_networks_zutis",)]:
+            del sys.modules[m]
+        sys.modules.update(saved)
+
+
+def test_delegate_follows_update_text_embeddings(monkeypatch):
+    """The delegate's text_embeddings is re-bound on every call (it was bound once and went stale after update_text_embeddings)."""
+    cfg = detgen.A4_TINY
+    NZ = _overlay(monkeypatch, cfg)
+
+    class Fake(nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+            inner = NZ.ZUTIS(**kw)
+            for n, m in inner.named_children():
+                self.add_module(n, m)
+            self.query_embed = inner.query_embed
+            self.text_embeddings = None
+
+        def forward(self, x):
+            return {"te": self.text_embeddings}
+    mod = types.ModuleType("zutis_reference_networks_zutis")
+    mod.ZUTIS = Fake
+    monkeypatch.setitem(sys.modules, "zutis_reference_networks_zutis", mod)
+    net = _make(NZ, cfg).train()
+    x = torch.from_numpy(detgen.images(1, 4 * cfg.patch, 5 * cfg.patch))
+    assert net(x)["te"] is net.text_embeddings
+    net.text_embeddings = torch.ones((2, cfg.embed_dim))          # what update_text_embeddings() does (zutis.py:333-338)
+    assert net(x)["te"] is net.text_embeddings

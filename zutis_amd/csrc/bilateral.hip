@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void bg_splat_final_kernel(const unsigned* cnt
   // conf added j times, IN ORDER (the very chain the per-vertex loops below walked: a vertex holds up to a spatial cell's pixels, a few
   // hundred, and a wave waited for its longest chain twice — 17.5 us of a 0.27-ms solve).  One thread walks the chain once per block into
   // LDS; every vertex looks its two sums up.  Counts beyond the table fall back to the loop.
-  constexpr int SPLAT_TAB = 320;      // >= (sigma_spatial + 2)^2 at the reference's sigma_spatial = 16: a spatial cell's pixels
+  constexpr int SPLAT_TAB = 320;      // a spatial cell holds up to (sigma_spatial + 2)^2 = 324 pixels at the reference's sigma_spatial = 16: counts 321 .. 324 take the loop below
   __shared__ double conf_times[SPLAT_TAB + 1];
   if (threadIdx.x == 0) {
     double a = 0.0;
@@ -491,19 +491,21 @@ __global__ __launch_bounds__(256) void cg_step_kernel(CgPtrs c0, int it, int las
   double alpha = 0.0, beta = 0.0;
   const double* pin = c.part + (size_t)((it + 1) & 1) * 3 * c.nblocks;
   double* pout = c.part + (size_t)(it & 1) * 3 * c.nblocks;
-  const double flag = c.sc[3], atol = c.sc[2];                               // both written by EARLIER kernels only
+  const double flag = c.sc[3], atol = c.sc[2], bzero = c.sc[7];               // all written by EARLIER kernels only
   const double gp = c.sc[it >= 1 ? ((it - 1) & 1) : 0], ap = c.sc[it >= 1 ? 5 + ((it - 1) & 1) : 5];
   if (it < 0) {
     const double bb = sum_partials(pin, nb, red);                           // atol = rtol * ||b||
-    if (blockIdx.x == 0 && threadIdx.x == 0) c.sc[2] = c.rtol * sqrt(bb);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc[2] = c.rtol * sqrt(bb); c.sc[7] = bb == 0.0 ? 1.0 : 0.0; }
   } else {
     if (flag != 0.0) return;                                                // converged earlier
     double gamma = 0.0, delta = 0.0, rr = 0.0;
     for (int i = threadIdx.x; i < nb; i += 256) { gamma += pin[i]; delta += pin[c.nblocks + i]; rr += pin[2 * c.nblocks + i]; }
     block_sum3(gamma, delta, rr, red);
-    // SciPy's test at the top of iteration `it`; and its `if bnrm2 == 0: return b` (atol = rtol ||b|| = 0: an EMPTY target — the
-    // pseudo-labeller found nothing — solves to zeros without iterating; x0 = b / w is already 0 there, where the loop would form 0 / 0)
-    if (sqrt(rr) < atol || atol == 0.0) {
+    // SciPy's test at the top of iteration `it`; and its `if bnrm2 == 0: return b` (||b|| = 0: an EMPTY target — the
+    // pseudo-labeller found nothing — solves to zeros without iterating; x0 = b / w is already 0 there, where the loop would form 0 / 0).
+    // The flag is ||b|| == 0 itself, recorded by K(-1): atol = rtol ||b|| is ALSO zero for cg_tol = 0 (or an underflowing product),
+    // where SciPy iterates to maxiter (round-5 advisor)
+    if (sqrt(rr) < atol || bzero != 0.0) {
       if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc[3] = 1.0; c.sc[4] = (double)it; }
       return;
     }

@@ -40,11 +40,34 @@ extern "C" int zh_dev_set_gemm_overrides(int group_m, int tile, int tile_small) 
   return ZH_OK;
 }
 
-// persistent big-tile GEMMs (gemm_kernel.h PERS): workgroups per launch = CUs of the chip; developer override for tests / A-B
-static int g_gemm_persist = [] { const char* e = getenv("ZH_GEMM_PERSIST"); return e ? atoi(e) : 256; }();
-int gemm_persist_cus() { return g_gemm_persist; }
+// persistent big-tile GEMMs (gemm_kernel.h PERS): workgroups per launch = the CUs of the CURRENT device rounded down to a multiple
+// of 8 (a persistent workgroup takes a CU's whole LDS; the tile walk deals ids modulo 8 to the XCDs) — 256 on an MI355X in SPX mode,
+// fewer in a partitioned mode.  Resolved at the first launch (no HIP call at load time: build() loads the library without a GPU) and
+// cached per process; ZH_GEMM_PERSIST / zh_dev_set_gemm_persist override it for tests and A/B runs (0 = off, else a multiple of 8).
+// The one mutable word that steers product launches: written only by the developer setter, read once per launch.
+static int gemm_persist_valid(int n) { return n >= 0 && n % 8 == 0; }
+static int g_gemm_persist = [] {
+  const char* e = getenv("ZH_GEMM_PERSIST");
+  if (!e) return -1;                                    // auto
+  char* end = nullptr;
+  const long v = strtol(e, &end, 10);
+  if (end == e || *end != 0 || v < 0 || v > (1 << 20) || !gemm_persist_valid((int)v)) {
+    fprintf(stderr, "zutis_hip: ZH_GEMM_PERSIST=%s ignored (not 0 or a multiple of 8)\n", e);
+    return -1;
+  }
+  return (int)v;
+}();
+int gemm_persist_cus() {
+  if (g_gemm_persist >= 0) return g_gemm_persist;
+  static const int auto_cus = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) return 256;
+    return cus / 8 * 8;
+  }();
+  return auto_cus;
+}
 extern "C" int zh_dev_set_gemm_persist(int workgroups) {
-  ZH_CHECK_ARG(workgroups >= 0 && workgroups % 8 == 0, "zh_dev_set_gemm_persist: %d is not 0 (off) or a multiple of 8", workgroups);
+  ZH_CHECK_ARG(workgroups >= -1 && (workgroups == -1 || gemm_persist_valid(workgroups)), "zh_dev_set_gemm_persist: %d is not -1 (auto), 0 (off) or a multiple of 8", workgroups);
   g_gemm_persist = workgroups;
   return ZH_OK;
 }

@@ -407,6 +407,160 @@ __global__ __launch_bounds__(256) void upsample_argmax_lds_kernel(const float* l
   }
 }
 
+// ---- round 6: the same tile walk with classes innermost in LDS, so that one ds_read_b128 brings FOUR classes of a pixel's row value
+// and the two interpolation steps run as v_pk_mul_f32 / v_pk_fma_f32 on two classes at once (each half is the same IEEE multiply /
+// fused multiply-add the scalar form does: bit-identical values), and the arg-max walks groups of four: two v_max3 give the group's
+// maximum, ONE compare decides whether any of the four beats the running best (strict >: the first maximum stays), and only a wave in
+// which some lane's best moved resolves WHICH of the four it was (first value equal to the group's maximum = torch's first-index
+// rule).  Per (pixel, class): 0.5 packed arithmetic + 1 max / compare / select + 0.5 LDS b128 instead of 5 VALU + 2 ds_read_b32.
+// What is class-independent (source rows / columns, the four weights) is computed once per tile as before.  The low-res window of
+// the NEXT class chunk is fetched into registers while this chunk is interpolated and compared.
+// profiles/NOTES.md round 6: 920 classes @518 px, 8 images: 830 us -> see there.
+#define UA_CHP (UA_CH + 4)              // class stride in LDS (floats): 16-byte aligned, and lanes 36 floats apart spread over all 64 banks
+#define UA_NPF 8                        // window values a thread carries for the next chunk (window <= 64 low-res pixels)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t ua_pk_mul(f32x2_t a, f32x2_t b) {
+  f32x2_t r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2_t ua_pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) {
+  f32x2_t r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float ua_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__global__ __launch_bounds__(256) void upsample_argmax_pk_kernel(const float* lo, long long* labels, int n, int h, int w,
+                                                                 int H, int W, float scale_h, float scale_w, int tiles_x, int tiles_y,
+                                                                 int wr_max, int wc_max) {
+  extern __shared__ __attribute__((aligned(16))) float ua_lds[];
+  float* win = ua_lds;                                   // [window pixel][UA_CHP]
+  float* R = ua_lds + wr_max * wc_max * UA_CHP;          // [window row][UA_TW columns][UA_CHP]
+  const int b = blockIdx.x / (tiles_x * tiles_y);
+  const int t = blockIdx.x - b * tiles_x * tiles_y;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int oy0 = ty * UA_TH, ox0 = tx * UA_TW;
+  const int oy1 = min(oy0 + UA_TH, H) - 1, ox1 = min(ox0 + UA_TW, W) - 1;
+  const int y_lo = lin_weights(oy0, h, H, scale_h).i0, y_hi = lin_weights(oy1, h, H, scale_h).i1;
+  const int x_lo = lin_weights(ox0, w, W, scale_w).i0, x_hi = lin_weights(ox1, w, W, scale_w).i1;
+  const int wr = y_hi - y_lo + 1, wc = x_hi - x_lo + 1, wsz = wr * wc;
+  const int txl = threadIdx.x % UA_TW, tyl = threadIdx.x / UA_TW;      // stage 2: column in the tile, first row (rows tyl + 8 i); stage 1: column, class group
+  const int ox = min(ox0 + txl, W - 1);
+  const LinW wx = lin_weights(ox, w, W, scale_w);
+  const int xa = (wx.i0 - x_lo) * UA_CHP + 4 * tyl, xb = (wx.i1 - x_lo) * UA_CHP + 4 * tyl;
+  const f32x2_t wx0 = {wx.l0, wx.l0}, wx1 = {wx.l1, wx.l1};
+  int ra[UA_PX], rb[UA_PX];
+  f32x2_t l0[UA_PX], l1[UA_PX];
+  float best[UA_PX];
+  int besti[UA_PX];
+#pragma unroll
+  for (int i = 0; i < UA_PX; ++i) {
+    const int oy = min(oy0 + tyl + (256 / UA_TW) * i, H - 1);
+    const LinW wy = lin_weights(oy, h, H, scale_h);
+    ra[i] = ((wy.i0 - y_lo) * UA_TW + txl) * UA_CHP;
+    rb[i] = ((wy.i1 - y_lo) * UA_TW + txl) * UA_CHP;
+    l0[i] = (f32x2_t){wy.l0, wy.l0}; l1[i] = (f32x2_t){wy.l1, wy.l1};
+    best[i] = -INFINITY; besti[i] = 0;                    // all -inf -> index 0, as torch.argmax
+  }
+  __shared__ int nan_seen;
+  const float* p = lo + (long)b * n * h * w;
+  // the window of a chunk, pixel-fastest over the threads (a window row is contiguous in memory): value j of this thread is
+  // (class e / wsz of the chunk, window pixel e % wsz), e = tid + 256 j
+  int pf_src[UA_NPF], pf_dst[UA_NPF], pf_cls[UA_NPF];
+#pragma unroll
+  for (int j = 0; j < UA_NPF; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    const int c = e / wsz, r = e - c * wsz;
+    const int yy = r / wc, xx = r - yy * wc;
+    pf_cls[j] = c < UA_CH ? c : n;                        // beyond the chunk: never fetched
+    pf_src[j] = (c * h + y_lo + yy) * w + x_lo + xx;
+    pf_dst[j] = r * UA_CHP + c;
+  }
+  float pf[UA_NPF];
+  auto fetch = [&](int c0) {
+    const float* q = p + (long)c0 * h * w;
+#pragma unroll
+    for (int j = 0; j < UA_NPF; ++j) pf[j] = c0 + pf_cls[j] < n ? q[pf_src[j]] : 0.f;
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < n; c0 += UA_CH) {
+    __syncthreads();                                      // previous chunk's R / win no longer read
+    if (threadIdx.x == 0) nan_seen = 0;
+#pragma unroll
+    for (int j = 0; j < UA_NPF; ++j)
+      if (pf_cls[j] < UA_CH) win[pf_dst[j]] = pf[j];
+    __syncthreads();
+    if (c0 + UA_CH < n) fetch(c0 + UA_CH);                // in flight under stages 1 and 2
+    // (1) x-interpolation of every window row for the tile's 32 columns: thread = (column txl, classes 4 tyl .. 4 tyl + 3)
+    {
+      bool nanflag = false;
+      const int cls = c0 + 4 * tyl;
+      float* dst = R + txl * UA_CHP + 4 * tyl;
+      const float* q = win;
+      for (int yy = 0; yy < wr; ++yy, q += wc * UA_CHP, dst += UA_TW * UA_CHP) {
+        const f32x4 a = *(const f32x4*)(q + xa), bq = *(const f32x4*)(q + xb);
+        const f32x2_t r01 = ua_pk_fma((f32x2_t){a[0], a[1]}, wx0, ua_pk_mul((f32x2_t){bq[0], bq[1]}, wx1));
+        const f32x2_t r23 = ua_pk_fma((f32x2_t){a[2], a[3]}, wx0, ua_pk_mul((f32x2_t){bq[2], bq[3]}, wx1));
+        f32x4 r = {r01[0], r01[1], r23[0], r23[1]};
+        // classes past n (the last chunk): -inf, never a maximum, never a NaN
+        r[0] = cls + 0 < n ? r[0] : -INFINITY; r[1] = cls + 1 < n ? r[1] : -INFINITY;
+        r[2] = cls + 2 < n ? r[2] : -INFINITY; r[3] = cls + 3 < n ? r[3] : -INFINITY;
+        nanflag |= (r[0] != r[0]) | (r[1] != r[1]) | (r[2] != r[2]) | (r[3] != r[3]);
+        *(f32x4*)dst = r;
+      }
+      if (nanflag) nan_seen = 1;
+    }
+    __syncthreads();
+    if (!nan_seen) {
+      // fast path (no NaN anywhere in this chunk's window): strict > keeps the first maximum
+#pragma unroll
+      for (int g = 0; g < UA_CH / 4; ++g) {                // fully unrolled: the LDS offsets are immediates
+        f32x4 a[UA_PX], bq[UA_PX];
+#pragma unroll
+        for (int i = 0; i < UA_PX; ++i) {                  // the group's eight reads together, then the arithmetic
+          a[i] = *(const f32x4*)(R + ra[i] + 4 * g);
+          bq[i] = *(const f32x4*)(R + rb[i] + 4 * g);
+        }
+        const int base = c0 + 4 * g;
+#pragma unroll
+        for (int i = 0; i < UA_PX; ++i) {
+          const f32x2_t v01 = ua_pk_fma((f32x2_t){a[i][0], a[i][1]}, l0[i], ua_pk_mul((f32x2_t){bq[i][0], bq[i][1]}, l1[i]));
+          const f32x2_t v23 = ua_pk_fma((f32x2_t){a[i][2], a[i][3]}, l0[i], ua_pk_mul((f32x2_t){bq[i][2], bq[i][3]}, l1[i]));
+          const float m = ua_max3(ua_max3(v01[0], v01[1], v23[0]), v23[1], -INFINITY);
+          const bool gt = m > best[i];                     // -inf padding / all -inf: never
+          if (__any(gt)) {                                 // wave-uniform: which of the four it was matters only when some lane's best moved
+            int k = base + 3;
+            k = v23[0] == m ? base + 2 : k;
+            k = v01[1] == m ? base + 1 : k;
+            k = v01[0] == m ? base : k;                    // the FIRST value equal to the group's maximum
+            besti[i] = gt ? k : besti[i];
+            best[i] = gt ? m : best[i];
+          }
+        }
+      }
+    } else {
+      const int nc = min(UA_CH, n - c0);
+      for (int c = 0; c < nc; ++c) {
+#pragma unroll
+        for (int i = 0; i < UA_PX; ++i) {
+          const float v = __fmaf_rn(R[ra[i] + c], l0[i][0], __fmul_rn(R[rb[i] + c], l1[i][0]));
+          // torch.argmax: first maximal index; NaN is treated as maximal (propagates)
+          if (v > best[i] || (v != v && best[i] == best[i])) { best[i] = v; besti[i] = c0 + c; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < UA_PX; ++i) {
+    const int oy = oy0 + tyl + (256 / UA_TW) * i;
+    if (oy < H && ox0 + txl < W) labels[((long)b * H + oy) * W + ox0 + txl] = besti[i];
+  }
+}
+
 extern "C" int zh_upsample_argmax(const float* logits_lo, long long* labels, int B, int n, int h, int w, int H, int W,
                                   float scale_h, float scale_w, hipStream_t stream) {
   ZH_CHECK_ARG(logits_lo && labels && B > 0 && n > 0 && h > 0 && w > 0 && H > 0 && W > 0, "zh_upsample_argmax: bad arguments");
@@ -414,7 +568,13 @@ extern "C" int zh_upsample_argmax(const float* logits_lo, long long* labels, int
   const int wr = (h == H ? UA_TH : (int)(UA_TH * scale_h) + 3), wc = (w == W ? UA_TW : (int)(UA_TW * scale_w) + 3);
   const size_t lds = (size_t)UA_CH * wr * (wc + UA_TW) * sizeof(float);
   const long tiles = (long)B * zh_cdiv(W, UA_TW) * zh_cdiv(H, UA_TH);
-  if (lds <= 48 * 1024 && tiles < (1L << 31)) {           // upsampling by >= ~2.5x; otherwise the direct kernel
+  const size_t lds_pk = (size_t)UA_CHP * wr * (wc + UA_TW) * sizeof(float);
+  static const bool pk_off = [] { const char* e = getenv("ZH_UPSAMPLE_ARGMAX_PK"); return e && atoi(e) == 0; }();   // developer A/B: 0 = the round-2 kernel
+  if (!pk_off && wr * wc <= 64 && lds_pk <= 48 * 1024 && tiles < (1L << 31)) {   // a window of <= 64 low-res pixels (upsampling by >= ~6x at 32 x 32 tiles)
+    const int tiles_y = zh_cdiv(H, UA_TH), tiles_x = zh_cdiv(W, UA_TW);
+    hipLaunchKernelGGL(upsample_argmax_pk_kernel, dim3((unsigned)tiles), dim3(256), lds_pk, stream, logits_lo, labels,
+                       n, h, w, H, W, scale_h, scale_w, tiles_x, tiles_y, wr, wc);
+  } else if (lds <= 48 * 1024 && tiles < (1L << 31)) {    // upsampling by >= ~2.5x; otherwise the direct kernel
     const int tiles_y = zh_cdiv(H, UA_TH), tiles_x = zh_cdiv(W, UA_TW);
     hipLaunchKernelGGL(upsample_argmax_lds_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, logits_lo, labels,
                        n, h, w, H, W, scale_h, scale_w, tiles_x, tiles_y, wr, wc);

@@ -48,11 +48,52 @@ _VIT_ARCHS = {
 
 
 # Where the reference's own ZUTIS class is looked up for the TRAINING branch of main.py (trainer.py:136 back-propagates through
-# forward): this overlay shadows `networks.zutis`, so the original has to be importable under another name.  One line in the launch
-# script does it, BEFORE the overlay's directory is put on sys.path ("Training"):
-#     import networks.zutis as m; sys.modules["zutis_reference_networks_zutis"] = m
-# or set ZUTIS_REFERENCE_MODULE to the dotted name of a module that holds the reference's ZUTIS class.
+# forward): this overlay shadows `networks.zutis`, so the original has to be importable under another name.  The launch script calls
+#     keep_reference_for_training("<reference checkout>/networks/zutis.py")        # once, after `import networks.zutis` (the overlay)
+# (file-copy deployment, where the overlay overwrote networks/zutis.py: keep the original as networks/zutis_reference.py and pass that
+# path, or set ZUTIS_REFERENCE_MODULE=networks.zutis_reference).  The helper loads the FILE under the private module name below and
+# leaves `networks*` / `utils*` in sys.modules exactly as it found them — aliasing by hand (`import networks.zutis as m;
+# sys.modules[...] = m`) needs the `del sys.modules[...]` lines of INTEGRATION.md and still leaves the reference's `utils` cached.
 REFERENCE_MODULE_NAMES = ("zutis_reference_networks_zutis", "zutis_reference.networks.zutis")
+_OVERLAID = ("networks", "networks.zutis", "networks.selfmask", "networks.selfmask.selfmask", "networks.clip_text",
+             "utils", "utils.running_score", "utils.bilateral_solver", "utils.extract_image_embeddings")
+
+
+def keep_reference_for_training(reference_zutis_py: str):
+    """Make the reference's own ZUTIS class available to the training delegate: execute the reference's `networks/zutis.py` FILE under
+    the private name `zutis_reference_networks_zutis`.  While it is imported its sibling imports (`networks.clip_arch`, `networks.transformer`,
+    `networks.positional_embedding`, `utils.iou`, networks/zutis.py:9-12) resolve against the reference checkout that holds the file;
+    afterwards every module name this overlay provides (`networks`, `networks.zutis`, `utils.running_score`, ...) is what it was
+    before the call — the overlay stays the canonical `networks.zutis`, which is asserted.  Returns the reference's class."""
+    import importlib.util
+    path = os.path.abspath(reference_zutis_py)
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    root = os.path.dirname(os.path.dirname(path))
+    mine = sys.modules.get(__name__)
+    saved = {k: sys.modules.pop(k) for k in _OVERLAID if k in sys.modules}
+    path0 = list(sys.path)
+    try:
+        sys.path.insert(0, root)                            # the reference's own networks/ and utils/ packages for ITS imports
+        spec = importlib.util.spec_from_file_location(REFERENCE_MODULE_NAMES[0], path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[REFERENCE_MODULE_NAMES[0]] = mod
+        try:
+            spec.loader.exec_module(mod)
+        except BaseException:
+            del sys.modules[REFERENCE_MODULE_NAMES[0]]
+            raise
+    finally:
+        sys.path[:] = path0
+        for k in _OVERLAID:                                 # the reference's packages of the same names leave; its other modules
+            sys.modules.pop(k, None)                        # (networks.clip_arch, utils.iou, ...) stay cached under their own names
+        sys.modules.update(saved)
+    cls = getattr(mod, "ZUTIS", None)
+    if cls is None or cls is globals().get("ZUTIS") or hasattr(mod, "keep_reference_for_training"):      # (a second copy of THIS file)
+        del sys.modules[REFERENCE_MODULE_NAMES[0]]
+        raise ImportError(f"{path} does not define the reference's ZUTIS class (is it the overlay's file?)")
+    assert mine is None or sys.modules.get(__name__) is mine, "keep_reference_for_training: the overlay must stay the canonical module"
+    return cls
 
 
 def reference_zutis_class():
@@ -286,8 +327,8 @@ class ZUTIS(nn.Module):
                     owner._parameters[leaf] = p
                 else:                                     # a bare Parameter attribute (query_embed = nn.Embedding(...).weight, zutis.py:131-134)
                     setattr(owner, leaf, p)
-            d.text_embeddings = self.text_embeddings
             object.__setattr__(self, "_delegate", d)
+        d.text_embeddings = self.text_embeddings           # every call: update_text_embeddings() re-binds the attribute
         d.train(self.training)
         return d
 

@@ -84,6 +84,38 @@ def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+
+def long_sequence_key_split(items: int, ktiles: int, head_dim: int, x3: bool, out_elems: int) -> int:
+    """Key split (1 .. 8) of a LONG self-attention (SelfMask's DINO ViT-S/8 at 512x683: T = 5505, networks/selfmask/vision_transformer.py:110-133)
+    from a round-quantisation model of zh_attention_f16's grid: `items` = (image, head, 128-query block) workgroups, each walking `ktiles`
+    key tiles.  A CU holds 3 such workgroups (2 for the pipelined split-pair loop and at dh = 96), so 4 images x 6 heads x 44 blocks = 1056
+    workgroups are 1.375 rounds of the chip's 768 slots — two rounds, the second a third full — and ONE image (264 workgroups) leaves
+    every SIMD a single wave with nothing to overlap its softmax with.  Splitting the keys over S workgroups per item (partials merged by
+    attn_combine_kernel) buys finer rounds for one pass over the fp32 partials.  Cost in key-tile times of a full CU:
+    rounds x (chunk + fixed) + a last partial round at the (faster) per-tile time of its occupancy + the merge traffic."""
+    def wpc_of(n):
+        if x3 and (head_dim == 96 or -(-n // 512) <= -(-n // 768)):
+            return 2                                       # the launcher's rule for the software-pipelined loop (attention.hip)
+        return 3 if head_dim == 64 else 2
+    tile_time = {1: 0.78, 2: 0.89, 3: 1.0}                 # per-tile time of a workgroup with 1 / 2 / 3 resident per CU (stamps, profiles/NOTES.md)
+    tile_us = 1.85 if x3 else 0.95                         # one key tile of a workgroup at full occupancy
+    best, best_cost = 1, None
+    for S in range(1, 9):
+        chunk = -(-ktiles // S)
+        if S > 1 and (S - 1) * chunk >= ktiles:
+            continue
+        n = items * S
+        wpc = wpc_of(n)
+        full, rem = divmod(n, 256 * wpc)
+        cost = full * (chunk + 2) * tile_time[wpc]
+        if rem:
+            cost += (chunk + 2) * tile_time[min(wpc, -(-rem // 256))]
+        if S > 1:
+            cost += S * out_elems * 4 * 2 / 3.0e12 * 1e6 / tile_us      # partials written and read once, ~3 TB/s
+        if best_cost is None or cost < best_cost * 0.97:               # a larger split must win by 3 %
+            best, best_cost = S, cost
+    return best
+
 class _EngineBase:
     """Shared plumbing: fp16 weight packing keyed on parameter versions, shape-keyed buffer cache, and the two
     kernel sequences both networks share — pre-LN ViT blocks and the post-norm DETR-style decoder."""
@@ -324,6 +356,8 @@ class _EngineBase:
             per_image = heads * -(-T // 128)
             eks = max(1, min(8, 256 // per_image)) if B * per_image <= 128 else 1      # the split itself does not depend on B
             ktiles = -(-T // (32 if xa else 64))
+            if eks == 1 and T >= 2048:
+                eks = long_sequence_key_split(B * per_image, ktiles, D // heads, xa, B * T * D)
             while eks > 1 and (eks - 1) * -(-ktiles // eks) >= ktiles:
                 eks -= 1
             if eks > 1:
