@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries and bench lines under profiles/ (run on the GPU box from the repo root, e.g.
-#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r05'
+#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r06'
 # then copy gpurun_out/<round>_* into profiles/).  One rocprofv3 --kernel-trace --stats pass per configuration; the PMC traffic
 # passes are the ones bench.py spawns itself (roofline.traffic of the default line).  The headline precision is `exact` (bench.py's
 # default); `fast` is profiled as the second precision.
-R=${1:-r05}
+R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
@@ -31,6 +31,11 @@ python3 tools/b1_joint.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_b1_joint.t
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_bs -- python3 tools/bilateral_prof_run.py 1 > gpurun_out/p_bs.log 2>&1
 f=$(find gpurun_out/p_bs -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${R}_bilateral_b1_kernel_stats.csv
 rm -rf gpurun_out/p_bs
+# the pseudo-label path (SelfMask T = 5505 + solver + resize), batch 4, default precision: per-kernel stats, and the SQ counters of its attention launch
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_sm -- python3 tools/selfmask_prof_run.py 4 exact > gpurun_out/p_sm.log 2>&1
+f=$(find gpurun_out/p_sm -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${R}_selfmask_b4_exact_kernel_stats.csv
+rm -rf gpurun_out/p_sm
+bash tools/attn_pmc.sh ${R}_attention_pmc_selfmask_x3 selfmask4 x3
 python3 bench.py 2> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench.json
 python3 bench.py --workload c4 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c4.json
 python3 bench.py --workload c5 2>> gpurun_out/${R}_bench.err | tail -1 > gpurun_out/${R}_bench_c5.json

@@ -393,6 +393,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   for (;;) {                                  // tiles of this workgroup: one, or (PERS) vb, vb + gridDim.x, ...
   const int vb_next = vb + (int)gridDim.x;
   const bool more = PERS && vb_next < p.total;
+#ifdef ZH_ABL_TAIL_SPLIT      // developer ablation (timing only, results are garbage; round 6): what an IDEAL stream-K / fixed-split tail round could
+  // return — the `rem` tiles of the last, partial round of a persistent launch run rem / gridDim.x of their K slices each, i.e. the round
+  // lasts as long as if its work were spread evenly over every workgroup, with no reduction traffic at all
+  int nk_tile = nk;
+  if (PERS && (int)gridDim.x < p.total) {
+    const int rem = p.total % (int)gridDim.x;
+    if (rem && vb >= p.total - rem) nk_tile = max(2 * DIST, ((nk * rem / (int)gridDim.x) + 1) & ~1);
+  }
+#define nk nk_tile
+#endif
 
   constexpr bool BIGT = SPLIT && BM * BN >= 192 * 256;    // the two-slot (SPLIT = 2: three-slot) big tiles
   static_assert(!SPLIT || K64 || BIGT == (STAGES == 2 || (SPLIT == 2 && STAGES == 3 && BM * BN >= 192 * 256)), "big split-pair tiles: 2 slots (x2: 2 or 3)");
@@ -863,6 +873,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
   }
   }
 
+#ifdef ZH_ABL_TAIL_SPLIT
+#undef nk
+#endif
   ZH_PROBE(2);
   // ---- epilogue: lane owns rows m = ..+(lane&15), 4 consecutive n at 4*(lane>>4).  ACT / VEC are template
   // parameters: a runtime switch unrolled 32x blew the instruction cache (fc GEMM 1.4x slower in the model).
@@ -1016,6 +1029,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : ((WM * WN * TM *
           const int m = m0 + wr * TM * 16 + pass * PR + row;
           const int n = n0 + wc * TN * 16 + ch * (16 / ESZ);
           f32x4 d = *(const f32x4*)(slab + row * RS + ch * 16);
+#ifdef ZH_ABL_SKIP_EPI_STORES  // developer ablation (timing only; round 6): the slab passes stay, the GLOBAL stores of a persistent tile that has a successor
+          if (more) { asm volatile("" :: "v"(d)); continue; }        // go — the most that moving the stores to other waves (wave-specialised roles) could hide
+#endif
           if (m < p.M && n < p.N) {
             // f32 output: the slab holds fp32, the residual joins before the store
             if (BIAS_LATE) d += bias_late;

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void upsample_argmax_pk_kernel(const float* lo
     const int e = threadIdx.x + 256 * j;
     const int c = e / wsz, r = e - c * wsz;
     const int yy = r / wc, xx = r - yy * wc;
-    pf_cls[j] = c < UA_CH ? c : n;                        // beyond the chunk: never fetched
+    pf_cls[j] = c < UA_CH ? c : (1 << 30);                // beyond the chunk: never fetched, never stored
     pf_src[j] = (c * h + y_lo + yy) * w + x_lo + xx;
     pf_dst[j] = r * UA_CHP + c;
   }
