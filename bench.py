@@ -61,6 +61,8 @@ def main():
                     "reference's build_model -> convert_weights leaves there (forces the three-product kernel)")
     ap.add_argument("--c5-layers", type=int, default=24, help="developer (tests): depth of the c5 tower; anything but 24 is not config 5")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight (HIP streams); 1 = eager, one stream")
+    ap.add_argument("--no-cross-ksplit-auto", dest="cross_ksplit_auto", action="store_false",
+                    help="batches with fewer (image, head) pairs than CUs (config 4's 8 images): do NOT split the cross-attention keys by the batch")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the N>1 code path (RCCL group + per-step all-gather) on one rank")
     ap.add_argument("--precision", default=None, choices=["fast", "exact", "f16"],
                     help="engine precision (zutis_amd/engine.py): exact (default, the headline) = every contraction in the f16x3 mode, the "

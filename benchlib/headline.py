@@ -60,6 +60,8 @@ def run(args):
         eng = engines.get(precision)
         if eng is None:
             eng = engines[precision] = ZutisEngine(P, cfg.patch, cfg.dec_heads, precision=precision)
+            if B * cfg.dec_heads < 256 and args.cross_ksplit_auto:
+                eng.cross_ksplit = "auto"      # fewer cross-attention workgroups than CUs (config 4: 8 images): keys split by the batch, engine_base._decoder
         host_x = x.cpu().pin_memory() if h2d else None
         lanes = build_lanes(eng, x, text, S, n, n_lanes, world=world, dist_on=dist_on, h2d=h2d, d2h=d2h)
         torch.cuda.synchronize()
@@ -201,7 +203,7 @@ def run(args):
                                    f"predict(semantic,size=({S},{S}))", "global_batch": world * B, "image_size": S,
                        "n_classes": n, "parallelism": f"dp{world}", "accumulate": "f32", "residual_stream": "f32",
                        "collective": "all_gather(low-res logits) per step, overlapped" if dist_on else "none",
-                       "steps_in_flight": n_lanes, "cross_attention_key_split": ZutisEngine.cross_ksplit, **({"input": "pinned host batch copied in every step (--h2d)"} if args.h2d else {}),
+                       "steps_in_flight": n_lanes, "cross_attention_key_split": eng.cross_ksplit, **({"input": "pinned host batch copied in every step (--h2d)"} if args.h2d else {}),
                        "launch": ("native launch plans, interleaved on %d HIP streams" % n_lanes) if n_lanes > 1 else "eager, 1 stream",
                        "flops_per_image": FLOPS_PER_IMAGE_C2 if (S, n) == (336, 81) else None},
             "model_tflops": round(total_images * FLOPS_PER_IMAGE_C2 / elapsed / 1e12 / world, 1) if (S, n) == (336, 81) else None,

@@ -500,6 +500,36 @@ def test_batch_invariance_full_size(dev, precision, t_mask, t_tok):
     assert 0 <= full["mask_proposals"].min().item() and full["mask_proposals"].max().item() <= 1
 
 
+def test_cross_attention_key_split_by_the_batch_is_opt_in_and_fp32_class(dev):
+    """`engine.cross_ksplit = "auto"` (bench.py's config-4 runs: fewer (image, head) pairs than CUs) splits the cross-attention keys by the
+    batch: 2 images x 8 heads -> a split of 8 (1024 keys); the outputs are those of the default (unsplit) engine to fp32 re-association,
+    and the default engine is untouched (equal rank shards must reproduce a batch bit for bit)."""
+    from zutis_amd import detgen
+    cfg = detgen.VIT_B16
+    eng = _engine(cfg, dev, "exact")
+    assert eng.cross_ksplit == 1
+    x = torch.from_numpy(detgen.images(2, 256, 256, seed=12)).to(dev)            # 16 x 16 patches -> 1024 memory tokens: the split's threshold
+    from zutis_amd import _lib
+
+    def counted(e):
+        counts = {}
+        _lib.COUNTER = counts
+        try:
+            o = {k: v.clone() for k, v in e.forward(x).items()}
+        finally:
+            _lib.COUNTER = None
+        return o, counts.get("zh_attention_f16_splitk", 0)
+    ref, n_ref = counted(eng)
+    auto = eng.fork()
+    auto.cross_ksplit = "auto"
+    out, n_auto = counted(auto)
+    assert n_auto - n_ref == cfg.dec_layers        # every decoder layer's cross-attention took the split form (the two-image encoder splits its keys either way)
+    assert float((out["mask_proposals"] - ref["mask_proposals"]).abs().max()) < 2e-5
+    assert float((out["patch_tokens"] - ref["patch_tokens"]).abs().max()) < 2e-6
+    again = eng.forward(x)
+    assert torch.equal(again["patch_tokens"], ref["patch_tokens"])             # the parent engine keeps its own (unsplit) arithmetic
+
+
 def test_launch_plan_refuses_stale_weights(dev):
     from zutis_amd import detgen, _lib
     cfg = detgen.TINY

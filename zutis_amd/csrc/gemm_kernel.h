@@ -1125,8 +1125,13 @@ static void launch_one(GemmArgs p, int batch, hipStream_t stream) {
   // them; never with pos tables (their slice is staged through the ring slot the next tile's prologue would use)
   constexpr bool PERS = !SPLIT && WM * WN == 8 && STAGES == 4 && VEC == 2 && (OUT == 1 || TN == 3);
   if (PERS) {
-    const int cus = gemm_persist_cus();                    // 256; developer override: 0 = off, n = a grid of n workgroups (multiple of 8)
+    const int cus = gemm_persist_cus();                    // the device's CUs; developer override: 0 = off, n = a grid of n workgroups (multiple of 8)
     if (cus > 0 && !p.pos_y && nblk > (unsigned)cus) nblk = (unsigned)cus;
+    // (Round 6, measured and removed: staggered starts — eight start phases per XCD, up to 7/8 of a tile apart, for the persistent walks
+    //  and, in a second pass, for the first round of every multi-round big-tile launch — so that the CUs' epilogue bursts (fp16 tiles: 128 KB
+    //  of stores; fp32 + residual: 256 KB in + 256 KB out, 9.6 TB/s chip-wide if all CUs are in them at once) do not coincide round
+    //  after round: config 5 at 6 layers 29.7 - 30.1 ms without, 29.7 - 30.3 with; profiles/r06_gemm_stagger_ab.txt.  What the
+    //  epilogue costs is not the coincidence of the bursts.)
   }
   hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, STAGES, OUT, ACT, VEC, SPLIT>), dim3(nblk), dim3(64 * WM * WN), 0, stream, p);
 }

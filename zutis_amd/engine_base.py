@@ -448,7 +448,13 @@ class _EngineBase:
         # i's result is bitwise independent of its position in the batch and of the other images, and bitwise equal across batch sizes that
         # fall on the same side of the shape thresholds of DESIGN 3b (split-K rows, key-split items, skinny rows); across a threshold the
         # sums are re-associated: ~1e-7 on tokens, ~5e-7 on masks (tests/test_e2e_gpu.py::test_batch_invariance_full_size).
-        ksplit = self.cross_ksplit if (Q <= 128 and M >= 1024) else 1
+        cs = self.cross_ksplit
+        if cs == "auto":
+            # opt-in (round 6; bench.py's config-4 runs: 8 images x 8 heads = 64 workgroups of 171 key tiles on 256 CUs): the split that
+            # puts about one workgroup on every CU.  It depends on the BATCH, so results are re-associated between batch sizes (~1e-7) —
+            # which is why it is not the default: equal rank shards must reproduce the single-GPU batch bit for bit
+            cs = max(1, min(8, 256 // max(1, B * heads)))
+        ksplit = cs if (Q <= 128 and M >= 1024) else 1
         ktiles = -(-M // (32 if xk else 64))               # key tiles of the kernel (32 keys for split pairs, 64 for fp16)
         while ksplit > 1 and (ksplit - 1) * -(-ktiles // ksplit) >= ktiles:
             ksplit -= 1                                    # the largest split that leaves no workgroup without keys (a function of M only)
