@@ -39,6 +39,14 @@ def test_default_workload_line_contract(dev):
     assert d["c4"]["timed_outputs_bitwise_equal_eager"] is True and d["c4"]["parity"]["logit_max_abs_err"] < 2e-5 and d["c4"]["value"] > 0
     assert d["c5"]["precision"] == "fast" and d["c5"]["parity"]["embedding_max_abs_err"] < 1e-3 and d["c5"]["roofline"]["peak"] == 2500.0
     assert d["bilateral_solver"]["batch1"]["ms_per_image"] > 0 and d["pseudo_labels"]["value"] > 0 and d["batch1"]["parity"]["category_list_identical"]
+    # the pseudo-label path is measured like the headline (round 6): roofline of its dominant kernel, parity of the final mask against the
+    # oracle chain, a bounded CPU baseline
+    pl = d["pseudo_labels"]
+    assert pl["roofline"]["bound"] == "mfma" and "attn_f16_kernel" in pl["roofline"]["kernel"] and 0.15 < pl["roofline"]["frac"] < 1.0
+    assert abs(pl["roofline"]["frac"] - pl["roofline"]["achieved"] / pl["roofline"]["peak"]) < 1e-3
+    assert pl["parity"]["differing_pixels_off_the_oracle_contour"] == 0 and pl["parity"]["differing_pixels"] <= 200
+    assert pl["parity"]["selected_query_identical"] is True and pl["cpu_baseline"]["kind"] == "port" and pl["cpu_baseline"]["value"] > 0
+    assert pl["value_noise_images"] > 0 and "natural" in pl["images"]
     assert list(d)[-1] == "summary" and len(json.dumps(d["summary"])) < 1500
     s = d["summary"]
-    assert s["checked"] is True and s["c4"]["ok"] is True and "c5_fast" in s and "solver_ms" in s and "b1_ms" in s
+    assert s["checked"] is True and s["c4"]["ok"] is True and "c5_fast" in s and "solver_ms" in s and "b1_ms" in s and s["pseudo"]["bad_px"] == 0

@@ -122,3 +122,35 @@ def test_label_mismatch_explanation_helper():
     bad = ref.copy()
     bad[0, y, x] = int(np.argmin(full[:, y, x]))
     assert unexplained_label_mismatches(bad, ref, lo, 1e-4, (80, 112))[1] == 1
+
+
+def test_long_sequence_key_split_model():
+    """engine_base.long_sequence_key_split (round 6): the split is 1 .. 8, never leaves a workgroup without keys, takes 1 when the grid
+    already fills whole rounds of the chip, and splits when the launch is one under-filled round (SelfMask at T = 5505: one image = 264
+    workgroups on 256 CUs; four images = 1.375 rounds of 768 slots) — the picks measured in profiles/r06_attn_long_split.txt."""
+    from zutis_amd.engine_base import long_sequence_key_split as f
+    T, H, dh = 5505, 6, 64
+    nqb = -(-T // 128)
+    picks = {B: f(B * H * nqb, -(-T // 32), dh, True, B * T * H * dh) for B in (1, 2, 4, 8)}
+    assert picks == {1: 5, 2: 4, 4: 2, 8: 1}, picks
+    for B in (1, 2, 3, 4, 5, 8, 16):
+        for x3 in (True, False):
+            kt = -(-T // (32 if x3 else 64))
+            S = f(B * H * nqb, kt, dh, x3, B * T * H * dh)
+            assert 1 <= S <= 8 and (S == 1 or (S - 1) * -(-kt // S) < kt)
+    assert f(768 * 4, 173, 64, True, 10 ** 9) == 1              # whole rounds already: nothing to gain, the merge only costs
+    assert f(96, 300, 96, True, 10 ** 6) > 1                    # dh = 96: two workgroups per CU, 96 items leave most CUs idle
+
+
+def test_natural_images_are_deterministic_and_normalised():
+    """benchlib.objects.natural_images (the pseudo-label bench / tests workload): the same tensor every time, ImageNet-normalised u8 values."""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    a = bench.natural_images(2, 40, 56, "cpu", seed=7)
+    b = bench.natural_images(2, 40, 56, "cpu", seed=7)
+    assert a.shape == (2, 3, 40, 56) and a.dtype == torch.float32 and torch.equal(a, b) and not torch.equal(a[0], a[1])
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    u8 = (a * std + mean) * 255.0
+    assert float((u8 - u8.round()).abs().max()) < 1e-3 and 0 <= float(u8.min()) and float(u8.max()) <= 255.001
