@@ -1,13 +1,10 @@
 """`bench.py --workload c5`: BASELINE config 5, the full line."""
 from __future__ import annotations
 
-import contextlib
 import json
 import os
-import sys
 import time
 
-import numpy as np
 import torch
 
 from .common import PRECISION_DTYPE, PRECISION_TEXT

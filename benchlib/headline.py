@@ -32,7 +32,6 @@ def run(args):
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # nccl == RCCL on ROCm
 
     from zutis_amd import detgen, ops
-    from zutis_amd import plan as zplan
     from zutis_amd import distributed as zd
     from zutis_amd.engine import ZutisEngine
 

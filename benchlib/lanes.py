@@ -2,12 +2,7 @@
 from __future__ import annotations
 
 import contextlib
-import json
-import os
-import sys
-import time
 
-import numpy as np
 import torch
 
 

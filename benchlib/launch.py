@@ -1,13 +1,10 @@
 """`python bench.py --gpus N` without a rank environment: N ranks as a child process tree."""
 from __future__ import annotations
 
-import contextlib
 import json
 import os
 import sys
-import time
 
-import numpy as np
 import torch
 
 from .common import BENCH_PY

@@ -1,10 +1,7 @@
 """Bounded objects of the default line: the other BASELINE configs (c4, c5), the bilateral solver and the pseudo-label path."""
 from __future__ import annotations
 
-import contextlib
-import json
 import os
-import sys
 import time
 
 import numpy as np

@@ -2,13 +2,9 @@
 counter passes (two child runs of bench.py)."""
 from __future__ import annotations
 
-import contextlib
-import json
 import os
 import sys
-import time
 
-import numpy as np
 import torch
 
 from .common import BENCH_PY, MFMA_F16_DENSE_PEAK_TFLOPS
