@@ -230,6 +230,9 @@ def run(args):
                 line["second_precision"]["vs_torch_gpu_fp32_eager"] = round(other["value"] / torch_gpu["value"], 2)
         # LAST key, compact (the driver keeps the last ~2000 characters of stdout): the numbers of every object above, no prose
         sm = {"c2_" + args.precision: line["value"], "frac": roof["frac"] if roof else None, "checked": line["timed_outputs_checked"]}
+        if collective is not None:   # N > 1 (or --force-dist): the proof that the gather saw every rank, in the part of the line the driver keeps
+            sm["coll"] = {"ranks": collective["ranks_in_gather"], "ok": bool(collective["verified"] and collective["gathers_retired_in_timed_region"] == args.steps),
+                          "distinct": collective["slices_distinct"], "exposed_ms": collective["gather_ms_exposed"], "rank_ips": collective["per_rank_images_per_s"]}
         if parity:
             sm["c2_err"] = float("%.2g" % parity["logit_max_abs_err"]); sm["c2_bad_labels"] = parity["unexplained_label_mismatches"]
         if other is not None:

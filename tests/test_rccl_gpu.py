@@ -70,3 +70,4 @@ def test_rccl_one_rank_bench_headline_force_dist(dev):
     assert abs(c["gather_ms_exposed"]) < 0.06 * d["ms_per_step"], c
     assert abs(c["ms_per_step_without_gather"] - d["ms_per_step"]) < 0.06 * d["ms_per_step"], (c, d["ms_per_step"])
     assert c["per_rank_images_per_s"]["min"] <= d["value"] * 1.001 and c["per_rank_images_per_s"]["max"] >= c["per_rank_images_per_s"]["min"]
+    assert d["summary"]["coll"]["ok"] is True and d["summary"]["coll"]["ranks"] == 1 and list(d)[-1] == "summary"
