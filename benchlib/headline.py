@@ -151,7 +151,7 @@ def run(args):
                             row["traffic_over_algorithmic"] = round(b / c / algo, 2) if algo else None
         if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 2)
-        roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r05_bench_%s_kernel_stats.csv"
+        roof["measured_on"] += ("; rocprofv3 --kernel-trace --stats of `bench.py --inflight 1` (this precision) = profiles/r06_bench_%s_kernel_stats.csv"
                                 % args.precision)
 
     # ---- CPU baseline: the oracle (CPU port of the reference path) on a bounded sample, rank 0 at N=1 only
