@@ -64,22 +64,26 @@ def pseudo_label_object(dev, precision="exact", B=4, reps=5, cpu=True, cpu_threa
     eng = SelfMaskEngine({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, precision=precision)
 
     def timed(x):
+        n = x.shape[0]
         for _ in range(2):
-            pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * B, True)
+            pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * n, True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            masks = pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * B, True)
+            masks = pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * n, True)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps, masks
     x = natural_images(B, H, W, dev)
     dt, masks = timed(x)
     roof = attention_roofline(ops, lambda: pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * B, True), dt)
     dt_noise, _ = timed(torch.from_numpy(detgen.images(B, H, W, seed=7)).to(dev))
+    dt8, _ = timed(natural_images(8, H, W, dev))             # the dataset driver's own default group size (pseudo_masks.dataset_generate_pseudo_masks batch_size=8)
     obj = {"what": f"SelfMask (DINO ViT-S/8 @{H}x{W}, T = 5505) + bilateral solver + threshold + nearest resize to {out_size[0]}x{out_size[1]}, "
                    f"{B} images per call, device side (datasets/index_dataset.py:177-226)",
            "value": round(B / dt, 1), "unit": "images/s", "ms_per_call": round(dt * 1e3, 2), "batch": B, "precision": precision, "calls": reps,
            "images": "natural colour statistics (detgen.selfmask_like_rgb, normalised): ~20 k lattice vertices per image",
+           "value_batch8": round(8 / dt8, 1),
+           "value_batch8_note": "8 images per call: the default group size of the dataset-signature driver (pseudo_masks.dataset_generate_pseudo_masks)",
            "value_noise_images": round(B / dt_noise, 1),
            "value_noise_images_note": "the workload rounds 2-5 quoted: N(0,1) images give the solver one lattice vertex per pixel (17x a photograph's)",
            "model_tflops": round(B * SELFMASK_FLOPS_PER_IMAGE / dt / 1e12, 1), "flops_per_image": SELFMASK_FLOPS_PER_IMAGE, "roofline": roof}
