@@ -258,7 +258,7 @@ def run(args):
             sm["solver_ms"] = [solvero["batch1"]["ms_per_image"], solvero["batch8"]["ms_per_image"]]
             sm["solver_frac"] = [solvero["batch1"]["frac"], solvero["batch8"]["frac"]]
         if pseudoo:
-            sm["selfmask_solver_ips"] = [pseudoo["value"], pseudoo["value_batch8"]]
+            sm["selfmask_solver_ips"] = {"b4": pseudoo["value"], "b8": pseudoo["value_batch8"], "b1": pseudoo["value_batch1"]}
             sm["pseudo"] = {"frac": pseudoo["roofline"]["frac"], **({"bad_px": pseudoo["parity"]["differing_pixels_off_the_oracle_contour"],
                                                                     "diff_px": pseudoo["parity"]["differing_pixels"]} if "parity" in pseudoo else {})}
         if io_rates:

@@ -78,10 +78,13 @@ def pseudo_label_object(dev, precision="exact", B=4, reps=5, cpu=True, cpu_threa
     roof = attention_roofline(ops, lambda: pseudo_masks.pseudo_masks_batch(eng, x, [out_size] * B, True), dt)
     dt_noise, _ = timed(torch.from_numpy(detgen.images(B, H, W, seed=7)).to(dev))
     dt8, _ = timed(natural_images(8, H, W, dev))             # the dataset driver's own default group size (pseudo_masks.dataset_generate_pseudo_masks batch_size=8)
+    dt1, _ = timed(x[:1].contiguous())                       # ONE image per call: the reference's own loop (datasets/index_dataset.py:187-204, DataLoader batch_size=1)
     obj = {"what": f"SelfMask (DINO ViT-S/8 @{H}x{W}, T = 5505) + bilateral solver + threshold + nearest resize to {out_size[0]}x{out_size[1]}, "
                    f"{B} images per call, device side (datasets/index_dataset.py:177-226)",
            "value": round(B / dt, 1), "unit": "images/s", "ms_per_call": round(dt * 1e3, 2), "batch": B, "precision": precision, "calls": reps,
            "images": "natural colour statistics (detgen.selfmask_like_rgb, normalised): ~20 k lattice vertices per image",
+           "value_batch1": round(1 / dt1, 1),
+           "value_batch1_note": "ONE image per call, as the reference's generate_pseudo_masks loops (DataLoader batch_size=1, datasets/index_dataset.py:187-204)",
            "value_batch8": round(8 / dt8, 1),
            "value_batch8_note": "8 images per call: the default group size of the dataset-signature driver (pseudo_masks.dataset_generate_pseudo_masks)",
            "value_noise_images": round(B / dt_noise, 1),
